@@ -1,0 +1,170 @@
+/*
+ * teeline_gpu.h — C ABI of libteeline_gpu.so: the MI355X (gfx950) local-search engine that slots in
+ * behind the solver entry points of the `teeline` Rust crate (timgluz/teeline).
+ *
+ * The reference has NO FFI and no Solver trait; its plug-in boundary is three free
+ * functions of identical shape selected by a `match`:
+ *     two_opt::solve / three_opt::solve / lin_kernighan::solve
+ *         (&TspProblem, &Options, Option<&Sender<ProgressMessage>>, Option<&[usize]>) -> Solution
+ *     reference: src/tsp/two_opt.rs:7-12, src/tsp/three_opt.rs:16-21, src/tsp/lin_kernighan.rs:35-40,
+ *                dispatch src/tsp/mod.rs:1690-1694,1718,1719.
+ * Each entry point below is what a Rust `extern "C"` block binds to replace the body
+ * of one of those functions or of a helper they call.  Plain pointers and sizes only.
+ *
+ * Conventions
+ *  - Tours are POSITIONS: indices 0..n-1 into the caller's city array (the reference maps
+ *    id<->position with HashMaps at every distance lookup, distance_matrix.rs:197-212; the shim does
+ *    that once at the boundary).  u32 is enough: n <= 2^32-1.
+ *  - `xy` is n x 2 f32 row-major in city order (KDPoint.coords, kdtree.rs:248-252).
+ *  - `dm_packed` (optional) is the reference's packed strict-lower-triangle matrix, n(n-1)/2 f32,
+ *    idx(i>j) = i(i-1)/2 + j (distance_matrix.rs:122-153,186).  Pass it for EXPLICIT / GEO problems;
+ *    NULL means EUC_2D computed on the fly from xy with the reference's exact f32 arithmetic
+ *    (sqrtf(dx*dx+dy*dy), no FMA; kdtree.rs:291-295).
+ *  - All host pointers are borrowed for the duration of the call only.  A tl_ctx is single-threaded;
+ *    distinct contexts are independent (own HIP stream and workspace) — the reference calls solvers
+ *    from arbitrary threads (teeline-api tsp_service.rs:295,328), so create one context per thread.
+ *  - Return value: TL_OK (0) or a negative tl_status; tl_last_error(ctx) has the message.
+ *  - There is NO CPU fallback: every compute entry point fails with TL_ERR_NO_DEVICE / TL_ERR_HIP when
+ *    no gfx950 device is usable.
+ */
+#ifndef TEELINE_GPU_H
+#define TEELINE_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TL_ABI_VERSION 1
+
+typedef struct tl_ctx tl_ctx;
+
+typedef enum tl_status {
+    TL_OK = 0,
+    TL_ERR_BADARG = -1,      /* NULL pointer, n out of range, init tour not a permutation, ...        */
+    TL_ERR_REF_PANICS = -2,  /* input on which the reference itself panics (e.g. 2-opt with n < 3,     */
+                             /* two_opt.rs:17,29 usize underflow); the shim turns this into panic!()   */
+    TL_ERR_NO_DEVICE = -3,   /* no HIP device / not gfx950                                             */
+    TL_ERR_HIP = -4,         /* a HIP runtime call failed                                              */
+    TL_ERR_NOMEM = -5,       /* device or host allocation failed                                       */
+    TL_ERR_UNSUPPORTED = -6, /* size/mode combination this build cannot run                            */
+    TL_ERR_NO_CONVERGE = -7  /* safety cap on sweeps hit (the reference would still be looping)        */
+} tl_status;
+
+/* 2-opt evaluation order */
+typedef enum tl_mode {
+    /* The reference's algorithm: first-improvement, in place, lexicographic (i,j), open path
+     * (two_opt.rs:26-61).  Tours are bit-identical to the reference's.  Default. */
+    TL_MODE_REF_ORDER = 0,
+    /* This build's own throughput mode: per sweep evaluate every (i,j), apply the single best
+     * improving move (lowest f32 delta, lowest linear index on ties), repeat.  NOT the reference's
+     * algorithm; parity-checked against oracle/tlo_two_opt_best. */
+    TL_MODE_BEST_SWEEP = 1
+} tl_mode;
+
+/* tl_create flags */
+#define TL_FLAG_NONE 0u
+/* Evaluate every candidate with two fresh correctly-rounded sqrt distances instead of the exact
+ * squared-distance pre-test (see DESIGN.md "Exact pruning").  Results are identical; only speed
+ * changes.  Used by bench.py to report the un-pruned rate next to the default one. */
+#define TL_FLAG_NO_PRUNE 1u
+
+/* matrix layouts for tl_dm_build */
+#define TL_DM_PACKED_LOWER 0 /* reference layout, n(n-1)/2 floats (distance_matrix.rs:122-153) */
+#define TL_DM_FULL 1         /* n x n row-major, zero diagonal (coalesced row gathers)           */
+
+/* distance function for tl_dm_build */
+#define TL_DIST_EUC2D 0 /* kdtree.rs:291-295            */
+#define TL_DIST_GEO 1   /* distance_matrix.rs:59-75     */
+
+typedef struct tl_stats {
+    uint64_t sweeps;     /* 2-opt: `while improved` iterations; 3-opt: passes; LK: lk_pass scans      */
+    uint64_t candidates; /* candidates whose delta test was decided, counted as the reference's loop  */
+                         /* visits them: 2-opt REF_ORDER/BEST_SWEEP = sweeps * (n-3)(n-2)/2            */
+    uint64_t moves;      /* improving moves applied                                                    */
+    uint64_t reversed;   /* tour elements moved by segment reversals                                   */
+    double kernel_ms;    /* device time of the solver kernel(s), HIP events on the context's stream   */
+    double total_ms;     /* wall time of the whole call incl. transfers                                */
+} tl_stats;
+
+typedef struct tl_lk_opts { /* LKOptions, src/tsp/mod.rs:1249-1267 */
+    uint32_t epochs;        /* default 100 (10000 from the CLI, mod.rs:596-613,1321-1325) */
+    uint32_t platoo_epochs; /* default 10                                                   */
+    uint32_t n_nearest;     /* default 5                                                    */
+    uint32_t max_depth;     /* default 5                                                    */
+} tl_lk_opts;
+
+/* ---- context ------------------------------------------------------------------------------- */
+int tl_abi_version(void);
+const char *tl_version(void);
+/* device: HIP ordinal (one process per GPU: pass LOCAL_RANK). */
+int tl_create(int device, uint32_t flags, tl_ctx **out);
+void tl_destroy(tl_ctx *ctx);
+const char *tl_last_error(const tl_ctx *ctx); /* ctx may be NULL: last tl_create failure */
+/* CU count, LDS bytes per workgroup and arch name of the context's device. */
+int tl_device_info(const tl_ctx *ctx, int *cus, int *lds_bytes, char *arch, size_t arch_len);
+/* Largest n the LDS-resident REF_ORDER 2-opt kernel takes (tour + coordinates live in one CU's LDS). */
+uint32_t tl_two_opt_lds_max_n(const tl_ctx *ctx);
+
+/* ---- distance matrix: replaces DistanceMatrix::build (distance_matrix.rs:122-153) ----------- */
+/* out_host may be NULL (matrix stays on the device for later calls on this context). */
+int tl_dm_build(tl_ctx *ctx, const float *xy, uint32_t n, int dist, int layout, float *out_host,
+                double *kernel_ms);
+
+/* ---- tour cost: replaces DistanceMatrix::tour_length_by_pos (distance_matrix.rs:235-245) ---- */
+/* total = d(last,first), then += d(w0,w1) in tour order (sequential f32, bit-exact). */
+int tl_tour_length(tl_ctx *ctx, const float *xy, const float *dm_packed, uint32_t n,
+                   const uint32_t *perm, float *out_cost);
+
+/* ---- 2-opt: replaces two_opt::solve (two_opt.rs:7-67) ---------------------------------------- */
+/* init_pos NULL = city order (two_opt.rs:18-20).  out_pos: n entries.  out_cost = tour_length(out_pos)
+ * as Solution::from_parts computes it (mod.rs:1776-1789). */
+int tl_two_opt(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed,
+               const uint32_t *init_pos, int mode, uint32_t *out_pos, float *out_cost,
+               tl_stats *stats);
+
+/* ---- 3-opt: replaces three_opt::solve (three_opt.rs:16-51) ---------------------------------- */
+int tl_three_opt(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed,
+                 const uint32_t *init_pos, uint32_t *out_pos, float *out_cost, tl_stats *stats);
+/* One find_best_move scan (three_opt.rs:58-131).  *found = 0/1; (i,j,k,case,savings) as the reference. */
+int tl_three_opt_find_best_move(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed,
+                                const uint32_t *path, int *found, uint32_t *i, uint32_t *j,
+                                uint32_t *k, int *kase, float *savings);
+
+/* ---- Lin–Kernighan: replaces lin_kernighan::solve (lin_kernighan.rs:35-100) ----------------- */
+/* seed drives the double-bridge kicks (the reference uses an unseeded thread RNG, :73). */
+int tl_lk(tl_ctx *ctx, const float *xy, uint32_t n, const uint32_t *init_pos, const tl_lk_opts *opts,
+          uint64_t seed, uint32_t *out_pos, float *out_cost, tl_stats *stats);
+
+/* ---- multi-start 2-opt (north-star config 4; no counterpart in the reference) ---------------- */
+/* Runs restarts [first, first+count) — restart r starts from the Fisher–Yates permutation drawn
+ * from splitmix64(seed + r) (specification: DESIGN.md / oracle tlo_restart_perm) — one descent per
+ * workgroup, all concurrently.  Returns the best tour of this shard; out_costs (count floats,
+ * optional) gets every restart's final cost.  Ranks shard [0,R) between themselves and min-reduce
+ * tl_pack_cost_key(best_cost, best_restart) with RCCL. */
+int tl_two_opt_multistart(tl_ctx *ctx, const float *xy, uint32_t n, uint64_t seed, uint32_t first,
+                          uint32_t count, int mode, uint32_t *out_best_pos, float *out_best_cost,
+                          uint32_t *out_best_restart, float *out_costs, tl_stats *stats);
+/* (float_bits(cost) << 32) | restart: order-preserving for cost >= 0, ties -> lowest restart. */
+uint64_t tl_pack_cost_key(float cost, uint32_t restart);
+
+/* ---- device-resident batch entry (bench / pipelines that keep data in HBM) ------------------- */
+/* All d_* are DEVICE pointers on the context's device.  d_init: count x n u32 (NULL: seeded restarts
+ * first..first+count as above; seed ignored otherwise).  d_out_pos: count x n u32, d_out_cost: count f32,
+ * d_out_stats: count x 4 u64 {sweeps, moves, reversed, status}.  stream: hipStream_t or NULL for the
+ * context's stream.  Asynchronous: returns after enqueueing. */
+int tl_two_opt_batch_dev(tl_ctx *ctx, const float *d_xy, uint32_t n, const uint32_t *d_init,
+                         uint64_t seed, uint32_t first, uint32_t count, int mode, uint32_t *d_out_pos,
+                         float *d_out_cost, uint64_t *d_out_stats, void *stream);
+/* Device time (ms) between the start and end of the most recent *_dev / solver kernel sequence on
+ * this context, from HIP events recorded on the launch stream.  Synchronises on the end event. */
+int tl_last_kernel_ms(tl_ctx *ctx, double *ms);
+int tl_dm_build_dev(tl_ctx *ctx, const float *d_xy, uint32_t n, int dist, int layout, float *d_out,
+                    void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEELINE_GPU_H */

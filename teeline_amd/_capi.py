@@ -1,0 +1,91 @@
+"""ctypes loader for libteeline_gpu.so — the C ABI declared in include/teeline_gpu.h.
+
+The library is the product; this module only binds it.  There is no CPU fallback anywhere in this
+package: if the shared object is missing or no gfx950 device is usable, calls raise.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libteeline_gpu.so")
+
+TL_OK = 0
+TL_ERR_BADARG, TL_ERR_REF_PANICS, TL_ERR_NO_DEVICE, TL_ERR_HIP = -1, -2, -3, -4
+TL_ERR_NOMEM, TL_ERR_UNSUPPORTED, TL_ERR_NO_CONVERGE = -5, -6, -7
+TL_MODE_REF_ORDER, TL_MODE_BEST_SWEEP = 0, 1
+TL_FLAG_NONE, TL_FLAG_NO_PRUNE = 0, 1
+TL_DM_PACKED_LOWER, TL_DM_FULL = 0, 1
+TL_DIST_EUC2D, TL_DIST_GEO = 0, 1
+
+# every symbol include/teeline_gpu.h declares (tests/test_abi.py checks header <-> library <-> this list)
+SYMBOLS = [
+    "tl_abi_version", "tl_version", "tl_create", "tl_destroy", "tl_last_error", "tl_device_info",
+    "tl_two_opt_lds_max_n", "tl_dm_build", "tl_tour_length", "tl_two_opt", "tl_three_opt",
+    "tl_three_opt_find_best_move", "tl_lk", "tl_two_opt_multistart", "tl_pack_cost_key",
+    "tl_two_opt_batch_dev", "tl_last_kernel_ms", "tl_dm_build_dev",
+]
+
+
+class TlStats(C.Structure):
+    _fields_ = [("sweeps", C.c_uint64), ("candidates", C.c_uint64), ("moves", C.c_uint64),
+                ("reversed", C.c_uint64), ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class TlLkOpts(C.Structure):
+    _fields_ = [("epochs", C.c_uint32), ("platoo_epochs", C.c_uint32), ("n_nearest", C.c_uint32),
+                ("max_depth", C.c_uint32)]
+
+
+class TeelineGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libteeline_gpu error {code}: {msg}")
+        self.code = code
+
+
+class ReferencePanics(TeelineGpuError):
+    """Input on which the reference solver itself panics (e.g. two_opt with n < 3)."""
+
+
+_lib = None
+
+
+def load():
+    """Load libteeline_gpu.so.  Raises if it has not been built — never falls back to a CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -m teeline_amd.build` (hipcc, gfx950). "
+            "teeline_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32, f32p = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_float)
+    L.tl_abi_version.restype = i32
+    L.tl_version.restype = C.c_char_p
+    L.tl_create.argtypes = [i32, u32, C.POINTER(vp)]
+    L.tl_destroy.argtypes = [vp]
+    L.tl_destroy.restype = None
+    L.tl_last_error.argtypes = [vp]
+    L.tl_last_error.restype = C.c_char_p
+    L.tl_device_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.c_char_p, C.c_size_t]
+    L.tl_two_opt_lds_max_n.argtypes = [vp]
+    L.tl_two_opt_lds_max_n.restype = u32
+    L.tl_dm_build.argtypes = [vp, vp, u32, i32, i32, vp, C.POINTER(C.c_double)]
+    L.tl_tour_length.argtypes = [vp, vp, vp, u32, vp, f32p]
+    L.tl_two_opt.argtypes = [vp, vp, u32, vp, vp, i32, vp, f32p, C.POINTER(TlStats)]
+    L.tl_three_opt.argtypes = [vp, vp, u32, vp, vp, vp, f32p, C.POINTER(TlStats)]
+    L.tl_three_opt_find_best_move.argtypes = [vp, vp, u32, vp, vp, C.POINTER(i32), C.POINTER(u32),
+                                              C.POINTER(u32), C.POINTER(u32), C.POINTER(i32), f32p]
+    L.tl_lk.argtypes = [vp, vp, u32, vp, C.POINTER(TlLkOpts), u64, vp, f32p, C.POINTER(TlStats)]
+    L.tl_two_opt_multistart.argtypes = [vp, vp, u32, u64, u32, u32, i32, vp, f32p, C.POINTER(u32), vp,
+                                        C.POINTER(TlStats)]
+    L.tl_pack_cost_key.argtypes = [C.c_float, u32]
+    L.tl_pack_cost_key.restype = u64
+    L.tl_two_opt_batch_dev.argtypes = [vp, vp, u32, vp, u64, u32, u32, i32, vp, vp, vp, vp]
+    L.tl_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_double)]
+    L.tl_dm_build_dev.argtypes = [vp, vp, u32, i32, i32, vp, vp]
+    _lib = L
+    return L

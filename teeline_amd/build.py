@@ -1,0 +1,58 @@
+"""Builds libteeline_gpu.so (hipcc, gfx950 only) in-tree next to this file.
+
+`python -m teeline_amd.build` or `teeline_amd.build.build()`; __graft_entry__.build() calls this.
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels with the tree to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "libteeline_gpu.so")
+
+SOURCES = ["tl_api.hip", "two_opt_ref.hip", "two_opt_dm.hip", "dm_build.hip"]
+HEADERS = ["tl_device.h", "tl_kernels.h", os.path.join(ROOT, "include", "teeline_gpu.h")]
+
+# -ffp-contract=off: the reference never fuses mul+add (src/tsp/kdtree.rs:291-295); bit-exact parity
+# depends on it.  Correctly rounded sqrt/div is hipcc's default and is spelled out here on purpose.
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
+    "-fno-gpu-rdc",
+    "-Wall", "-Wno-unused-function",
+]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found — libteeline_gpu cannot be built (there is no CPU fallback)")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    deps.append(os.path.abspath(__file__))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    if not force and not needs_build():
+        return LIB
+    cmd = [_hipcc()] + FLAGS + list(extra_flags) + ["-I", os.path.join(ROOT, "include"), "-o", LIB + ".tmp"]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,427 @@
+// tl_api.hip — host side of the C ABI declared in include/teeline_gpu.h.
+//
+// A tl_ctx owns one HIP stream, a grow-only device workspace and a pair of HIP events; every entry
+// point validates its arguments on the host (shapes, permutation validity, size limits of the
+// kernel it is about to launch) before anything reaches the GPU.  There is no CPU fallback.
+#include "../../include/teeline_gpu.h"
+#include "tl_kernels.h"
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace tl;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct tl_ctx {
+    int device = 0;
+    uint32_t flags = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    int cus = 0, lds_bytes = 0;
+    std::string arch;
+    std::string err;
+    DevBuf xy, dm, init, out_pos, out_cost, out_stats, misc, work, dmfull;
+    uint32_t dm_n = 0;
+    int dm_layout = -1;
+};
+
+static std::string g_create_err;
+
+static int fail(tl_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_create_err = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                           \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return fail((c), _e == hipErrorOutOfMemory ? TL_ERR_NOMEM : TL_ERR_HIP, "%s: %s", #expr, \
+                        hipGetErrorString(_e));                                                   \
+    } while (0)
+
+static int ensure(tl_ctx *c, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return TL_OK;
+    if (b.p) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t cap = bytes + bytes / 8 + 256;
+    HIPCHK(c, hipMalloc(&b.p, cap));
+    b.cap = cap;
+    return TL_OK;
+}
+
+static bool is_permutation(const uint32_t *p, uint32_t n)  // validate_tour, src/tsp/mod.rs:1620-1634
+{
+    std::vector<unsigned char> seen(n, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (p[i] >= n || seen[p[i]]) return false;
+        seen[p[i]] = 1;
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int tl_abi_version(void) { return TL_ABI_VERSION; }
+extern "C" const char *tl_version(void) { return "teeline-gpu 0.1 (gfx950)"; }
+
+extern "C" const char *tl_last_error(const tl_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int tl_create(int device, uint32_t flags, tl_ctx **out)
+{
+    if (!out) return fail(nullptr, TL_ERR_BADARG, "tl_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, TL_ERR_NO_DEVICE, "tl_create: no HIP device (%s) — libteeline_gpu has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "count=0");
+    if (device < 0 || device >= count)
+        return fail(nullptr, TL_ERR_BADARG, "tl_create: device %d out of range [0,%d)", device, count);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess)
+        return fail(nullptr, TL_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, TL_ERR_NO_DEVICE, "tl_create: device %d is %s; this library is built for gfx950 only",
+                    device, prop.gcnArchName);
+    tl_ctx *c = new tl_ctx();
+    c->device = device;
+    c->flags = flags;
+    c->cus = prop.multiProcessorCount;
+    c->lds_bytes = (int)prop.sharedMemPerBlock;
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > c->lds_bytes)
+            c->lds_bytes = v;
+    }
+    c->arch = prop.gcnArchName;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+        int rc = fail(nullptr, TL_ERR_HIP, "tl_create: %s", hipGetErrorString(e));
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return TL_OK;
+}
+
+extern "C" void tl_destroy(tl_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (DevBuf *b : {&c->xy, &c->dm, &c->init, &c->out_pos, &c->out_cost, &c->out_stats, &c->misc, &c->work, &c->dmfull})
+        if (b->p) (void)hipFree(b->p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int tl_device_info(const tl_ctx *c, int *cus, int *lds_bytes, char *arch, size_t arch_len)
+{
+    if (!c) return TL_ERR_BADARG;
+    if (cus) *cus = c->cus;
+    if (lds_bytes) *lds_bytes = c->lds_bytes;
+    if (arch && arch_len) snprintf(arch, arch_len, "%s", c->arch.c_str());
+    return TL_OK;
+}
+
+static uint32_t lds_max_n(int lds_bytes)
+{
+    // 10 B per city (float2 + u16) on n rounded up to 64 plus one pad tile, + control + scratch
+    const long avail = (long)lds_bytes - 64 - (long)TL_TWO_OPT_NT * 4;
+    long n_pad = avail / 10;
+    n_pad -= n_pad % 64;
+    long n = n_pad - 64;
+    if (n > 65535) n = 65535;  // u16 tour entries, (i<<16|j) keys
+    return n < 0 ? 0u : (uint32_t)n;
+}
+
+extern "C" uint32_t tl_two_opt_lds_max_n(const tl_ctx *c) { return c ? lds_max_n(c->lds_bytes) : 0u; }
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int tl_last_kernel_ms(tl_ctx *c, double *ms)
+{
+    if (!c || !ms) return TL_ERR_BADARG;
+    if (!c->ev_valid) return fail(c, TL_ERR_BADARG, "tl_last_kernel_ms: no kernel sequence recorded yet");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float f = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&f, c->ev0, c->ev1));
+    *ms = (double)f;
+    return TL_OK;
+}
+
+extern "C" int tl_dm_build_dev(tl_ctx *c, const float *d_xy, uint32_t n, int dist, int layout, float *d_out, void *stream)
+{
+    if (!c || !d_xy || !d_out) return fail(c, TL_ERR_BADARG, "tl_dm_build_dev: NULL argument");
+    if (n < 2) return fail(c, TL_ERR_BADARG, "distance matrix requires at least 2 points");  // distance_matrix.rs:124-126
+    if ((dist != TL_DIST_EUC2D && dist != TL_DIST_GEO) || (layout != TL_DM_PACKED_LOWER && layout != TL_DM_FULL))
+        return fail(c, TL_ERR_BADARG, "tl_dm_build_dev: bad dist/layout");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    HIPCHK(c, hipEventRecord(c->ev0, s));
+    HIPCHK(c, launch_dm_build(reinterpret_cast<const float2 *>(d_xy), n, dist, layout, d_out, s));
+    HIPCHK(c, hipEventRecord(c->ev1, s));
+    c->ev_valid = true;
+    return TL_OK;
+}
+
+extern "C" int tl_dm_build(tl_ctx *c, const float *xy, uint32_t n, int dist, int layout, float *out_host, double *kernel_ms)
+{
+    if (!c || !xy) return fail(c, TL_ERR_BADARG, "tl_dm_build: NULL argument");
+    if (n < 2) return fail(c, TL_ERR_BADARG, "distance matrix requires at least 2 points");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t elems = layout == TL_DM_FULL ? (size_t)n * n : (size_t)n * (n - 1) / 2;
+    int rc;
+    if ((rc = ensure(c, c->xy, (size_t)n * 8))) return rc;
+    DevBuf &dst = layout == TL_DM_FULL ? c->dmfull : c->dm;
+    if ((rc = ensure(c, dst, elems * 4))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    if ((rc = tl_dm_build_dev(c, (const float *)c->xy.p, n, dist, layout, (float *)dst.p, nullptr))) return rc;
+    if (out_host) HIPCHK(c, hipMemcpyAsync(out_host, dst.p, elems * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (kernel_ms) tl_last_kernel_ms(c, kernel_ms);
+    return TL_OK;
+}
+
+extern "C" int tl_tour_length(tl_ctx *c, const float *xy, const float *dm_packed, uint32_t n, const uint32_t *perm, float *out_cost)
+{
+    if (!c || (!xy && !dm_packed) || !perm || !out_cost) return fail(c, TL_ERR_BADARG, "tl_tour_length: NULL argument");
+    if (n < 2) {  // distance_matrix.rs:236-238
+        *out_cost = 0.0f;
+        return TL_OK;
+    }
+    for (uint32_t i = 0; i < n; ++i)
+        if (perm[i] >= n) return fail(c, TL_ERR_BADARG, "tl_tour_length: position %u out of range at %u", perm[i], i);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->init, (size_t)n * 4)) || (rc = ensure(c, c->out_cost, 4))) return rc;
+    const float2 *dxy = nullptr;
+    const float *ddm = nullptr;
+    if (dm_packed) {
+        const size_t b = (size_t)n * (n - 1) / 2 * 4;
+        if ((rc = ensure(c, c->dm, b))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->dm.p, dm_packed, b, hipMemcpyHostToDevice, c->stream));
+        ddm = (const float *)c->dm.p;
+    } else {
+        if ((rc = ensure(c, c->xy, (size_t)n * 8))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+        dxy = (const float2 *)c->xy.p;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->init.p, perm, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_tour_length(dxy, ddm, n, (const uint32_t *)c->init.p, (float *)c->out_cost.p, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out_cost, c->out_cost.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return TL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2-opt
+// ------------------------------------------------------------------------------------------------
+static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uint32_t n, const uint32_t *d_init,
+                           uint32_t init_mode, uint64_t seed, uint32_t first, uint32_t count, int mode,
+                           uint32_t *d_out_pos, float *d_out_cost, uint64_t *d_out_stats, hipStream_t s)
+{
+    if (mode != TL_MODE_REF_ORDER) return fail(c, TL_ERR_UNSUPPORTED, "batch 2-opt supports TL_MODE_REF_ORDER only");
+    if (n < 3) return fail(c, TL_ERR_REF_PANICS, "two_opt: n=%u < 3 — the reference underflows `n_indices - 2` (two_opt.rs:17,29)", n);
+    if (count == 0) return TL_OK;
+    TwoOptBatchArgs A{};
+    A.xy = d_xy;
+    A.dm = d_dm;
+    A.init = d_init;
+    A.out_pos = d_out_pos;
+    A.out_cost = d_out_cost;
+    A.out_stats = d_out_stats;
+    A.seed = seed;
+    A.first = first;
+    A.n = n;
+    A.max_sweeps = 1u << 20;
+    A.init_mode = init_mode;
+    HIPCHK(c, hipEventRecord(c->ev0, s));
+    if (d_dm) {
+        if (init_mode == TL_INIT_SEEDED) return fail(c, TL_ERR_UNSUPPORTED, "seeded restarts need coordinates (dm_packed must be NULL)");
+        if (two_opt_ref_dm_lds_bytes(n) > (size_t)c->lds_bytes)
+            return fail(c, TL_ERR_UNSUPPORTED, "two_opt (matrix form): n=%u exceeds the LDS tour capacity", n);
+        HIPCHK(c, launch_two_opt_ref_dm(A, count, s));
+    } else {
+        const uint32_t nmax = lds_max_n(c->lds_bytes);
+        if (n > nmax)
+            return fail(c, TL_ERR_UNSUPPORTED, "two_opt (on-the-fly form): n=%u exceeds the LDS-resident limit %u", n, nmax);
+        HIPCHK(c, launch_two_opt_ref_lds(A, count, !(c->flags & TL_FLAG_NO_PRUNE), s));
+    }
+    HIPCHK(c, hipEventRecord(c->ev1, s));
+    c->ev_valid = true;
+    return TL_OK;
+}
+
+extern "C" int tl_two_opt_batch_dev(tl_ctx *c, const float *d_xy, uint32_t n, const uint32_t *d_init, uint64_t seed,
+                                    uint32_t first, uint32_t count, int mode, uint32_t *d_out_pos, float *d_out_cost,
+                                    uint64_t *d_out_stats, void *stream)
+{
+    if (!c || !d_xy || !d_out_pos || !d_out_cost || !d_out_stats) return fail(c, TL_ERR_BADARG, "tl_two_opt_batch_dev: NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return two_opt_enqueue(c, (const float2 *)d_xy, nullptr, n, d_init, d_init ? TL_INIT_ARRAY : TL_INIT_SEEDED, seed, first,
+                           count, mode, d_out_pos, d_out_cost, d_out_stats, s);
+}
+
+static void fill_stats(tl_stats *st, uint32_t n, const uint64_t *raw, uint32_t count, double kernel_ms, double total_ms)
+{
+    if (!st) return;
+    memset(st, 0, sizeof(*st));
+    const uint64_t per_sweep = n >= 4 ? (uint64_t)(n - 3) * (n - 2) / 2 : 0;
+    for (uint32_t r = 0; r < count; ++r) {
+        st->sweeps += raw[4 * r + 0];
+        st->moves += raw[4 * r + 1];
+        st->reversed += raw[4 * r + 2];
+    }
+    st->candidates = st->sweeps * per_sweep;
+    st->kernel_ms = kernel_ms;
+    st->total_ms = total_ms;
+}
+
+static int two_opt_best_sweep(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
+                              uint32_t *out_pos, float *out_cost, tl_stats *stats);
+
+extern "C" int tl_two_opt(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos, int mode,
+                          uint32_t *out_pos, float *out_cost, tl_stats *stats)
+{
+    if (!c || (!xy && !dm_packed) || !out_pos) return fail(c, TL_ERR_BADARG, "tl_two_opt: NULL argument");
+    if (mode != TL_MODE_REF_ORDER && mode != TL_MODE_BEST_SWEEP) return fail(c, TL_ERR_BADARG, "tl_two_opt: bad mode %d", mode);
+    if (n < 3) return fail(c, TL_ERR_REF_PANICS, "two_opt: n=%u < 3 — the reference underflows `n_indices - 2` (two_opt.rs:17,29)", n);
+    if (init_pos && !is_permutation(init_pos, n)) return fail(c, TL_ERR_BADARG, "tl_two_opt: init tour is not a permutation of 0..n-1");
+    if (mode == TL_MODE_BEST_SWEEP) return two_opt_best_sweep(c, xy, n, dm_packed, init_pos, out_pos, out_cost, stats);
+    const auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->out_pos, (size_t)n * 4)) || (rc = ensure(c, c->out_cost, 4)) || (rc = ensure(c, c->out_stats, 32))) return rc;
+    const float2 *dxy = nullptr;
+    const float *ddm = nullptr;
+    if (dm_packed) {
+        const size_t b = (size_t)n * (n - 1) / 2 * 4;
+        if ((rc = ensure(c, c->dm, b))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->dm.p, dm_packed, b, hipMemcpyHostToDevice, c->stream));
+        ddm = (const float *)c->dm.p;
+    }
+    if (xy) {
+        if ((rc = ensure(c, c->xy, (size_t)n * 8))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+        dxy = (const float2 *)c->xy.p;
+    }
+    const uint32_t *dinit = nullptr;
+    if (init_pos) {
+        if ((rc = ensure(c, c->init, (size_t)n * 4))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->init.p, init_pos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        dinit = (const uint32_t *)c->init.p;
+    }
+    if ((rc = two_opt_enqueue(c, dxy, ddm, n, dinit, dinit ? TL_INIT_ARRAY : TL_INIT_IDENTITY, 0, 0, 1, mode,
+                              (uint32_t *)c->out_pos.p, (float *)c->out_cost.p, (uint64_t *)c->out_stats.p, c->stream)))
+        return rc;
+    uint64_t raw[4];
+    float cost = 0.f;
+    HIPCHK(c, hipMemcpyAsync(out_pos, c->out_pos.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&cost, c->out_cost.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(raw, c->out_stats.p, 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (raw[3] != 0) return fail(c, TL_ERR_NO_CONVERGE, "two_opt: sweep cap reached");
+    if (out_cost) *out_cost = cost;
+    double kms = 0;
+    tl_last_kernel_ms(c, &kms);
+    fill_stats(stats, n, raw, 1, kms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    return TL_OK;
+}
+
+extern "C" uint64_t tl_pack_cost_key(float cost, uint32_t restart)
+{
+    uint32_t bits;
+    memcpy(&bits, &cost, 4);
+    return ((uint64_t)bits << 32) | restart;
+}
+
+extern "C" int tl_two_opt_multistart(tl_ctx *c, const float *xy, uint32_t n, uint64_t seed, uint32_t first, uint32_t count,
+                                     int mode, uint32_t *out_best_pos, float *out_best_cost, uint32_t *out_best_restart,
+                                     float *out_costs, tl_stats *stats)
+{
+    if (!c || !xy || !out_best_pos) return fail(c, TL_ERR_BADARG, "tl_two_opt_multistart: NULL argument");
+    if (count == 0) return fail(c, TL_ERR_BADARG, "tl_two_opt_multistart: count == 0");
+    if (n < 3) return fail(c, TL_ERR_REF_PANICS, "two_opt: n=%u < 3", n);
+    const auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->out_pos, (size_t)count * n * 4)) ||
+        (rc = ensure(c, c->out_cost, (size_t)count * 4)) || (rc = ensure(c, c->out_stats, (size_t)count * 32)))
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    if ((rc = two_opt_enqueue(c, (const float2 *)c->xy.p, nullptr, n, nullptr, TL_INIT_SEEDED, seed, first, count, mode,
+                              (uint32_t *)c->out_pos.p, (float *)c->out_cost.p, (uint64_t *)c->out_stats.p, c->stream)))
+        return rc;
+    std::vector<float> costs(count);
+    std::vector<uint64_t> raw((size_t)count * 4);
+    HIPCHK(c, hipMemcpyAsync(costs.data(), c->out_cost.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(raw.data(), c->out_stats.p, (size_t)count * 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint32_t best = 0;
+    uint64_t best_key = ~0ull;
+    for (uint32_t r = 0; r < count; ++r) {
+        if (raw[4 * r + 3] != 0) return fail(c, TL_ERR_NO_CONVERGE, "two_opt: sweep cap reached in restart %u", first + r);
+        const uint64_t k = tl_pack_cost_key(costs[r], first + r);
+        if (k < best_key) {
+            best_key = k;
+            best = r;
+        }
+    }
+    HIPCHK(c, hipMemcpy(out_best_pos, (const uint32_t *)c->out_pos.p + (size_t)best * n, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (out_best_cost) *out_best_cost = costs[best];
+    if (out_best_restart) *out_best_restart = first + best;
+    if (out_costs) memcpy(out_costs, costs.data(), (size_t)count * 4);
+    double kms = 0;
+    tl_last_kernel_ms(c, &kms);
+    fill_stats(stats, n, raw.data(), count, kms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    return TL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// not yet built in this revision
+// ------------------------------------------------------------------------------------------------
+static int two_opt_best_sweep(tl_ctx *c, const float *, uint32_t, const float *, const uint32_t *, uint32_t *, float *, tl_stats *)
+{
+    return fail(c, TL_ERR_UNSUPPORTED, "TL_MODE_BEST_SWEEP: not built yet");
+}
+
+extern "C" int tl_three_opt(tl_ctx *c, const float *, uint32_t, const float *, const uint32_t *, uint32_t *, float *, tl_stats *)
+{
+    return fail(c, TL_ERR_UNSUPPORTED, "tl_three_opt: not built yet");
+}
+
+extern "C" int tl_three_opt_find_best_move(tl_ctx *c, const float *, uint32_t, const float *, const uint32_t *, int *, uint32_t *,
+                                           uint32_t *, uint32_t *, int *, float *)
+{
+    return fail(c, TL_ERR_UNSUPPORTED, "tl_three_opt_find_best_move: not built yet");
+}
+
+extern "C" int tl_lk(tl_ctx *c, const float *, uint32_t, const uint32_t *, const tl_lk_opts *, uint64_t, uint32_t *, float *, tl_stats *)
+{
+    return fail(c, TL_ERR_UNSUPPORTED, "tl_lk: not built yet");
+}

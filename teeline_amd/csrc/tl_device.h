@@ -1,0 +1,75 @@
+// tl_device.h — device-side helpers shared by every kernel of libteeline_gpu (gfx950 only).
+//
+// Numerics contract (reference: src/tsp/kdtree.rs:291-295 `KDPoint::distance`):
+//   d = sqrt(dx*dx + dy*dy) in f32, separate roundings for both products and the sum (Rust never
+//   contracts to FMA), correctly rounded sqrt.  This file is compiled with -ffp-contract=off and
+//   also pins the pragma below so a stray build flag cannot change results.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace tl {
+
+constexpr int kWave = 64;  // CDNA wavefront width
+
+__device__ __forceinline__ float sqdist(float2 p, float2 q)
+{
+    float dx = p.x - q.x;
+    float dy = p.y - q.y;
+    return dx * dx + dy * dy;
+}
+
+// Correctly rounded f32 sqrt.  hipcc (-fhip-fp32-correctly-rounded-divide-sqrt, default on) expands
+// this to v_sqrt_f32 plus a +-1ulp FMA fix-up; tests/test_gpu_numerics.py checks it bit-for-bit
+// against the host's sqrtf over a dense sample of all binades.
+__device__ __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }
+
+__device__ __forceinline__ float dist(float2 p, float2 q) { return sqrt_rn(sqdist(p, q)); }
+
+// distance_matrix.rs:59-75 geo_distance (f64 trig -> floor -> f32)
+__device__ __forceinline__ double geo_to_rad(float x)
+{
+    const double PI = 3.14159265358979323846264338327950288;
+    double deg = (double)truncf(x);
+    double min = (double)(x - truncf(x));
+    return PI * (deg + 5.0 * min / 3.0) / 180.0;
+}
+
+__device__ __forceinline__ float geo_dist(float2 p, float2 q)
+{
+    double lat1 = geo_to_rad(p.x), lon1 = geo_to_rad(p.y);
+    double lat2 = geo_to_rad(q.x), lon2 = geo_to_rad(q.y);
+    double q1 = cos(lon1 - lon2);
+    double q2 = cos(lat1 - lat2);
+    double q3 = cos(lat1 + lat2);
+    const double RRR = 6378.388;
+    return (float)floor(RRR * acos(0.5 * ((1.0 + q1) * q2 - (1.0 - q1) * q3)) + 1.0);
+}
+
+// distance_matrix.rs:177-191 distance_by_pos on the packed strict lower triangle
+__device__ __forceinline__ float dm_lookup(const float *__restrict__ packed, uint32_t p, uint32_t q)
+{
+    if (p == q) return 0.0f;
+    uint64_t from = p > q ? p : q;
+    uint64_t to = p > q ? q : p;
+    return packed[from * (from - 1) / 2 + to];
+}
+
+__device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t k)
+{
+    // k-th output (k = 0,1,...) of the splitmix64 stream started at `seed`: the state is a counter,
+    // so draws are independent of each other and can be computed in parallel.
+    uint64_t z = seed + (k + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ float readlane_f(float v, int l)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+}  // namespace tl

@@ -1,0 +1,55 @@
+// tl_kernels.h — kernel argument blocks and launch entry points (internal to libteeline_gpu).
+#pragma once
+#include "tl_device.h"
+
+#ifndef TL_TWO_OPT_NT
+#define TL_TWO_OPT_NT 1024  // threads per descent workgroup (16 waves, 4 per SIMD)
+#endif
+
+namespace tl {
+
+enum : uint32_t { TL_INIT_IDENTITY = 0, TL_INIT_ARRAY = 1, TL_INIT_SEEDED = 2 };
+
+struct TwoOptBatchArgs {
+    const float2 *xy;        // n cities, city order
+    const float *dm;         // packed lower triangle (matrix kernels) or nullptr
+    const uint32_t *init;    // [count][n] when init_mode == TL_INIT_ARRAY
+    uint32_t *out_pos;       // [count][n]
+    float *out_cost;         // [count]
+    uint64_t *out_stats;     // [count][4] = sweeps, moves, reversed, status(0 ok, 1 sweep cap)
+    uint64_t seed;
+    uint32_t first;          // restart index of descent 0 (seeded init)
+    uint32_t n;
+    uint32_t n_pad;
+    uint32_t max_sweeps;
+    uint32_t init_mode;
+    uint32_t *work;          // per-descent global workspace (global-memory variants)
+};
+
+// two_opt_ref.hip
+size_t two_opt_ref_lds_bytes(uint32_t n, uint32_t *n_pad_out, int nt);
+hipError_t launch_two_opt_ref_lds(const TwoOptBatchArgs &A, uint32_t count, bool prune, hipStream_t s);
+
+// two_opt_dm.hip — same algorithm, distances gathered from the packed matrix in HBM/L2
+size_t two_opt_ref_dm_lds_bytes(uint32_t n);
+hipError_t launch_two_opt_ref_dm(const TwoOptBatchArgs &A, uint32_t count, hipStream_t s);
+
+// two_opt_best.hip — BEST_SWEEP mode (whole chip per sweep)
+struct BestSweepArgs {
+    const float2 *xy;
+    const float *dm;      // nullptr = on-the-fly
+    uint32_t *perm;       // [n] in/out (device)
+    float2 *P;            // [n_pad] tour-ordered coords workspace
+    unsigned long long *key;  // packed argmin key, device
+    uint32_t n;
+};
+hipError_t launch_best_sweep_gather(const BestSweepArgs &A, hipStream_t s);
+hipError_t launch_best_sweep_scan(const BestSweepArgs &A, hipStream_t s);
+hipError_t launch_best_sweep_apply(const BestSweepArgs &A, uint64_t *counters, hipStream_t s);
+
+// dm_build.hip
+hipError_t launch_dm_build(const float2 *xy, uint32_t n, int dist, int layout, float *out, hipStream_t s);
+hipError_t launch_tour_length(const float2 *xy, const float *dm, uint32_t n, const uint32_t *perm,
+                              float *out_cost, hipStream_t s);
+
+}  // namespace tl

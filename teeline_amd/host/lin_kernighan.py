@@ -1,0 +1,25 @@
+"""lin_kernighan::solve — mirror of src/tsp/lin_kernighan.rs:35-100 over tl_lk."""
+import ctypes as C
+
+import numpy as np
+
+
+def solve(problem, opts=None, progress_tx=None, init_tour=None, *, ctx=None, seed=1):
+    from . import LKOptions, Solution, default_context
+    from .. import _capi
+    ctx = ctx or default_context()
+    opts = opts or LKOptions()
+    opts.validate()
+    n = len(problem)
+    init_pos = problem.positions_of(init_tour) if init_tour is not None else None
+    o = _capi.TlLkOpts(opts.heuristic.epochs, opts.heuristic.platoo_epochs, opts.heuristic.n_nearest, opts.max_depth)
+    out = np.empty(n, dtype=np.uint32)
+    cost = C.c_float()
+    st = _capi.TlStats()
+    ctx.check(ctx.lib.tl_lk(ctx.handle, problem.xy.ctypes.data_as(C.c_void_p), n,
+                            None if init_pos is None else init_pos.ctypes.data_as(C.c_void_p), C.byref(o), int(seed),
+                            out.ctypes.data_as(C.c_void_p), C.byref(cost), C.byref(st)))
+    route = problem.ids[out]
+    if progress_tx is not None:
+        progress_tx("PathUpdate", ([int(v) for v in route], float(cost.value)))
+    return Solution(cost.value, route, problem, st.as_dict())

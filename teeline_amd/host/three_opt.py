@@ -1,0 +1,44 @@
+"""three_opt::solve — mirror of src/tsp/three_opt.rs:16-51 over tl_three_opt."""
+import ctypes as C
+
+import numpy as np
+
+
+def solve(problem, opts=None, progress_tx=None, init_tour=None, *, ctx=None):
+    from . import Solution, default_context
+    ctx = ctx or default_context()
+    n = len(problem)
+    init_pos = problem.positions_of(init_tour) if init_tour is not None else None
+    packed = problem.explicit_packed()
+    out = np.empty(n, dtype=np.uint32)
+    cost = C.c_float()
+    from .. import _capi
+    st = _capi.TlStats()
+    ctx.check(ctx.lib.tl_three_opt(ctx.handle, problem.xy.ctypes.data_as(C.c_void_p), n,
+                                   None if packed is None else packed.ctypes.data_as(C.c_void_p),
+                                   None if init_pos is None else init_pos.ctypes.data_as(C.c_void_p),
+                                   out.ctypes.data_as(C.c_void_p), C.byref(cost), C.byref(st)))
+    route = problem.ids[out]
+    if progress_tx is not None:
+        progress_tx("PathUpdate", ([int(v) for v in route], float(cost.value)))
+        progress_tx("Done", None)
+    return Solution(cost.value, route, problem, st.as_dict())
+
+
+def find_best_move(problem, path_pos, *, ctx=None):
+    """three_opt::find_best_move (three_opt.rs:58-131) on positions; returns (i, j, k, case, savings) or None."""
+    from . import default_context
+    ctx = ctx or default_context()
+    n = len(problem)
+    path = np.ascontiguousarray(path_pos, dtype=np.uint32)
+    packed = problem.explicit_packed()
+    found, kase = C.c_int(), C.c_int()
+    i, j, k = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    sav = C.c_float()
+    ctx.check(ctx.lib.tl_three_opt_find_best_move(ctx.handle, problem.xy.ctypes.data_as(C.c_void_p), n,
+                                                  None if packed is None else packed.ctypes.data_as(C.c_void_p),
+                                                  path.ctypes.data_as(C.c_void_p), C.byref(found), C.byref(i), C.byref(j),
+                                                  C.byref(k), C.byref(kase), C.byref(sav)))
+    if not found.value:
+        return None
+    return (i.value, j.value, k.value, kase.value, np.float32(sav.value))

@@ -1,0 +1,98 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads, exports every symbol the
+header declares, and refuses to compute without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "teeline_gpu.h")
+
+
+def header_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tl_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from teeline_amd import build
+    build.build()
+    from teeline_amd import _capi
+    return _capi.load()
+
+
+def test_header_declares_what_the_binding_lists():
+    from teeline_amd import _capi
+    assert header_symbols() == sorted(_capi.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for name in header_symbols():
+        assert hasattr(lib, name), f"libteeline_gpu.so does not export {name}"
+    assert lib.tl_abi_version() == 1
+    assert b"gfx950" in lib.tl_version()
+
+
+def test_library_contains_gfx950_code_object():
+    from teeline_amd import _capi
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "-S", _capi.LIB_PATH], capture_output=True, text=True)
+    if out.returncode != 0:
+        pytest.skip("llvm-readelf unavailable")
+    assert ".hip_fatbin" in out.stdout
+    blob = open(_capi.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"k_two_opt_ref_lds" in blob
+
+
+def test_pack_cost_key_orders_by_cost_then_restart(lib):
+    k = lib.tl_pack_cost_key
+    assert k(1.0, 5) < k(1.5, 0) and k(2.0, 3) < k(2.0, 4) and k(77647.55469, 0) >> 32 == 0x4797A7C7
+
+
+def test_no_cpu_fallback_without_device(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    rc = lib.tl_create(0, 0, C.byref(h))
+    assert rc == -3 and not h.value  # TL_ERR_NO_DEVICE
+    assert b"no CPU fallback" in lib.tl_last_error(None)
+    import teeline_amd
+    with pytest.raises(teeline_amd.TeelineGpuError):
+        teeline_amd.Context(0)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "teeline_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "tl_oracle" not in text and "libtl_oracle" not in text, f"{f} references the oracle"
+                assert not re.search(r"^\s*(from|import)\s+_?oracle", text, flags=re.M), f"{f} imports the oracle"
+
+
+def test_host_mirror_tsplib_and_types(tsplib_dir):
+    import numpy as np
+    import teeline_amd as T
+    import _tsplib
+    for name in ("berlin52", "a280", "att532", "gr17", "ring6_explicit", "bays29", "burma14", "att48"):
+        d = T.tsplib.read_from_file(os.path.join(tsplib_dir, f"{name}.tsp"))
+        e = _tsplib.parse_tsplib(os.path.join(tsplib_dir, f"{name}.tsp"))
+        assert len(d) == e["n"] and np.array_equal(d.xy, e["xy"]) and np.array_equal(d.ids, e["ids"])
+        if e["packed"] is not None:
+            assert np.array_equal(d.raw_distances, e["packed"])
+    d = T.tsplib.read_from_file(os.path.join(tsplib_dir, "att532.tsp"))
+    assert d.distance_type == "euc2d"  # ATT silently becomes EUC_2D (tsplib.rs:199-202)
+    with pytest.raises(ValueError):
+        T.tsplib.read_from_str("NAME: x\nTYPE: ATSP\nDIMENSION: 2\nNODE_COORD_SECTION\n1 0 0\n2 1 1\nEOF\n")
+    p = T.TspProblem([1, 2, 3], [[0, 0], [1, 0], [0, 1]])
+    assert p.positions_of([3, 1, 2]).tolist() == [2, 0, 1]
+    with pytest.raises(T.ReferencePanics):
+        p.positions_of([3, 1, 9])
+    assert T.validate_tour([3, 1, 2], p) and not T.validate_tour([3, 1, 1], p)
+    with pytest.raises(ValueError):
+        T.LKOptions(max_depth=0).validate()

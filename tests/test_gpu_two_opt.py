@@ -1,0 +1,199 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle.
+
+Bit-exact bar: tours element-for-element, costs bit-for-bit (f32), sweep/move/reversal counters equal.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as O
+import _tsplib as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def goldens(golden_dir):
+    with open(os.path.join(golden_dir, "goldens.json")) as fh:
+        return json.load(fh)
+
+
+def f5(x):
+    return f"{float(x):.5f}"
+
+
+def gpu_two_opt(ctx, xy, packed, n, init=None, mode=0):
+    import teeline_amd as TA
+    prob = TA.TspProblem(np.arange(n), xy if xy is not None else np.zeros((n, 2), np.float32),
+                         None if packed is None else TA.distance_matrix.DistanceMatrix(n, packed, np.arange(n), "explicit"))
+    sol = TA.two_opt.solve(prob, None, None, None if init is None else [int(v) for v in init], ctx=ctx, mode=mode)
+    return np.asarray(sol.route(), dtype=np.uint32), sol.total, sol.stats
+
+
+def assert_same(gpu, ora, n):
+    route, cost, st = gpu
+    rc, oroute, ocost, ost = ora
+    assert rc == 0
+    assert route.tolist() == oroute.tolist(), "tour differs from the oracle"
+    assert np.float32(cost).tobytes() == np.float32(ocost).tobytes(), f"cost {cost!r} != {ocost!r}"
+    for k in ("sweeps", "candidates", "moves", "reversed"):
+        assert st[k] == ost[k], f"{k}: gpu {st[k]} != oracle {ost[k]}"
+
+
+def test_device_is_gfx950_and_lds_limit(ctx):
+    info = ctx.device_info()
+    assert info["arch"].startswith("gfx950") and info["cus"] >= 200
+    assert ctx.two_opt_lds_max_n() >= 13509  # configs 3 and 5 sizes fit one CU's LDS
+
+
+def test_tsp5_reference_unit_tests(ctx):
+    # two_opt.rs:100-131
+    pts = np.array([[0.0, 0.0], [0.0, 0.5], [0.0, 1.0], [1.0, 1.0], [1.0, 0.0]], dtype=np.float32)
+    route, cost, st = gpu_two_opt(ctx, pts, None, 5)
+    assert route.tolist() == [0, 1, 2, 3, 4] and cost == np.float32(4.0)
+    route, cost, st = gpu_two_opt(ctx, pts, None, 5, init=[0, 1, 2, 3, 4])
+    assert route.tolist() == [0, 1, 2, 3, 4]
+
+
+@pytest.mark.parametrize("name", ["berlin52", "a280", "att532", "att48"])
+def test_tsplib_euclid_matches_oracle_and_goldens(ctx, name, tsplib_dir, goldens):
+    d = T.parse_tsplib(os.path.join(tsplib_dir, f"{name}.tsp"))
+    xy, n, ids = d["xy"], d["n"], d["ids"]
+    rc, nn, _ = O.nearest_neighbor(xy, None, n, 3)
+    for key, init in (("identity_two_opt", None), ("nn_two_opt", nn)):
+        g = gpu_two_opt(ctx, xy, None, n, init)
+        assert_same(g, O.two_opt(xy, None, n, init=init), n)
+        assert f5(g[1]) == goldens[name][key]["cost"]
+        assert ids[g[0]].tolist() == goldens[name][key]["route_ids"]
+
+
+def test_edge_sizes(ctx):
+    import teeline_amd as TA
+    xy = O.synth_xy(70, seed=11)
+    for n in (3, 4, 5, 6, 7, 63, 64, 65, 66, 67, 70):
+        assert_same(gpu_two_opt(ctx, xy[:n], None, n), O.two_opt(xy[:n], None, n), n)
+    for n in (1, 2):  # the reference panics (usize underflow, two_opt.rs:17,29)
+        with pytest.raises(TA.ReferencePanics):
+            gpu_two_opt(ctx, xy[:n], None, n)
+    with pytest.raises(TA.TeelineGpuError):  # not a permutation
+        prob = TA.TspProblem(np.arange(5), xy[:5])
+        out = np.empty(5, np.uint32)
+        import ctypes as C
+        bad = np.array([0, 1, 1, 3, 4], np.uint32)
+        ctx.check(ctx.lib.tl_two_opt(ctx.handle, prob.xy.ctypes.data_as(C.c_void_p), 5, None,
+                                     bad.ctypes.data_as(C.c_void_p), 0, out.ctypes.data_as(C.c_void_p), None, None))
+
+
+def test_duplicate_points_and_ties(ctx):
+    # collisions: repeated coordinates and a lattice (many exactly equal distances -> strict `<` matters)
+    g = np.stack(np.meshgrid(np.arange(12, dtype=np.float32), np.arange(12, dtype=np.float32)), -1).reshape(-1, 2)
+    rng = np.random.default_rng(5)
+    lattice = g[rng.permutation(len(g))]
+    assert_same(gpu_two_opt(ctx, lattice, None, len(lattice)), O.two_opt(lattice, None, len(lattice)), len(lattice))
+    dup = np.concatenate([lattice[:50], lattice[:50], np.zeros((10, 2), np.float32)])
+    dup = np.ascontiguousarray(dup[rng.permutation(len(dup))])
+    assert_same(gpu_two_opt(ctx, dup, None, len(dup)), O.two_opt(dup, None, len(dup)), len(dup))
+
+
+@pytest.mark.parametrize("n,seed", [(257, 1), (1002, 0), (2000, 9), (4097, 4)])
+def test_synthetic_random_and_greedy_starts(ctx, n, seed):
+    xy = O.synth_xy(n, seed=seed)
+    rc, nn, _ = O.nearest_neighbor(xy, None, n, 3)
+    assert_same(gpu_two_opt(ctx, xy, None, n, nn), O.two_opt(xy, None, n, init=nn), n)
+    rp = O.restart_perm(n, 777, 2)
+    assert_same(gpu_two_opt(ctx, xy, None, n, rp), O.two_opt(xy, None, n, init=rp), n)
+
+
+def test_synthetic_10000_full_size(ctx, goldens):
+    # BASELINE config 3 at full size against the committed golden (oracle: 12 sweeps, 599 700 036 candidates)
+    n = 10000
+    g = goldens["synthetic10000"]
+    xy = O.synth_xy(n)
+    rc, nn, cnn = O.nearest_neighbor(xy, None, n, 3)
+    assert f5(cnn) == g["nn_cost"]
+    route, cost, st = gpu_two_opt(ctx, xy, None, n, nn)
+    w = np.arange(1, n + 1, dtype=np.uint32)
+    assert f5(cost) == g["nn_two_opt"]["cost"] == "77647.55469"
+    assert {k: st[k] for k in ("sweeps", "candidates", "moves", "reversed")} == g["nn_two_opt"]["stats"]
+    assert int(np.bitwise_xor.reduce(route * w)) == g["nn_two_opt"]["route_crc"]
+    assert O.validate_tour(route) and route[0] == nn[0] and route[-1] == nn[-1]  # open path endpoints fixed
+    # size-independent property: the result is a fixed point of the reference's sweep
+    rc, again, c2, st2 = O.two_opt(xy, None, n, init=route, max_candidates=1)
+    assert st2["moves"] == 0 and again.tolist() == route.tolist() and c2 == cost
+    # random restart start (70 970 moves)
+    rp = O.restart_perm(n, 12345, 0)
+    route, cost, st = gpu_two_opt(ctx, xy, None, n, rp)
+    gg = g["restart0_seed12345_two_opt"]
+    assert f5(cost) == gg["cost"] and {k: st[k] for k in ("sweeps", "candidates", "moves", "reversed")} == gg["stats"]
+    assert int(np.bitwise_xor.reduce(route * w)) == gg["route_crc"]
+
+
+def test_no_prune_flag_gives_identical_results(tsplib_dir):
+    import teeline_amd as TA
+    with TA.Context(0, TA.TL_FLAG_NO_PRUNE) as c2:
+        for n, seed in ((500, 3), (1500, 8)):
+            xy = O.synth_xy(n, seed=seed)
+            rp = O.restart_perm(n, 1, 0)
+            assert_same(gpu_two_opt(c2, xy, None, n, rp), O.two_opt(xy, None, n, init=rp), n)
+
+
+@pytest.mark.parametrize("name", ["gr17", "ring6_explicit", "bays29"])
+def test_explicit_matrix_form(ctx, name, tsplib_dir, goldens):
+    d = T.parse_tsplib(os.path.join(tsplib_dir, f"{name}.tsp"))
+    g = gpu_two_opt(ctx, None, d["packed"], d["n"])
+    assert_same(g, O.two_opt(None, d["packed"], d["n"]), d["n"])
+    assert g[0].tolist() == goldens[name]["identity_two_opt"]["route_pos"]
+
+
+def test_matrix_form_equals_on_the_fly_form_pr1002_size(ctx):
+    # BASELINE config 2 shape (pr1002 itself is not in the reference tree: synthetic n = 1002, labelled)
+    n = 1002
+    xy = O.synth_xy(n)
+    packed = O.dm_build_packed(xy)
+    rp = O.restart_perm(n, 5, 1)
+    a = gpu_two_opt(ctx, xy, None, n, rp)
+    b = gpu_two_opt(ctx, None, packed, n, rp)
+    assert a[0].tolist() == b[0].tolist() and a[1] == b[1]
+    assert_same(b, O.two_opt(None, packed, n, init=rp), n)
+
+
+def test_multistart_matches_per_restart_oracle(ctx):
+    import teeline_amd as TA
+    n, R, seed = 600, 12, 4242
+    xy = O.synth_xy(n, seed=21)
+    prob = TA.TspProblem(np.arange(n), xy)
+    sol, costs = TA.two_opt.multistart(prob, R, seed=seed, first=3, ctx=ctx, return_costs=True)
+    ocosts, oroutes = [], []
+    for r in range(3, 3 + R):
+        rc, p, c, st = O.two_opt(xy, None, n, init=O.restart_perm(n, seed, r))
+        ocosts.append(c)
+        oroutes.append(p)
+    assert [np.float32(c).tobytes() for c in costs] == [np.float32(c).tobytes() for c in ocosts]
+    keys = [ctx.lib.tl_pack_cost_key(float(c), 3 + i) for i, c in enumerate(ocosts)]
+    best = int(np.argmin(keys))
+    assert sol.stats["best_restart"] == 3 + best
+    assert list(sol.route()) == oroutes[best].tolist() and sol.total == ocosts[best]
+
+
+def test_tour_length_and_dm_build(ctx, tsplib_dir):
+    import teeline_amd as TA
+    b = T.parse_tsplib(os.path.join(tsplib_dir, "berlin52.tsp"))
+    dm = TA.distance_matrix.build(b["ids"], b["xy"], ctx=ctx)
+    assert np.array_equal(dm.items, O.dm_build_packed(b["xy"]))
+    opt = T.parse_opt_tour(os.path.join(tsplib_dir, "berlin52.opt.tour"))
+    assert f5(dm.tour_length(opt, ctx=ctx)) == "7544.36572"  # README.md:365
+    # n = 10^4: 49 995 000 correctly rounded sqrt, bit-for-bit (also the sqrt_rn check over dense mantissas)
+    xy = O.synth_xy(10000)
+    dmb, ms = TA.distance_matrix.build(np.arange(10000), xy, ctx=ctx, return_ms=True)
+    ref = O.dm_build_packed(xy)
+    assert np.array_equal(dmb.items.view(np.uint32), ref.view(np.uint32))
+    perm = O.restart_perm(10000, 3, 0)
+    assert dmb.tour_length_by_pos(perm, ctx=ctx).tobytes() == O.tour_length(xy, None, perm).tobytes()
+    # GEO (distance_matrix.rs:59-75, 457-464)
+    d = T.parse_tsplib(os.path.join(tsplib_dir, "burma14.tsp"))
+    geo = TA.distance_matrix.build(d["ids"], d["xy"], kind="geo", ctx=ctx)
+    assert np.array_equal(geo.items, O.dm_build_packed(d["xy"], geo=True))
+    pair = TA.distance_matrix.build([1, 2], np.array([[16.47, 96.10], [23.70, 96.99]], np.float32), kind="geo", ctx=ctx)
+    assert pair.items.tolist() == [837.0]
