@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X 2-opt engine (BASELINE.json metric).
+
+metric : 2-opt candidate swaps evaluated/sec (+ final tour cost), EUC_2D n = 10 000
+workload: BASELINE configs 3/4 — synthetic EUC_2D n=10000 (xorshift64 generator),
+          multi-start REF_ORDER 2-opt: R seeded random restarts per GPU, every restart a full
+          first-improvement descent to its local optimum (the reference's algorithm, two_opt.rs:26-61),
+          one descent per CU, all concurrently.  One "step" = one such batch.
+          Weak scaling: rank k runs restarts [k*R, (k+1)*R); after every step the ranks min-all-reduce
+          (RCCL) the packed key (f32 cost bits << 32 | restart id) of their best tour.
+          Inputs (coordinates) are resident in HBM before the timed region; restart permutations are
+          generated on the device inside the timed region (they are part of the job).
+candidates are counted as the reference's loop visits them: sweeps x (n-3)(n-2)/2 per descent.
+
+Usage: python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+ALG_BYTES_PER_CANDIDATE = 8.0   # one new tour-ordered (x,y) per j-step, on-the-fly form
+FP32_VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md chip table
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=10000)
+    ap.add_argument("--restarts", type=int, default=256, help="restarts per GPU per step (one per CU)")
+    ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-descent / no-prune / matrix-build extras")
+    return ap.parse_args()
+
+
+def cpu_baseline(n, seed, xy):
+    """Oracle ("port" of two_opt.rs:26-61) timed on this host's cores: one full restart descent per core,
+    all cores concurrently (ctypes releases the GIL).  Bounded: ~5e8 candidates per core (~5-10 s)."""
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    O.lib()
+    cores = max(1, min(os.cpu_count() or 1, 32))
+    res = [None] * cores
+
+    def work(k):
+        init = O.restart_perm(n, seed, k)
+        rc, p, c, st = O.two_opt(xy, None, n, init=init, flavor=0)
+        res[k] = (st["candidates"], float(c))
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    wall = time.perf_counter() - t0
+    total = sum(r[0] for r in res)
+    # the reference's own cost model (packed matrix + 2 SipHash id lookups per distance), 1 core, 1 sweep
+    t1 = time.perf_counter()
+    rc, p, c, st = O.two_opt(xy, None, n, init=O.restart_perm(n, seed, 0), flavor=1, max_candidates=1)
+    wall_f = time.perf_counter() - t1
+    return {
+        "value": total / wall, "unit": "candidates/s", "cores": cores, "kind": "port",
+        "sample": f"{cores} full restart descents (restarts 0..{cores - 1}, n={n}, ~{total / cores:.2e} candidates each), "
+                  f"one per core, on-the-fly f32 distances (best-effort flavour); wall {wall:.1f} s",
+        "per_core": total / wall / cores,
+        "ref_faithful_1core": {"value": st["candidates"] / wall_f, "unit": "candidates/s",
+                               "sample": f"1 sweep ({st['candidates']} candidates) of restart 0 with the packed matrix + "
+                                         f"two SipHash-1-3 id lookups per distance (distance_matrix.rs:197-212), "
+                                         f"incl. 200 MB matrix build; wall {wall_f:.1f} s"},
+    }
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libteeline_gpu has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import teeline_amd as TA
+    from teeline_amd import _capi
+    n, R = a.n, a.restarts
+    xy = TA.synth.synth_xy(n)
+    ctx = TA.Context(local)
+    info = ctx.device_info()
+    lib, h = ctx.lib, ctx.handle
+
+    d_xy = torch.from_numpy(xy).to(dev)
+    d_pos = torch.empty((R, n), dtype=torch.int32, device=dev)
+    d_cost = torch.empty(R, dtype=torch.float32, device=dev)
+    d_stats = torch.zeros((R, _capi.TL_DEV_STATS_STRIDE), dtype=torch.int64, device=dev)
+    ids = torch.arange(rank * R, rank * R + R, dtype=torch.int64, device=dev)
+    per_sweep = (n - 3) * (n - 2) // 2
+    stream = torch.cuda.current_stream()
+
+    def step():
+        ctx.check(lib.tl_two_opt_batch_dev(h, d_xy.data_ptr(), n, None, a.seed, rank * R, R, _capi.TL_MODE_REF_ORDER,
+                                           d_pos.data_ptr(), d_cost.data_ptr(), d_stats.data_ptr(),
+                                           C.c_void_p(stream.cuda_stream)))
+        key = ((d_cost.view(torch.int32).to(torch.int64) << 32) | ids).min().reshape(1)
+        if dist is not None:
+            dist.all_reduce(key, op=dist.ReduceOp.MIN)  # RCCL over xGMI: 8 bytes per round
+        return key
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    kernel_ms, cands = [], 0
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        key = step()
+        kernel_ms.append(ctx.last_kernel_ms())       # HIP events on the launch stream (syncs on the end event)
+        cands += int(d_stats[:, 0].sum().item()) * per_sweep
+    sync()
+    dt = time.perf_counter() - t0
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    c = torch.tensor([cands], dtype=torch.int64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    dt_max, total = float(t.item()), int(c.item())
+    best_key = int(key.item())
+    best_cost = float(np.frombuffer(np.uint32(best_key >> 32).tobytes(), dtype=np.float32)[0])
+    best_restart = best_key & 0xFFFFFFFF
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    status_bad = int((d_stats[:, 3] != 0).sum().item())
+    k_ms = float(np.mean(kernel_ms))
+    cand_per_launch = cands / a.steps
+    achieved = cand_per_launch * ALG_BYTES_PER_CANDIDATE / (k_ms * 1e-3) / 1e9
+    out = {
+        "metric": "2-opt candidate swaps evaluated/sec + final tour cost, TSPLIB EUC_2D n=10000",
+        "value": total / dt_max,
+        "unit": "candidates/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt_max / a.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"configs[2]/[3]: synthetic EUC_2D n={n} (xorshift64 seed 88172645463325252), multi-start "
+                               f"REF_ORDER 2-opt to local optimum, {R} seeded random restarts per GPU (one descent per CU), "
+                               f"on-the-fly f32 distances, tour resident in LDS",
+                   "n": n, "restarts_per_gpu": R, "restarts_total": R * world, "mode": "REF_ORDER",
+                   "restart_seed": a.seed, "collective": "RCCL min-all-reduce of (cost_bits<<32|restart) per step" if world > 1 else "none (1 GPU)"},
+        "final_tour_cost": best_cost, "best_restart": best_restart,
+        "candidates_per_step_per_gpu": cand_per_launch,
+        "descents_not_converged": status_bad,
+        "device": info,
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": None,
+            "kernel": "k_two_opt_ref_lds", "kernel_ms_avg": k_ms, "launches": a.steps,
+            "algorithmic_bytes_per_candidate": ALG_BYTES_PER_CANDIDATE,
+            "note": "algorithmic bytes = 8 B per candidate (SURVEY.md §8(d)); the tour lives in LDS for the whole descent, so real "
+                    "HBM traffic is ~n*(8+4) B per restart and the kernel is VALU/LDS/latency-bound, not HBM-bound (DESIGN.md §5)",
+        },
+    }
+    # traffic from a committed PMC pass, if one exists for this round
+    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            out["roofline"]["traffic"] = json.load(open(tpath)).get("traffic_bytes_per_launch")
+        except Exception:
+            pass
+
+    if world == 1 and not a.no_extras:
+        extras = {}
+        prob = TA.TspProblem(np.arange(n), xy)
+        init = TA.synth.restart_perm(n, a.seed, 0)
+        sol = TA.two_opt.solve(prob, None, None, [int(v) for v in init], ctx=ctx)
+        extras["single_descent_random_start"] = {"candidates_per_s": sol.stats["candidates"] / (sol.stats["kernel_ms"] * 1e-3),
+                                                 "kernel_ms": sol.stats["kernel_ms"], "cost": float(sol.total),
+                                                 "moves": sol.stats["moves"], "sweeps": sol.stats["sweeps"]}
+        with TA.Context(local, TA.TL_FLAG_NO_PRUNE) as c2:
+            s2 = TA.two_opt.multistart(prob, R, seed=a.seed, first=0, ctx=c2)
+            extras["no_prune_multistart"] = {"candidates_per_s": s2.stats["candidates"] / (s2.stats["kernel_ms"] * 1e-3),
+                                             "kernel_ms": s2.stats["kernel_ms"], "best_cost": float(s2.total),
+                                             "note": "TL_FLAG_NO_PRUNE: every candidate decided with two fresh correctly rounded sqrt"}
+        dm, ms = TA.distance_matrix.build(np.arange(n), xy, ctx=ctx, return_ms=True)
+        dm, ms = TA.distance_matrix.build(np.arange(n), xy, ctx=ctx, return_ms=True)
+        gb = n * (n - 1) / 2 * 4 / 1e9
+        extras["dm_build_packed"] = {"kernel_ms": ms, "GBps": gb / (ms * 1e-3), "frac_of_hbm_peak": gb / (ms * 1e-3) / HBM_PEAK_GBPS,
+                                     "bytes": n * (n - 1) // 2 * 4}
+        out["extras"] = extras
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(n, a.seed, xy)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

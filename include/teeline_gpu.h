@@ -79,6 +79,9 @@ typedef enum tl_mode {
 #define TL_DIST_EUC2D 0 /* kdtree.rs:291-295            */
 #define TL_DIST_GEO 1   /* distance_matrix.rs:59-75     */
 
+/* u64 words per descent written by tl_two_opt_batch_dev into d_out_stats */
+#define TL_DEV_STATS_STRIDE 16
+
 typedef struct tl_stats {
     uint64_t sweeps;     /* 2-opt: `while improved` iterations; 3-opt: passes; LK: lk_pass scans      */
     uint64_t candidates; /* candidates whose delta test was decided, counted as the reference's loop  */
@@ -153,7 +156,7 @@ uint64_t tl_pack_cost_key(float cost, uint32_t restart);
 /* ---- device-resident batch entry (bench / pipelines that keep data in HBM) ------------------- */
 /* All d_* are DEVICE pointers on the context's device.  d_init: count x n u32 (NULL: seeded restarts
  * first..first+count as above; seed ignored otherwise).  d_out_pos: count x n u32, d_out_cost: count f32,
- * d_out_stats: count x 4 u64 {sweeps, moves, reversed, status}.  stream: hipStream_t or NULL for the
+ * d_out_stats: count x TL_DEV_STATS_STRIDE u64 {sweeps, moves, reversed, status, steps, reserved...}.  stream: hipStream_t or NULL for the
  * context's stream.  Asynchronous: returns after enqueueing. */
 int tl_two_opt_batch_dev(tl_ctx *ctx, const float *d_xy, uint32_t n, const uint32_t *d_init,
                          uint64_t seed, uint32_t first, uint32_t count, int mode, uint32_t *d_out_pos,

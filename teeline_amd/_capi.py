@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libteeline_gpu.so")
+# TEELINE_GPU_LIB: developer override to load a differently-built variant (tuning experiments)
+LIB_PATH = os.environ.get("TEELINE_GPU_LIB") or os.path.join(_HERE, "libteeline_gpu.so")
+TL_DEV_STATS_STRIDE = 16
 
 TL_OK = 0
 TL_ERR_BADARG, TL_ERR_REF_PANICS, TL_ERR_NO_DEVICE, TL_ERR_HIP = -1, -2, -3, -4

@@ -42,16 +42,18 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra_flags=()):
-    if not force and not needs_build():
+def build(force=False, verbose=False, extra_flags=(), out=None):
+    """out: alternative output path (tuning variants built with extra -D flags); default = the product library."""
+    if out is None and not force and not needs_build():
         return LIB
-    cmd = [_hipcc()] + FLAGS + list(extra_flags) + ["-I", os.path.join(ROOT, "include"), "-o", LIB + ".tmp"]
+    LIB_OUT = out or LIB
+    cmd = [_hipcc()] + FLAGS + list(extra_flags) + ["-I", os.path.join(ROOT, "include"), "-o", LIB_OUT + ".tmp"]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(LIB_OUT + ".tmp", LIB_OUT)
+    return LIB_OUT
 
 
 if __name__ == "__main__":

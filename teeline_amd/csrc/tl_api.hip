@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -149,13 +150,14 @@ extern "C" int tl_device_info(const tl_ctx *c, int *cus, int *lds_bytes, char *a
 
 static uint32_t lds_max_n(int lds_bytes)
 {
-    // 10 B per city (float2 + u16) on n rounded up to 64 plus one pad tile, + control + scratch
-    const long avail = (long)lds_bytes - 64 - (long)TL_TWO_OPT_NT * 4;
-    long n_pad = avail / 10;
-    n_pad -= n_pad % 64;
-    long n = n_pad - 64;
-    if (n > 65535) n = 65535;  // u16 tour entries, (i<<16|j) keys
-    return n < 0 ? 0u : (uint32_t)n;
+    // largest n whose LDS image (10 B per city on a padded length + control + queues) fits one workgroup
+    uint32_t lo = 0, hi = 65535;  // u16 tour entries, (i<<16|j) keys
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo + 1) / 2;
+        if (two_opt_ref_lds_bytes(mid, nullptr, TL_TWO_OPT_NT) <= (size_t)lds_bytes) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
 }
 
 extern "C" uint32_t tl_two_opt_lds_max_n(const tl_ctx *c) { return c ? lds_max_n(c->lds_bytes) : 0u; }
@@ -293,9 +295,9 @@ static void fill_stats(tl_stats *st, uint32_t n, const uint64_t *raw, uint32_t c
     memset(st, 0, sizeof(*st));
     const uint64_t per_sweep = n >= 4 ? (uint64_t)(n - 3) * (n - 2) / 2 : 0;
     for (uint32_t r = 0; r < count; ++r) {
-        st->sweeps += raw[4 * r + 0];
-        st->moves += raw[4 * r + 1];
-        st->reversed += raw[4 * r + 2];
+        st->sweeps += raw[TL_STATS_STRIDE * r + 0];
+        st->moves += raw[TL_STATS_STRIDE * r + 1];
+        st->reversed += raw[TL_STATS_STRIDE * r + 2];
     }
     st->candidates = st->sweeps * per_sweep;
     st->kernel_ms = kernel_ms;
@@ -316,7 +318,7 @@ extern "C" int tl_two_opt(tl_ctx *c, const float *xy, uint32_t n, const float *d
     const auto t0 = std::chrono::steady_clock::now();
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
-    if ((rc = ensure(c, c->out_pos, (size_t)n * 4)) || (rc = ensure(c, c->out_cost, 4)) || (rc = ensure(c, c->out_stats, 32))) return rc;
+    if ((rc = ensure(c, c->out_pos, (size_t)n * 4)) || (rc = ensure(c, c->out_cost, 4)) || (rc = ensure(c, c->out_stats, TL_STATS_STRIDE * 8))) return rc;
     const float2 *dxy = nullptr;
     const float *ddm = nullptr;
     if (dm_packed) {
@@ -339,12 +341,17 @@ extern "C" int tl_two_opt(tl_ctx *c, const float *xy, uint32_t n, const float *d
     if ((rc = two_opt_enqueue(c, dxy, ddm, n, dinit, dinit ? TL_INIT_ARRAY : TL_INIT_IDENTITY, 0, 0, 1, mode,
                               (uint32_t *)c->out_pos.p, (float *)c->out_cost.p, (uint64_t *)c->out_stats.p, c->stream)))
         return rc;
-    uint64_t raw[4];
+    uint64_t raw[TL_STATS_STRIDE];
     float cost = 0.f;
     HIPCHK(c, hipMemcpyAsync(out_pos, c->out_pos.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(&cost, c->out_cost.p, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(raw, c->out_stats.p, 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(raw, c->out_stats.p, TL_STATS_STRIDE * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (getenv("TL_DUMP_STATS")) {
+        fprintf(stderr, "[tl] raw stats:");
+        for (int q = 0; q < TL_STATS_STRIDE; ++q) fprintf(stderr, " %llu", (unsigned long long)raw[q]);
+        fprintf(stderr, "\n");
+    }
     if (raw[3] != 0) return fail(c, TL_ERR_NO_CONVERGE, "two_opt: sweep cap reached");
     if (out_cost) *out_cost = cost;
     double kms = 0;
@@ -371,21 +378,21 @@ extern "C" int tl_two_opt_multistart(tl_ctx *c, const float *xy, uint32_t n, uin
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
     if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->out_pos, (size_t)count * n * 4)) ||
-        (rc = ensure(c, c->out_cost, (size_t)count * 4)) || (rc = ensure(c, c->out_stats, (size_t)count * 32)))
+        (rc = ensure(c, c->out_cost, (size_t)count * 4)) || (rc = ensure(c, c->out_stats, (size_t)count * TL_STATS_STRIDE * 8)))
         return rc;
     HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     if ((rc = two_opt_enqueue(c, (const float2 *)c->xy.p, nullptr, n, nullptr, TL_INIT_SEEDED, seed, first, count, mode,
                               (uint32_t *)c->out_pos.p, (float *)c->out_cost.p, (uint64_t *)c->out_stats.p, c->stream)))
         return rc;
     std::vector<float> costs(count);
-    std::vector<uint64_t> raw((size_t)count * 4);
+    std::vector<uint64_t> raw((size_t)count * TL_STATS_STRIDE);
     HIPCHK(c, hipMemcpyAsync(costs.data(), c->out_cost.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(raw.data(), c->out_stats.p, (size_t)count * 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(raw.data(), c->out_stats.p, (size_t)count * TL_STATS_STRIDE * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     uint32_t best = 0;
     uint64_t best_key = ~0ull;
     for (uint32_t r = 0; r < count; ++r) {
-        if (raw[4 * r + 3] != 0) return fail(c, TL_ERR_NO_CONVERGE, "two_opt: sweep cap reached in restart %u", first + r);
+        if (raw[TL_STATS_STRIDE * r + 3] != 0) return fail(c, TL_ERR_NO_CONVERGE, "two_opt: sweep cap reached in restart %u", first + r);
         const uint64_t k = tl_pack_cost_key(costs[r], first + r);
         if (k < best_key) {
             best_key = k;

@@ -8,6 +8,9 @@
 
 namespace tl {
 
+// u64 words per descent in out_stats: sweeps, moves, reversed, status, steps, then profile words
+#define TL_STATS_STRIDE 16
+
 enum : uint32_t { TL_INIT_IDENTITY = 0, TL_INIT_ARRAY = 1, TL_INIT_SEEDED = 2 };
 
 struct TwoOptBatchArgs {
@@ -16,7 +19,7 @@ struct TwoOptBatchArgs {
     const uint32_t *init;    // [count][n] when init_mode == TL_INIT_ARRAY
     uint32_t *out_pos;       // [count][n]
     float *out_cost;         // [count]
-    uint64_t *out_stats;     // [count][4] = sweeps, moves, reversed, status(0 ok, 1 sweep cap)
+    uint64_t *out_stats;     // [count][TL_STATS_STRIDE] = sweeps, moves, reversed, status(0 ok, 1 sweep cap), steps, ...
     uint64_t seed;
     uint32_t first;          // restart index of descent 0 (seeded init)
     uint32_t n;

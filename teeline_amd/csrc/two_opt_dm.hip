@@ -122,11 +122,12 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
     }
     if (tid == 0) {
         A.out_cost[d] = total;
-        uint64_t *st = A.out_stats + (size_t)d * 4;
+        uint64_t *st = A.out_stats + (size_t)d * TL_STATS_STRIDE;
         st[0] = sweeps;
         st[1] = moves;
         st[2] = reversed;
         st[3] = status;
+        st[4] = step;
     }
 }
 

@@ -28,22 +28,65 @@ namespace tl {
 namespace {
 
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
-constexpr int kRMax = 32;        // rows per speculative block (<= 63: row table is lane-resident)
-constexpr float kStepCost = 3000.0f;  // per-step fixed overhead in candidate-equivalents (tuning only)
+#ifndef TL_RMAX
+#define TL_RMAX 32
+#endif
+#ifndef TL_STEP_COST
+#define TL_STEP_COST 3000.0f
+#endif
+constexpr int kRMax = TL_RMAX;             // rows per speculative block (<= 63: row table is lane-resident)
+constexpr float kStepCost = TL_STEP_COST;  // per-step fixed overhead in candidate-equivalents (tuning only)
+
+#ifdef TL_PROFILE
+#define TL_STAMP(var) do { if (tid == 0) { const uint64_t _t = __builtin_amdgcn_s_memtime(); prof[var] += _t - tlast; tlast = _t; } } while (0)
+#else
+#define TL_STAMP(var) do { } while (0)
+#endif
+constexpr uint32_t kQCap = 128;       // per-wave survivor queue entries (power of two, >= 2 * 64)
 
 struct Ctl {
     uint32_t keys[4];
 };
 
-template <bool PRUNE, bool MASKED>
-__device__ __forceinline__ int scan_rows(const float2 c, const float2 e, const float sqce,
-                                         const float rowx, const float rowy, const float rowsq,
-                                         const int rlo, const int rhi, const uint32_t i0,
-                                         const uint32_t j, const uint32_t j0, uint32_t *hit_j)
+// Exact decision for up to 64 queued survivors of the squared-distance pre-test, one per lane.
+// Level 2: the hardware v_sqrt_f32 (<= 1 ulp) decides every candidate whose |new - cur| exceeds a
+// margin ~3x the worst-case accumulated error; level 3: the few near-ties (and degenerate tiny
+// operands) take four correctly rounded sqrt — the reference's arithmetic (two_opt.rs:35-49).
+__device__ __forceinline__ void flush_survivors(const float2 *P, const uint32_t *q, uint32_t head,
+                                                uint32_t count, uint32_t *keyslot, int lane)
 {
-    // returns the first row r in [rlo, rhi) with an improving lane (and that lane's j), else -1
-    float ax = readlane_f(rowx, rlo), ay = readlane_f(rowy, rlo);
-    for (int r = rlo; r < rhi; ++r) {
+    const bool act = (uint32_t)lane < count;
+    const uint32_t key = act ? q[(head + (uint32_t)lane) & (kQCap - 1u)] : 0u;
+    const uint32_t i = key >> 16, j = key & 0xFFFFu;
+    const float2 a = P[i], b = P[i + 1u], c = P[j], e = P[j + 1u];
+    const float s1 = sqdist(a, c), s2 = sqdist(b, e), sab = sqdist(a, b), sce = sqdist(c, e);
+    const float neu_a = __builtin_amdgcn_sqrtf(s1) + __builtin_amdgcn_sqrtf(s2);
+    const float cur_a = __builtin_amdgcn_sqrtf(sab) + __builtin_amdgcn_sqrtf(sce);
+    const float margin = cur_a * 1.9073486e-6f;  // 2^-19
+    const float smin = fminf(fminf(s1, s2), fminf(sab, sce));
+    bool imp = act & (neu_a < cur_a - margin);
+    const bool tie = act & !imp & ((neu_a <= cur_a + margin) | (smin < 1e-30f) | !(cur_a < 3.0e38f));
+    if (__builtin_amdgcn_ballot_w64(tie)) {
+        const float neu = sqrt_rn(s1) + sqrt_rn(s2);
+        const float cur = sqrt_rn(sab) + sqrt_rn(sce);
+        imp = act & (tie ? (neu < cur) : imp);
+    }
+    if (imp) atomicMin(keyslot, key);
+}
+
+// Scans rows [0, rhi) of the block against one 64-wide j tile held in registers.
+// PRUNE: survivors of the exact squared-distance pre-test are queued (per-wave ring in LDS) and
+// decided 64 at a time by flush_survivors.  !PRUNE: every in-range candidate is decided inline with
+// four correctly rounded sqrt (TL_FLAG_NO_PRUNE).
+template <bool PRUNE, bool MASKED>
+__device__ __forceinline__ void scan_rows(const float2 *P, const float2 c, const float2 e, const float sqce,
+                                          const float rowx, const float rowy, const float rowsq, int rhi,
+                                          const uint32_t i0, const uint32_t tb, const uint32_t j,
+                                          const uint32_t j0, uint32_t *q, uint32_t &head, uint32_t &tail,
+                                          uint32_t *keyslot, const int lane)
+{
+    float ax = readlane_f(rowx, 0), ay = readlane_f(rowy, 0);
+    for (int r = 0; r < rhi; ++r) {
         const float bx = readlane_f(rowx, r + 1), by = readlane_f(rowy, r + 1);
         const float sqab = readlane_f(rowsq, r);
         float dx = ax - c.x, dy = ay - c.y;
@@ -51,27 +94,44 @@ __device__ __forceinline__ int scan_rows(const float2 c, const float2 e, const f
         dx = bx - e.x;
         dy = by - e.y;
         const float s2 = dx * dx + dy * dy;
+        ax = bx;
+        ay = by;
         bool test;
         if (PRUNE) test = (s1 < sqab) | (s2 < sqce);
-        else test = (sqce >= 0.0f);  // every in-range lane takes the exact path
+        else test = (sqce >= 0.0f);  // every in-range lane
         if (MASKED) {
             const uint32_t jmin = (r == 0) ? j0 : (i0 + (uint32_t)r + 2u);
             test = test & (j >= jmin);
         }
-        if (__builtin_amdgcn_ballot_w64(test)) {
-            const float dac = sqrt_rn(s1), dbe = sqrt_rn(s2);
-            const float dab = sqrt_rn(sqab), dce = sqrt_rn(sqce);
-            const bool imp = test & ((dac + dbe) < (dab + dce));  // two_opt.rs:35-49
-            const uint64_t m = __builtin_amdgcn_ballot_w64(imp);
-            if (m) {
-                *hit_j = j - (uint32_t)(threadIdx.x & 63) + (uint32_t)(__builtin_ffsll((long long)m) - 1);
-                return r;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(test);
+        if (m == 0) continue;
+        const uint32_t key = ((i0 + (uint32_t)r) << 16) | j;
+        if (PRUNE) {
+            const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (test) q[(tail + off) & (kQCap - 1u)] = key;
+            tail += (uint32_t)__builtin_popcountll(m);
+            if (tail - head >= 64u) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                flush_survivors(P, q, head, 64u, keyslot, lane);
+                head += 64u;
+                // a hit bounds the rows this tile still has to look at
+                const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot);
+                if (kb != kNoKey) {
+                    const int lim = (int)((kb >> 16) - i0) + (tb <= (kb & 0xFFFFu) ? 1 : 0);
+                    rhi = rhi < lim ? rhi : lim;
+                }
+            }
+        } else {
+            const float neu = sqrt_rn(s1) + sqrt_rn(s2);
+            const float cur = sqrt_rn(sqab) + sqrt_rn(sqce);
+            const bool imp = test & (neu < cur);  // two_opt.rs:35-49
+            const uint64_t mi = __builtin_amdgcn_ballot_w64(imp);
+            if (mi) {
+                if (lane == 0) atomicMin(keyslot, (key & 0xFFFF0000u) | (tb + (uint32_t)(__builtin_ffsll((long long)mi) - 1)));
+                return;  // later rows of this tile are lexicographically later
             }
         }
-        ax = bx;
-        ay = by;
     }
-    return -1;
 }
 
 }  // namespace
@@ -85,7 +145,9 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     float2 *P = reinterpret_cast<float2 *>(smem);
     uint16_t *perm = reinterpret_cast<uint16_t *>(smem + (size_t)npad * 8);
     Ctl *ctl = reinterpret_cast<Ctl *>(smem + (size_t)npad * 10);
-    float *scratch = reinterpret_cast<float *>(smem + (size_t)npad * 10 + 64);  // NT floats
+    // survivor queues (NW x kQCap u32) during the descent; reused as NT floats for the cost sum
+    uint32_t *queues = reinterpret_cast<uint32_t *>(smem + (size_t)npad * 10 + 64);
+    float *scratch = reinterpret_cast<float *>(queues);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> SGPR loop control
@@ -130,6 +192,12 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     uint32_t sweeps = 1, step = 0, status = 0;
     uint64_t moves = 0, reversed = 0;
     float gap_est = 0.0f, since = 0.0f;
+#ifdef TL_PROFILE
+    uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tlast = __builtin_amdgcn_s_memtime();
+    const uint64_t t_begin = tlast, rt_begin = __builtin_amdgcn_s_memrealtime();
+    uint64_t rows_total = 0;
+#endif
 
     while (n >= 4) {
         const uint32_t slot = step % 3u;
@@ -148,8 +216,12 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         const float2 rq = P[i0 + (uint32_t)lane + 1u];
         const float rowsq = sqdist(rp, rq);
 
+        TL_STAMP(0);
         // row 0 resumes at j0; rows r >= 1 start at their own diagonal i0+r+2 (<= j0 possible)
         const uint32_t tile_lo = ((R == 1) ? j0 : (i0 + 2u)) >> 6;
+        uint32_t *q = queues + (uint32_t)wave * kQCap;
+        uint32_t qhead = 0, qtail = 0;
+        uint32_t *keyslot = &ctl->keys[slot];
         for (uint32_t tb = (tile_lo + (uint32_t)wave) << 6; tb <= n - 2u; tb += (uint32_t)NW << 6) {
             const uint32_t j = tb + (uint32_t)lane;
             float2 c = P[j];
@@ -164,7 +236,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             {
                 const int lim = (int)(tb + 62u - i0);  // need i + 2 <= tb + 63
                 rhi = rhi < lim ? rhi : lim;
-                const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->keys[slot]);
+                const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot);
                 if (kb != kNoKey) {
                     const int kr = (int)((kb >> 16) - i0), kj = (int)(kb & 0xFFFFu);
                     const int lim2 = kr + ((int)tb <= kj ? 1 : 0);
@@ -174,14 +246,22 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             if (rhi <= 0) continue;
             // first row of the block resumes at j0; rows below the diagonal need j >= i+2
             const bool masked = (tb < j0) | (tb < i0 + (uint32_t)rhi + 1u);
-            uint32_t hj = 0;
-            int hr;
-            if (masked) hr = scan_rows<PRUNE, true>(c, e, sqce, rp.x, rp.y, rowsq, 0, rhi, i0, j, j0, &hj);
-            else hr = scan_rows<PRUNE, false>(c, e, sqce, rp.x, rp.y, rowsq, 0, rhi, i0, j, j0, &hj);
-            if (hr >= 0 && lane == 0) atomicMin(&ctl->keys[slot], ((i0 + (uint32_t)hr) << 16) | hj);
+            if (masked) scan_rows<PRUNE, true>(P, c, e, sqce, rp.x, rp.y, rowsq, rhi, i0, tb, j, j0, q, qhead, qtail, keyslot, lane);
+            else scan_rows<PRUNE, false>(P, c, e, sqce, rp.x, rp.y, rowsq, rhi, i0, tb, j, j0, q, qhead, qtail, keyslot, lane);
+            // decide this tile's survivors before moving on: a hit found now stops the other tiles/waves early
+            if (PRUNE && qtail != qhead) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                flush_survivors(P, q, qhead, qtail - qhead, keyslot, lane);
+                qhead = qtail;
+            }
         }
+        TL_STAMP(1);
         __syncthreads();
+        TL_STAMP(2);
         const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->keys[slot]);
+#ifdef TL_PROFILE
+        rows_total += (uint64_t)R;
+#endif
 
         if (key == kNoKey) {
             since += (float)R * rowlen;
@@ -200,7 +280,9 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 perm[lo + t] = v;
                 perm[hi - t] = u;
             }
+            TL_STAMP(3);
             __syncthreads();
+            TL_STAMP(4);
             improved = true;
             ++moves;
             reversed += (uint64_t)(js - is);
@@ -256,11 +338,18 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     }
     if (tid == 0) {
         A.out_cost[d] = total;
-        uint64_t *st = A.out_stats + (size_t)d * 4;
+        uint64_t *st = A.out_stats + (size_t)d * TL_STATS_STRIDE;
         st[0] = sweeps;
         st[1] = moves;
         st[2] = reversed;
         st[3] = status;
+        st[4] = step;
+#ifdef TL_PROFILE
+        for (int q = 0; q < 5; ++q) st[5 + q] = prof[q];
+        st[10] = __builtin_amdgcn_s_memtime() - t_begin;
+        st[11] = __builtin_amdgcn_s_memrealtime() - rt_begin;
+        st[12] = rows_total;
+#endif
     }
 }
 
@@ -271,7 +360,8 @@ size_t two_opt_ref_lds_bytes(uint32_t n, uint32_t *n_pad_out, int nt)
 {
     const uint32_t n_pad = ((n + 64u + 63u) / 64u) * 64u;  // P[j+1] of any lane of the last tile is in range
     if (n_pad_out) *n_pad_out = n_pad;
-    return (size_t)n_pad * 10 + 64 + (size_t)nt * 4;
+    const size_t tail = (size_t)(nt / 64) * kQCap * 4;  // survivor queues, >= nt floats of scratch
+    return (size_t)n_pad * 10 + 64 + (tail > (size_t)nt * 4 ? tail : (size_t)nt * 4);
 }
 
 template <int NT, bool PRUNE>
