@@ -7,18 +7,23 @@
 // sequential *between* moves and parallel only *within* the stretch of candidates up to the next
 // improving one.  MI355X mapping:
 //   - one descent = one workgroup = one CU; tour-ordered coordinates P[k] = xy[perm[k]] (float2) and
-//     perm (u16) live in that CU's LDS for the whole descent (10 B/city: n <= ~16 K) — zero HBM
+//     perm (u16) live in that CU's LDS for the whole descent (10 B/city: n <= ~15 K) — zero HBM
 //     traffic inside the loop; 256 CUs = 256 concurrent restarts (north-star config 4);
-//   - a step speculatively evaluates a block of R rows (i0..i0+R) x all j under "no move yet":
-//     lanes run along j (stride-1 LDS reads), the row endpoints a=P[i], b=P[i+1] are wave-uniform
-//     (v_readlane -> SGPR operands); the lexicographically first improving (i,j) is reduced with
-//     ballot/ffs per wave and one ds_min_u32 per wave on a packed key (i<<16 | j);
-//   - the workgroup applies that reversal cooperatively in LDS and resumes at (i, j+1), exactly
-//     where the reference's inner loop continues; R adapts to the observed gap between moves.
-// Exact pruning: d_ac + d_be < d_ab + d_ce can only hold if sq_ac < sq_ab or
-// sq_be < sq_ce (f32 sqrt and add are monotone), so a candidate is decided "not improving" from
-// squared distances alone; only the rare survivors pay the four correctly rounded sqrt.  The
-// decision for every candidate is identical to the reference's; TL_FLAG_NO_PRUNE disables it.
+//   - a step speculatively decides a block of R rows (i0..i0+R) x all j under "no move yet" and
+//     reduces the lexicographically first improving (i,j) with one ds_min_u32 on a packed key
+//     (i<<16 | j); the workgroup then applies that reversal cooperatively in LDS and resumes at
+//     (i, j+1), exactly where the reference's inner loop continues.
+//
+// Every candidate is decided exactly as the reference decides it, by a cascade of exact tests
+// (DESIGN.md "Exact decision cascade"; f32 add, mul, sqrt are monotone, so each bound holds in
+// the reference's own arithmetic, not just over the reals):
+//   L0  tile bound   lanes = 64-position tiles.  With box_t the bounding box of P[64t..64t+64] and
+//                    msq_t the largest squared tour-edge in the tile: if lb(a, box_t) >= sq_ab and
+//                    lb(b, box_t) >= msq_t then no j in tile t can improve row (a,b).
+//   L1  pair bound   lanes = j.  improving  =>  sq_ac < sq_ab  or  sq_be < sq_ce.
+//   L2  approximate  v_sqrt_f32 (<= 1 ulp) decides unless |new - cur| is within ~3x the error bound.
+//   L3  exact        four correctly rounded sqrt, two adds, strict compare (two_opt.rs:35-49).
+// TL_FLAG_NO_PRUNE runs L3 on every candidate instead.
 #include "tl_kernels.h"
 
 #pragma clang fp contract(off)
@@ -29,29 +34,79 @@ namespace {
 
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 #ifndef TL_RMAX
-#define TL_RMAX 32
+#define TL_RMAX 16
 #endif
-#ifndef TL_STEP_COST
-#define TL_STEP_COST 3000.0f
+#ifndef TL_DENSE_ROWS
+#define TL_DENSE_ROWS 8.0f
 #endif
-constexpr int kRMax = TL_RMAX;             // rows per speculative block (<= 63: row table is lane-resident)
-constexpr float kStepCost = TL_STEP_COST;  // per-step fixed overhead in candidate-equivalents (tuning only)
+constexpr int kRMax = TL_RMAX;        // rows per speculative block in pruned mode (<= 63: lane-resident row table)
+constexpr uint32_t kQCap = 128;       // per-wave survivor queue entries (power of two, >= 2 * 64)
+constexpr int kMaxGroups = 4;         // 64-tile groups: n_pad <= 4 * 64 * 64 = 16384
 
 #ifdef TL_PROFILE
 #define TL_STAMP(var) do { if (tid == 0) { const uint64_t _t = __builtin_amdgcn_s_memtime(); prof[var] += _t - tlast; tlast = _t; } } while (0)
 #else
 #define TL_STAMP(var) do { } while (0)
 #endif
-constexpr uint32_t kQCap = 128;       // per-wave survivor queue entries (power of two, >= 2 * 64)
 
 struct Ctl {
     uint32_t keys[4];
 };
 
-// Exact decision for up to 64 queued survivors of the squared-distance pre-test, one per lane.
-// Level 2: the hardware v_sqrt_f32 (<= 1 ulp) decides every candidate whose |new - cur| exceeds a
-// margin ~3x the worst-case accumulated error; level 3: the few near-ties (and degenerate tiny
-// operands) take four correctly rounded sqrt — the reference's arithmetic (two_opt.rs:35-49).
+template <int CTRL>
+__device__ __forceinline__ float dpp_shr(float v)
+{
+    // row_shr within rows of 16 lanes; lanes without a source keep their own value (old = v)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_min(float v)
+{
+    v = fminf(v, dpp_shr<0x111>(v));
+    v = fminf(v, dpp_shr<0x112>(v));
+    v = fminf(v, dpp_shr<0x114>(v));
+    v = fminf(v, dpp_shr<0x118>(v));  // lane 15 of each row: min of the row (min is idempotent)
+    return fminf(fminf(readlane_f(v, 15), readlane_f(v, 31)), fminf(readlane_f(v, 47), readlane_f(v, 63)));
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+    v = fmaxf(v, dpp_shr<0x111>(v));
+    v = fmaxf(v, dpp_shr<0x112>(v));
+    v = fmaxf(v, dpp_shr<0x114>(v));
+    v = fmaxf(v, dpp_shr<0x118>(v));
+    return fmaxf(fmaxf(readlane_f(v, 15), readlane_f(v, 31)), fmaxf(readlane_f(v, 47), readlane_f(v, 63)));
+}
+
+// L0 metadata of tile t: bounding box of P[64t .. 64t+64] over the positions that take part in a
+// candidate (j <= n-2 as c, j+1 as e) and the largest squared tour-edge sq(P[j],P[j+1]) in it.
+__device__ __forceinline__ void build_tile_meta(const float2 *P, uint32_t n, uint32_t t, int lane, float4 *tbox, float *tmsq)
+{
+    const uint32_t j = (t << 6) + (uint32_t)lane;
+    const bool valid = j + 2u <= n;  // j <= n-2
+    const float2 c = P[j], e = P[j + 1u];
+    const float inf = __builtin_inff();
+    const float mnx = wave_min(valid ? fminf(c.x, e.x) : inf), mny = wave_min(valid ? fminf(c.y, e.y) : inf);
+    const float mxx = wave_max(valid ? fmaxf(c.x, e.x) : -inf), mxy = wave_max(valid ? fmaxf(c.y, e.y) : -inf);
+    const float msq = wave_max(valid ? sqdist(c, e) : -1.0f);
+    if (lane == 0) {
+        tbox[t] = make_float4(mnx, mny, mxx, mxy);
+        tmsq[t] = msq;
+    }
+}
+
+// f32 lower bound of sqdist(p, q) over every q inside the box (monotone ops only -> valid in f32).
+// d = max(lo - p, p - hi, 0) is taken on the bit patterns as signed ints: negative floats are negative
+// ints and non-negative floats order like ints, so one v_max3_i32 does it without NaN canonicalisation.
+__device__ __forceinline__ float box_lb(float px, float py, float4 box)
+{
+    const int ux = __builtin_bit_cast(int, box.x - px), vx = __builtin_bit_cast(int, px - box.z);
+    const int uy = __builtin_bit_cast(int, box.y - py), vy = __builtin_bit_cast(int, py - box.w);
+    const int mx = ux > vx ? ux : vx, my = uy > vy ? uy : vy;
+    const float dx = __builtin_bit_cast(float, mx > 0 ? mx : 0);
+    const float dy = __builtin_bit_cast(float, my > 0 ? my : 0);
+    return dx * dx + dy * dy;
+}
+
+// L2 + L3 for up to 64 queued survivors of L1, one per lane.
 __device__ __forceinline__ void flush_survivors(const float2 *P, const uint32_t *q, uint32_t head,
                                                 uint32_t count, uint32_t *keyslot, int lane)
 {
@@ -69,68 +124,43 @@ __device__ __forceinline__ void flush_survivors(const float2 *P, const uint32_t 
     if (__builtin_amdgcn_ballot_w64(tie)) {
         const float neu = sqrt_rn(s1) + sqrt_rn(s2);
         const float cur = sqrt_rn(sab) + sqrt_rn(sce);
-        imp = act & (tie ? (neu < cur) : imp);
+        imp = act & (tie ? (neu < cur) : imp);  // two_opt.rs:35-49
     }
     if (imp) atomicMin(keyslot, key);
 }
 
-// Scans rows [0, rhi) of the block against one 64-wide j tile held in registers.
-// PRUNE: survivors of the exact squared-distance pre-test are queued (per-wave ring in LDS) and
-// decided 64 at a time by flush_survivors.  !PRUNE: every in-range candidate is decided inline with
-// four correctly rounded sqrt (TL_FLAG_NO_PRUNE).
-template <bool PRUNE, bool MASKED>
-__device__ __forceinline__ void scan_rows(const float2 *P, const float2 c, const float2 e, const float sqce,
-                                          const float rowx, const float rowy, const float rowsq, int rhi,
-                                          const uint32_t i0, const uint32_t tb, const uint32_t j,
-                                          const uint32_t j0, uint32_t *q, uint32_t &head, uint32_t &tail,
-                                          uint32_t *keyslot, const int lane)
+// L1 (or, for !PRUNE, L3 inline) for one row (a,b) against one 64-wide j tile.
+template <bool PRUNE>
+__device__ __forceinline__ void scan_tile(const float2 *P, uint32_t n, uint32_t i, uint32_t tb, uint32_t jmin,
+                                          float ax, float ay, float bx, float by, float sqab, uint32_t *q,
+                                          uint32_t &head, uint32_t &tail, uint32_t *keyslot, int lane)
 {
-    float ax = readlane_f(rowx, 0), ay = readlane_f(rowy, 0);
-    for (int r = 0; r < rhi; ++r) {
-        const float bx = readlane_f(rowx, r + 1), by = readlane_f(rowy, r + 1);
-        const float sqab = readlane_f(rowsq, r);
-        float dx = ax - c.x, dy = ay - c.y;
-        const float s1 = dx * dx + dy * dy;
-        dx = bx - e.x;
-        dy = by - e.y;
-        const float s2 = dx * dx + dy * dy;
-        ax = bx;
-        ay = by;
-        bool test;
-        if (PRUNE) test = (s1 < sqab) | (s2 < sqce);
-        else test = (sqce >= 0.0f);  // every in-range lane
-        if (MASKED) {
-            const uint32_t jmin = (r == 0) ? j0 : (i0 + (uint32_t)r + 2u);
-            test = test & (j >= jmin);
+    const uint32_t j = tb + (uint32_t)lane;
+    const float2 c = P[j], e = P[j + 1u];
+    const float sqce = sqdist(c, e);
+    float dx = ax - c.x, dy = ay - c.y;
+    const float s1 = dx * dx + dy * dy;
+    dx = bx - e.x;
+    dy = by - e.y;
+    const float s2 = dx * dx + dy * dy;
+    bool test = (j >= jmin) & (j + 2u <= n);
+    if (PRUNE) test = test & ((s1 < sqab) | (s2 < sqce));
+    const uint64_t m = __builtin_amdgcn_ballot_w64(test);
+    if (m == 0) return;
+    const uint32_t key = (i << 16) | j;
+    if (PRUNE) {
+        const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (test) q[(tail + off) & (kQCap - 1u)] = key;
+        tail += (uint32_t)__builtin_popcountll(m);
+        if (tail - head >= 64u) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            flush_survivors(P, q, head, 64u, keyslot, lane);
+            head += 64u;
         }
-        const uint64_t m = __builtin_amdgcn_ballot_w64(test);
-        if (m == 0) continue;
-        const uint32_t key = ((i0 + (uint32_t)r) << 16) | j;
-        if (PRUNE) {
-            const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (test) q[(tail + off) & (kQCap - 1u)] = key;
-            tail += (uint32_t)__builtin_popcountll(m);
-            if (tail - head >= 64u) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                flush_survivors(P, q, head, 64u, keyslot, lane);
-                head += 64u;
-                // a hit bounds the rows this tile still has to look at
-                const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot);
-                if (kb != kNoKey) {
-                    const int lim = (int)((kb >> 16) - i0) + (tb <= (kb & 0xFFFFu) ? 1 : 0);
-                    rhi = rhi < lim ? rhi : lim;
-                }
-            }
-        } else {
-            const float neu = sqrt_rn(s1) + sqrt_rn(s2);
-            const float cur = sqrt_rn(sqab) + sqrt_rn(sqce);
-            const bool imp = test & (neu < cur);  // two_opt.rs:35-49
-            const uint64_t mi = __builtin_amdgcn_ballot_w64(imp);
-            if (mi) {
-                if (lane == 0) atomicMin(keyslot, (key & 0xFFFF0000u) | (tb + (uint32_t)(__builtin_ffsll((long long)mi) - 1)));
-                return;  // later rows of this tile are lexicographically later
-            }
-        }
+    } else {
+        const float neu = sqrt_rn(s1) + sqrt_rn(s2);
+        const float cur = sqrt_rn(sqab) + sqrt_rn(sqce);
+        if (test & (neu < cur)) atomicMin(keyslot, key);  // two_opt.rs:35-49
     }
 }
 
@@ -141,12 +171,19 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = NT / 64;
+    static_assert(NW == 16, "tile -> wave assignment below assumes 16 waves");
     const uint32_t n = A.n, npad = A.n_pad;
+    const uint32_t ntile = npad >> 6;                  // tiles incl. the pad tile
+    const int G = (int)((ntile + 63u) >> 6);           // 64-tile groups (<= kMaxGroups)
     float2 *P = reinterpret_cast<float2 *>(smem);
     uint16_t *perm = reinterpret_cast<uint16_t *>(smem + (size_t)npad * 8);
-    Ctl *ctl = reinterpret_cast<Ctl *>(smem + (size_t)npad * 10);
+    unsigned char *tailp = smem + (size_t)npad * 10;
+    float4 *tbox = reinterpret_cast<float4 *>(tailp);                        // kMaxGroups*64 entries
+    float *tmsq = reinterpret_cast<float *>(tailp + kMaxGroups * 64 * 16);     // kMaxGroups*64
+    uint64_t *masks = reinterpret_cast<uint64_t *>(tailp + kMaxGroups * 64 * 20);  // 64 rows x kMaxGroups
+    Ctl *ctl = reinterpret_cast<Ctl *>(tailp + kMaxGroups * 64 * 20 + 64 * kMaxGroups * 8);
     // survivor queues (NW x kQCap u32) during the descent; reused as NT floats for the cost sum
-    uint32_t *queues = reinterpret_cast<uint32_t *>(smem + (size_t)npad * 10 + 64);
+    uint32_t *queues = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(ctl) + 64);
     float *scratch = reinterpret_cast<float *>(queues);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -181,83 +218,160 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         }
     }
     if (tid < 4) ctl->keys[tid] = kNoKey;
+    for (uint32_t k = tid; k < (uint32_t)kMaxGroups * 64u; k += NT) {
+        const float inf = __builtin_inff();
+        tbox[k] = make_float4(inf, inf, -inf, -inf);  // empty box: never live
+        tmsq[k] = -1.0f;
+    }
     __syncthreads();
     for (uint32_t k = tid; k < npad; k += NT) P[k] = (k < n) ? xy[perm[k]] : make_float2(0.f, 0.f);
+    __syncthreads();
+    for (uint32_t t = (uint32_t)wave; t < ntile; t += NW) build_tile_meta(P, n, t, lane, tbox, tmsq);
     __syncthreads();
 
     // ---------------------------------------------------------------- descent
     const uint32_t nrows = n - 3;  // rows i in [0, n-3); j in [i+2, n-2]
+    const uint32_t last_tile = n >= 2 ? (n - 2u) >> 6 : 0u;
     uint32_t i0 = 0, j0 = 2;
     bool improved = false;
     uint32_t sweeps = 1, step = 0, status = 0;
     uint64_t moves = 0, reversed = 0;
     float gap_est = 0.0f, since = 0.0f;
+    uint32_t *q = queues + (uint32_t)wave * kQCap;
+    uint32_t dirty_lo = 0xFFFFFFFFu, dirty_hi = 0;               // tiles whose L0 metadata is stale
 #ifdef TL_PROFILE
     uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tlast = __builtin_amdgcn_s_memtime();
     const uint64_t t_begin = tlast, rt_begin = __builtin_amdgcn_s_memrealtime();
-    uint64_t rows_total = 0;
+    uint64_t rows_total = 0, livetiles = 0;
 #endif
 
     while (n >= 4) {
         const uint32_t slot = step % 3u;
-        if (tid == 0) ctl->keys[(step + 1u) % 3u] = kNoKey;  // slot of the next step (see DESIGN.md)
+        if (tid == 0) ctl->keys[(step + 1u) % 3u] = kNoKey;  // slot of the next step
         ++step;
+        uint32_t *keyslot = &ctl->keys[slot];
 
-        // rows of this block
+        // block geometry: dense mode (moves every few rows: one row, every tile) or pruned mode (R rows, L0)
         const float rowlen = (float)(n - 2u - i0);
         const float g = fmaxf(gap_est, since);
-        int R = (int)(sqrtf(2.0f * g * kStepCost) / rowlen);
-        R = R < 1 ? 1 : (R > kRMax ? kRMax : R);
-        if ((uint32_t)R > nrows - i0) R = (int)(nrows - i0);
+        int R = 1;
+        if (PRUNE && g > TL_DENSE_ROWS * rowlen) {
+            R = kRMax;
+            if ((uint32_t)R > nrows - i0) R = (int)(nrows - i0);
+        }
+        const bool pruned = PRUNE && R > 1;
 
         // lane-resident row table: lane l holds P[i0+l] and sq(P[i0+l], P[i0+l+1])
         const float2 rp = P[i0 + (uint32_t)lane];
         const float2 rq = P[i0 + (uint32_t)lane + 1u];
         const float rowsq = sqdist(rp, rq);
 
-        TL_STAMP(0);
-        // row 0 resumes at j0; rows r >= 1 start at their own diagonal i0+r+2 (<= j0 possible)
-        const uint32_t tile_lo = ((R == 1) ? j0 : (i0 + 2u)) >> 6;
-        uint32_t *q = queues + (uint32_t)wave * kQCap;
         uint32_t qhead = 0, qtail = 0;
-        uint32_t *keyslot = &ctl->keys[slot];
-        for (uint32_t tb = (tile_lo + (uint32_t)wave) << 6; tb <= n - 2u; tb += (uint32_t)NW << 6) {
-            const uint32_t j = tb + (uint32_t)lane;
-            float2 c = P[j];
-            const float2 e = P[j + 1u];
-            float sqce = sqdist(c, e);
-            if (j > n - 2u) {  // out-of-range lane: can never pass either test
-                c.x = 1e30f;
-                sqce = -1.0f;
+        if (pruned) {
+            // L0 metadata is rebuilt lazily: only tiles touched by reversals since the last pruned step
+            if (dirty_lo <= dirty_hi) {
+                for (uint32_t t = dirty_lo + (uint32_t)wave; t <= dirty_hi; t += NW) build_tile_meta(P, n, t, lane, tbox, tmsq);
+                dirty_lo = 0xFFFFFFFFu;
+                dirty_hi = 0;
+                __syncthreads();
             }
-            // rows that can still matter for this tile
-            int rhi = R;
-            {
-                const int lim = (int)(tb + 62u - i0);  // need i + 2 <= tb + 63
-                rhi = rhi < lim ? rhi : lim;
-                const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot);
-                if (kb != kNoKey) {
-                    const int kr = (int)((kb >> 16) - i0), kj = (int)(kb & 0xFFFFu);
-                    const int lim2 = kr + ((int)tb <= kj ? 1 : 0);
-                    rhi = rhi < lim2 ? rhi : lim2;
+            // ---- phase A: L0 tile bounds; wave w takes rows w, w+16, ...; lanes = tiles of group gI
+            float4 box[kMaxGroups];
+            float msq[kMaxGroups];
+#pragma unroll
+            for (int gI = 0; gI < kMaxGroups; ++gI) {
+                if (gI < G) {
+                    box[gI] = tbox[((uint32_t)gI << 6) + (uint32_t)lane];
+                    msq[gI] = tmsq[((uint32_t)gI << 6) + (uint32_t)lane];
                 }
             }
-            if (rhi <= 0) continue;
-            // first row of the block resumes at j0; rows below the diagonal need j >= i+2
-            const bool masked = (tb < j0) | (tb < i0 + (uint32_t)rhi + 1u);
-            if (masked) scan_rows<PRUNE, true>(P, c, e, sqce, rp.x, rp.y, rowsq, rhi, i0, tb, j, j0, q, qhead, qtail, keyslot, lane);
-            else scan_rows<PRUNE, false>(P, c, e, sqce, rp.x, rp.y, rowsq, rhi, i0, tb, j, j0, q, qhead, qtail, keyslot, lane);
-            // decide this tile's survivors before moving on: a hit found now stops the other tiles/waves early
-            if (PRUNE && qtail != qhead) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                flush_survivors(P, q, qhead, qtail - qhead, keyslot, lane);
-                qhead = qtail;
+            for (int r = wave; r < R; r += NW) {
+                const float ax = readlane_f(rp.x, r), ay = readlane_f(rp.y, r);
+                const float bx = readlane_f(rp.x, r + 1), by = readlane_f(rp.y, r + 1);
+                const float sqab = readlane_f(rowsq, r);
+                const uint32_t jmin = (r == 0) ? j0 : (i0 + (uint32_t)r + 2u);
+                const uint32_t tmin = jmin >> 6;
+#pragma unroll
+                for (int gI = 0; gI < kMaxGroups; ++gI) {
+                    if (gI < G) {
+                        const uint32_t t = ((uint32_t)gI << 6) + (uint32_t)lane;
+                        const bool live = (t >= tmin) && ((box_lb(ax, ay, box[gI]) < sqab) || (box_lb(bx, by, box[gI]) < msq[gI]));
+                        const uint64_t m = __builtin_amdgcn_ballot_w64(live);
+                        if (lane == 0) masks[r * kMaxGroups + gI] = m;
+                    }
+                }
+            }
+            TL_STAMP(0);
+            __syncthreads();
+            TL_STAMP(1);
+
+            // ---- phase B: L1 on the live (row, tile) pairs; tile t belongs to wave t % 16.
+            // The R x kMaxGroups mask words are lane-resident (entry e = r*kMaxGroups + g in lane e%64 of
+            // word e/64); a ballot picks the entries that hold work for this wave.
+            const int nent = R * kMaxGroups;
+            for (int w0 = 0; w0 < nent; w0 += 64) {
+                const int e = w0 + lane;
+                // pair (row r, tile t) belongs to wave (t + r) % 16: the diagonal tile, live for ~64 consecutive
+                // rows, is spread over all waves instead of piling up on one
+                const uint64_t rbits = 0x0001000100010001ULL << (((uint32_t)wave - (uint32_t)(e / kMaxGroups)) & 15u);
+                const uint64_t mine = (e < nent && (e % kMaxGroups) < G) ? (masks[e] & rbits) : 0ULL;
+                uint64_t em = __builtin_amdgcn_ballot_w64(mine != 0ULL);
+                while (em) {
+                    const int el = __builtin_ffsll((long long)em) - 1;
+                    em &= em - 1;
+                    const int ent = w0 + el;
+                    const int r = ent / kMaxGroups, gI = ent % kMaxGroups;
+                    uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(mine >> 32), el) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readlane((int)mine, el);
+                    const uint32_t i = i0 + (uint32_t)r;
+                    const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot);
+                    if (kb != kNoKey && (kb >> 16) < i) {  // a hit in an earlier row makes the rest moot
+                        em = 0;
+                        break;
+                    }
+                    const float ax = readlane_f(rp.x, r), ay = readlane_f(rp.y, r);
+                    const float bx = readlane_f(rp.x, r + 1), by = readlane_f(rp.y, r + 1);
+                    const float sqab = readlane_f(rowsq, r);
+                    const uint32_t jmin = (r == 0) ? j0 : (i + 2u);
+                    while (m) {
+                        const uint32_t t = ((uint32_t)gI << 6) + (uint32_t)(__builtin_ffsll((long long)m) - 1);
+                        m &= m - 1;
+#ifdef TL_PROFILE
+                        ++livetiles;
+#endif
+                        scan_tile<PRUNE>(P, n, i, t << 6, jmin, ax, ay, bx, by, sqab, q, qhead, qtail, keyslot, lane);
+                    }
+                    if (qtail != qhead) {  // decide this row's survivors before looking at later rows
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        flush_survivors(P, q, qhead, qtail - qhead, keyslot, lane);
+                        qhead = qtail;
+                    }
+                }
+            }
+        } else {
+            // ---- dense mode: one row, every tile from the resume column on; tile t belongs to wave t % 16
+            const uint32_t i = i0;
+            const float ax = readlane_f(rp.x, 0), ay = readlane_f(rp.y, 0);
+            const float bx = readlane_f(rp.x, 1), by = readlane_f(rp.y, 1);
+            const float sqab = readlane_f(rowsq, 0);
+            for (uint32_t t = (j0 >> 6) + (((uint32_t)wave - (j0 >> 6)) & 15u); t <= last_tile; t += NW) {
+                const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot);
+                if (kb != kNoKey && (kb & 0xFFFFu) < (t << 6)) break;  // an earlier column already improves
+#ifdef TL_PROFILE
+                ++livetiles;
+#endif
+                scan_tile<PRUNE>(P, n, i, t << 6, j0, ax, ay, bx, by, sqab, q, qhead, qtail, keyslot, lane);
+                if (PRUNE && qtail != qhead) {  // decide right away so a hit stops the other tiles early
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    flush_survivors(P, q, qhead, qtail - qhead, keyslot, lane);
+                    qhead = qtail;
+                }
             }
         }
-        TL_STAMP(1);
-        __syncthreads();
         TL_STAMP(2);
+        __syncthreads();
+        TL_STAMP(3);
         const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->keys[slot]);
 #ifdef TL_PROFILE
         rows_total += (uint64_t)R;
@@ -280,9 +394,15 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 perm[lo + t] = v;
                 perm[hi - t] = u;
             }
-            TL_STAMP(3);
-            __syncthreads();
             TL_STAMP(4);
+            __syncthreads();
+            // L0 metadata of every tile that saw a changed position or tour-edge (j = lo-1 .. hi) is now stale
+            {
+                const uint32_t t0 = (lo - 1u) >> 6, t1 = hi >> 6;
+                dirty_lo = t0 < dirty_lo ? t0 : dirty_lo;
+                dirty_hi = t1 > dirty_hi ? t1 : dirty_hi;
+            }
+            TL_STAMP(6);
             improved = true;
             ++moves;
             reversed += (uint64_t)(js - is);
@@ -317,6 +437,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     // closing edge first.  Edge lengths in parallel, the sum by one lane in tour order.
     float total = 0.0f;
     if (n >= 2) total = dist(P[n - 1], P[0]);
+    __syncthreads();
     for (uint32_t base = 0; base + 1 < n; base += NT) {
         const uint32_t k = base + tid;
         scratch[tid] = (k + 1 < n) ? dist(P[k], P[k + 1]) : 0.0f;
@@ -324,15 +445,15 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         if (tid == 0) {
             const uint32_t cnt = (n - 1 - base) < (uint32_t)NT ? (n - 1 - base) : (uint32_t)NT;
             const float4 *s4 = reinterpret_cast<const float4 *>(scratch);
-            uint32_t q = 0;
-            for (; q + 4 <= cnt; q += 4) {
-                const float4 v = s4[q >> 2];
+            uint32_t qd = 0;
+            for (; qd + 4 <= cnt; qd += 4) {
+                const float4 v = s4[qd >> 2];
                 total += v.x;
                 total += v.y;
                 total += v.z;
                 total += v.w;
             }
-            for (; q < cnt; ++q) total += scratch[q];
+            for (; qd < cnt; ++qd) total += scratch[qd];
         }
         __syncthreads();
     }
@@ -345,10 +466,11 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         st[3] = status;
         st[4] = step;
 #ifdef TL_PROFILE
-        for (int q = 0; q < 5; ++q) st[5 + q] = prof[q];
-        st[10] = __builtin_amdgcn_s_memtime() - t_begin;
-        st[11] = __builtin_amdgcn_s_memrealtime() - rt_begin;
-        st[12] = rows_total;
+        for (int qd = 0; qd < 7; ++qd) st[5 + qd] = prof[qd];
+        st[12] = __builtin_amdgcn_s_memtime() - t_begin;
+        st[13] = __builtin_amdgcn_s_memrealtime() - rt_begin;
+        st[14] = rows_total;
+        st[15] = livetiles;
 #endif
     }
 }
@@ -360,8 +482,10 @@ size_t two_opt_ref_lds_bytes(uint32_t n, uint32_t *n_pad_out, int nt)
 {
     const uint32_t n_pad = ((n + 64u + 63u) / 64u) * 64u;  // P[j+1] of any lane of the last tile is in range
     if (n_pad_out) *n_pad_out = n_pad;
+    if (n_pad > (uint32_t)kMaxGroups * 64u * 64u) return ~(size_t)0;  // beyond the tile-table capacity
+    const size_t meta = (size_t)kMaxGroups * 64 * 20 + (size_t)64 * kMaxGroups * 8 + 64;
     const size_t tail = (size_t)(nt / 64) * kQCap * 4;  // survivor queues, >= nt floats of scratch
-    return (size_t)n_pad * 10 + 64 + (tail > (size_t)nt * 4 ? tail : (size_t)nt * 4);
+    return (size_t)n_pad * 10 + meta + (tail > (size_t)nt * 4 ? tail : (size_t)nt * 4);
 }
 
 template <int NT, bool PRUNE>
