@@ -113,18 +113,16 @@ def main():
     d_pos = torch.empty((R, n), dtype=torch.int32, device=dev)
     d_cost = torch.empty(R, dtype=torch.float32, device=dev)
     d_stats = torch.zeros((R, _capi.TL_DEV_STATS_STRIDE), dtype=torch.int64, device=dev)
-    ids = torch.arange(rank * R, rank * R + R, dtype=torch.int64, device=dev)
+    first, _ = TA.multistart.shard(rank, R)
     per_sweep = (n - 3) * (n - 2) // 2
     stream = torch.cuda.current_stream()
 
     def step():
-        ctx.check(lib.tl_two_opt_batch_dev(h, d_xy.data_ptr(), n, None, a.seed, rank * R, R, _capi.TL_MODE_REF_ORDER,
+        ctx.check(lib.tl_two_opt_batch_dev(h, d_xy.data_ptr(), n, None, a.seed, first, R, _capi.TL_MODE_REF_ORDER,
                                            d_pos.data_ptr(), d_cost.data_ptr(), d_stats.data_ptr(),
                                            C.c_void_p(stream.cuda_stream)))
-        key = ((d_cost.view(torch.int32).to(torch.int64) << 32) | ids).min().reshape(1)
-        if dist is not None:
-            dist.all_reduce(key, op=dist.ReduceOp.MIN)  # RCCL over xGMI: 8 bytes per round
-        return key
+        # RCCL over xGMI: one 8-byte min-all-reduce per round
+        return TA.multistart.allreduce_best(TA.multistart.pack_keys(d_cost, first), dist)
 
     def sync():
         torch.cuda.synchronize()
@@ -144,15 +142,8 @@ def main():
     sync()
     dt = time.perf_counter() - t0
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    c = torch.tensor([cands], dtype=torch.int64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-    dt_max, total = float(t.item()), int(c.item())
-    best_key = int(key.item())
-    best_cost = float(np.frombuffer(np.uint32(best_key >> 32).tobytes(), dtype=np.float32)[0])
-    best_restart = best_key & 0xFFFFFFFF
+    total, dt_max = TA.multistart.aggregate_throughput(cands, dt, dev, dist)
+    best_cost, best_restart = TA.multistart.unpack_key(key.item())
 
     if rank != 0:
         if dist is not None:

@@ -1,0 +1,90 @@
+"""N > 1 path on CPU: two processes, gloo backend, 127.0.0.1 rendezvous.  Covers the host logic bench.py runs
+between ranks — restart sharding, key packing, the min-all-reduce of the best (cost, restart) key and the
+whole-job throughput aggregation — with per-shard costs produced by the CPU oracle standing in for the GPU
+descents (the GPU kernels themselves are covered by the -m gpu tests)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+WORLD = 2
+R_PER_RANK = 3
+N = 120
+SEED = 77
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, port, outq):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    import _oracle as O
+    from teeline_amd.host import multistart as ms
+    from teeline_amd.host import synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        xy = synth.synth_xy(N)
+        first, count = ms.shard(rank, R_PER_RANK)
+        costs, cands = [], 0
+        for r in range(first, first + count):
+            init = synth.restart_perm(N, SEED, r)
+            rc, p, c, st = O.two_opt(xy, None, N, init=init)
+            costs.append(c)
+            cands += st["candidates"]
+        keys = ms.pack_keys(torch.tensor(np.asarray(costs, dtype=np.float32)), first)
+        best = ms.allreduce_best(keys, dist)
+        total, tmax = ms.aggregate_throughput(cands, 1.0 + rank, torch.device("cpu"), dist)
+        dist.barrier()
+        outq.put((rank, int(best.item()), total, tmax, [float(c) for c in costs], cands))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_min_allreduce_of_best_tour_key():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(WORLD)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in range(WORLD))
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    from teeline_amd.host import multistart as ms
+    all_costs = res[0][4] + res[1][4]
+    assert len(all_costs) == WORLD * R_PER_RANK
+    # every rank ends with the same key = global (min cost, lowest restart id on ties)
+    assert res[0][1] == res[1][1]
+    cost, restart = ms.unpack_key(res[0][1])
+    want = min(range(len(all_costs)), key=lambda i: (np.float32(all_costs[i]), i))
+    assert restart == want and np.float32(cost) == np.float32(all_costs[want])
+    # whole-job accounting: candidates are summed, time is the slowest rank's
+    assert res[0][2] == res[1][2] == res[0][5] + res[1][5]
+    assert res[0][3] == res[1][3] == 2.0
+
+
+def test_key_packing_matches_c_abi_definition():
+    from teeline_amd.host import multistart as ms
+    costs = torch.tensor([3.5, 1.25, 1.25, 77647.55469], dtype=torch.float32)
+    keys = ms.pack_keys(costs, 10)
+    assert keys.dtype == torch.int64 and int(keys.argmin()) == 1            # tie -> lowest restart id
+    assert ms.unpack_key(int(keys[3])) == (float(np.float32(77647.55469)), 13)
+    from teeline_amd import _capi, build
+    build.build()
+    lib = _capi.load()
+    for i, c in enumerate(costs.tolist()):
+        assert lib.tl_pack_cost_key(c, 10 + i) == int(keys[i])
+    assert ms.shard(3, 256) == (768, 256)
