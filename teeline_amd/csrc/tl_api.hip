@@ -417,15 +417,163 @@ static int two_opt_best_sweep(tl_ctx *c, const float *, uint32_t, const float *,
     return fail(c, TL_ERR_UNSUPPORTED, "TL_MODE_BEST_SWEEP: not built yet");
 }
 
-extern "C" int tl_three_opt(tl_ctx *c, const float *, uint32_t, const float *, const uint32_t *, uint32_t *, float *, tl_stats *)
+// ------------------------------------------------------------------------------------------------
+// 3-opt
+// ------------------------------------------------------------------------------------------------
+struct ThreeOptSetup {
+    ThreeOptArgs A{};
+    uint32_t nblocks = 0;
+    bool dm = false;
+};
+
+static uint32_t three_opt_max_n(const tl_ctx *c)
 {
-    return fail(c, TL_ERR_UNSUPPORTED, "tl_three_opt: not built yet");
+    long n = ((long)c->lds_bytes - 1024) / 20 - 2;
+    if (n > 65535) n = 65535;
+    return n < 0 ? 0u : (uint32_t)n;
 }
 
-extern "C" int tl_three_opt_find_best_move(tl_ctx *c, const float *, uint32_t, const float *, const uint32_t *, int *, uint32_t *,
-                                           uint32_t *, uint32_t *, int *, float *)
+// uploads inputs, lays out the workspace in c->work and fills the kernel argument block
+static int three_opt_setup(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *path, ThreeOptSetup &S)
 {
-    return fail(c, TL_ERR_UNSUPPORTED, "tl_three_opt_find_best_move: not built yet");
+    if (n > three_opt_max_n(c))
+        return fail(c, TL_ERR_UNSUPPORTED, "three_opt: n=%u exceeds the LDS row-cache limit %u of this build", n, three_opt_max_n(c));
+    int rc;
+    S.dm = dm_packed != nullptr;
+    const uint32_t jc = n <= 256 ? 4u : 16u;
+    std::vector<uint32_t> prefix(n - 1);
+    uint32_t acc = 0;
+    for (uint32_t i = 0; i + 2 < n; ++i) {
+        prefix[i] = acc;
+        acc += ((n - 2u - i) + jc - 1u) / jc;  // j in [i+1, n-1)
+    }
+    prefix[n - 2] = acc;
+    S.nblocks = acc;
+    if (S.dm) {
+        const size_t b = (size_t)n * (n - 1) / 2 * 4;
+        if ((rc = ensure(c, c->dm, b))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->dm.p, dm_packed, b, hipMemcpyHostToDevice, c->stream));
+    } else {
+        if ((rc = ensure(c, c->xy, (size_t)n * 8))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    // workspace: perm | Pt | E | prefix | partials | best | counters
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_perm = 0, o_pt = up(o_perm + (size_t)n * 4), o_e = up(o_pt + (size_t)(n + 1) * 8), o_pre = up(o_e + (size_t)n * 4),
+                 o_par = up(o_pre + (size_t)(n - 1) * 4), o_best = up(o_par + (size_t)S.nblocks * sizeof(ThreeOptBest)),
+                 o_cnt = up(o_best + sizeof(ThreeOptBest)), total = up(o_cnt + 16);
+    if ((rc = ensure(c, c->work, total))) return rc;
+    unsigned char *w = (unsigned char *)c->work.p;
+    std::vector<uint32_t> ident;
+    if (!path) {
+        ident.resize(n);
+        for (uint32_t i = 0; i < n; ++i) ident[i] = i;
+        path = ident.data();
+    }
+    HIPCHK(c, hipMemcpyAsync(w + o_perm, path, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(w + o_pre, prefix.data(), (size_t)(n - 1) * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(w + o_cnt, 0, 16, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // host vectors above go out of scope
+    S.A.xy = (const float2 *)c->xy.p;
+    S.A.dm = S.dm ? (const float *)c->dm.p : nullptr;
+    S.A.perm = (uint32_t *)(w + o_perm);
+    S.A.Pt = (float2 *)(w + o_pt);
+    S.A.E = (float *)(w + o_e);
+    S.A.chunk_prefix = (const uint32_t *)(w + o_pre);
+    S.A.partials = (ThreeOptBest *)(w + o_par);
+    S.A.best = (ThreeOptBest *)(w + o_best);
+    S.A.counters = (uint64_t *)(w + o_cnt);
+    S.A.n = n;
+    S.A.jc = jc;
+    return TL_OK;
+}
+
+extern "C" int tl_three_opt_find_best_move(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *path,
+                                           int *found, uint32_t *oi, uint32_t *oj, uint32_t *ok, int *kase, float *savings)
+{
+    if (!c || (!xy && !dm_packed) || !path || !found) return fail(c, TL_ERR_BADARG, "tl_three_opt_find_best_move: NULL argument");
+    *found = 0;
+    if (n < 4) return TL_OK;
+    if (!is_permutation(path, n)) return fail(c, TL_ERR_BADARG, "tl_three_opt_find_best_move: path is not a permutation of 0..n-1");
+    HIPCHK(c, hipSetDevice(c->device));
+    ThreeOptSetup S;
+    int rc;
+    if ((rc = three_opt_setup(c, xy, n, dm_packed, path, S))) return rc;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    HIPCHK(c, launch_three_opt_pass(S.A, S.nblocks, S.dm, 0, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    c->ev_valid = true;
+    ThreeOptBest b{};
+    HIPCHK(c, hipMemcpyAsync(&b, S.A.best, sizeof(b), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (b.found) {
+        *found = 1;
+        if (oi) *oi = b.ij >> 16;
+        if (oj) *oj = b.ij & 0xFFFFu;
+        if (ok) *ok = b.kc >> 3;
+        if (kase) *kase = (int)(b.kc & 7u);
+        if (savings) *savings = b.sav;
+    }
+    return TL_OK;
+}
+
+extern "C" int tl_three_opt(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
+                            uint32_t *out_pos, float *out_cost, tl_stats *stats)
+{
+    if (!c || (!xy && !dm_packed) || !out_pos) return fail(c, TL_ERR_BADARG, "tl_three_opt: NULL argument");
+    const auto t0 = std::chrono::steady_clock::now();
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (n < 4) {  // three_opt.rs:25-28: returns the cities order, init_tour ignored
+        for (uint32_t i = 0; i < n; ++i) out_pos[i] = i;
+        if (out_cost) {
+            if (n < 2) *out_cost = 0.0f;
+            else {
+                int rc = tl_tour_length(c, xy, dm_packed, n, out_pos, out_cost);
+                if (rc) return rc;
+            }
+        }
+        return TL_OK;
+    }
+    if (init_pos && !is_permutation(init_pos, n)) return fail(c, TL_ERR_BADARG, "tl_three_opt: init tour is not a permutation of 0..n-1");
+    HIPCHK(c, hipSetDevice(c->device));
+    ThreeOptSetup S;
+    int rc;
+    if ((rc = three_opt_setup(c, xy, n, dm_packed, init_pos, S))) return rc;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    uint64_t passes = 0, moves = 0;
+    const uint64_t cap = 64ull * n + 1024;  // safety cap, far above any observed pass count
+    for (;;) {
+        HIPCHK(c, launch_three_opt_pass(S.A, S.nblocks, S.dm, 1, c->stream));
+        ThreeOptBest b{};
+        HIPCHK(c, hipMemcpyAsync(&b, S.A.best, sizeof(b), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        ++passes;
+        if (!b.found) break;  // three_opt.rs:36-45
+        ++moves;
+        if (passes > cap) return fail(c, TL_ERR_NO_CONVERGE, "three_opt: pass cap reached");
+    }
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    c->ev_valid = true;
+    HIPCHK(c, hipMemcpyAsync(out_pos, S.A.perm, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (out_cost) {
+        // Solution::from_parts -> tour_length (mod.rs:1776-1789)
+        if ((rc = ensure(c, c->out_cost, 4))) return rc;
+        HIPCHK(c, launch_tour_length(S.dm ? nullptr : S.A.xy, S.A.dm, n, S.A.perm, (float *)c->out_cost.p, c->stream));
+        HIPCHK(c, hipMemcpyAsync(out_cost, c->out_cost.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (stats) {
+        stats->sweeps = passes;
+        stats->moves = moves;
+        const uint64_t nn = n;
+        stats->candidates = passes * (nn * (nn - 1) * (nn - 2) / 6 - (nn - 2));  // C(n,3) - (n-2) triples per pass
+        double kms = 0;
+        tl_last_kernel_ms(c, &kms);
+        stats->kernel_ms = kms;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return TL_OK;
 }
 
 extern "C" int tl_lk(tl_ctx *c, const float *, uint32_t, const uint32_t *, const tl_lk_opts *, uint64_t, uint32_t *, float *, tl_stats *)

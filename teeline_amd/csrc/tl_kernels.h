@@ -50,6 +50,29 @@ hipError_t launch_best_sweep_gather(const BestSweepArgs &A, hipStream_t s);
 hipError_t launch_best_sweep_scan(const BestSweepArgs &A, hipStream_t s);
 hipError_t launch_best_sweep_apply(const BestSweepArgs &A, uint64_t *counters, hipStream_t s);
 
+// three_opt.hip
+struct ThreeOptBest {
+    float sav;
+    uint32_t ij;     // i << 16 | j
+    uint32_t kc;     // k << 3 | case (1..7); 0xFFFFFFFF = none
+    uint32_t found;
+};
+struct ThreeOptArgs {
+    const float2 *xy;
+    const float *dm;             // packed matrix or nullptr
+    uint32_t *perm;              // [n] tour positions, updated in place by k_three_opt_pick
+    float2 *Pt;                  // [n+1] tour-ordered coordinates (coordinate form)
+    float *E;                    // [n] tour-edge lengths, E[n-1] = closing edge
+    const uint32_t *chunk_prefix;  // [n-1]: chunks of rows < i
+    ThreeOptBest *partials;      // one per scan workgroup
+    ThreeOptBest *best;          // result of the pass
+    uint64_t *counters;          // passes, moves
+    uint32_t n;
+    uint32_t jc;                 // j values per scan workgroup
+};
+size_t three_opt_scan_lds_bytes(uint32_t n);
+hipError_t launch_three_opt_pass(const ThreeOptArgs &A, uint32_t nblocks, bool dm, int apply, hipStream_t s);
+
 // dm_build.hip
 hipError_t launch_dm_build(const float2 *xy, uint32_t n, int dist, int layout, float *out, hipStream_t s);
 hipError_t launch_tour_length(const float2 *xy, const float *dm, uint32_t n, const uint32_t *perm,

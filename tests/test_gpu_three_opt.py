@@ -1,0 +1,124 @@
+"""GPU parity tests for 3-opt (-m gpu): tl_three_opt / tl_three_opt_find_best_move through the C ABI vs the oracle
+(reference: src/tsp/three_opt.rs).  Bit-exact: same move (i,j,k,case), same f32 savings, same tours and costs."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as O
+import _tsplib as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def goldens(golden_dir):
+    with open(os.path.join(golden_dir, "goldens.json")) as fh:
+        return json.load(fh)
+
+
+def f5(x):
+    return f"{float(x):.5f}"
+
+
+def problem(xy, packed, n):
+    import teeline_amd as TA
+    return TA.TspProblem(np.arange(n), xy if xy is not None else np.zeros((n, 2), np.float32),
+                         None if packed is None else TA.distance_matrix.DistanceMatrix(n, packed, np.arange(n), "explicit"))
+
+
+def gpu_three_opt(ctx, xy, packed, n, init=None):
+    import teeline_amd as TA
+    sol = TA.three_opt.solve(problem(xy, packed, n), None, None, None if init is None else [int(v) for v in init], ctx=ctx)
+    return np.asarray(sol.route(), dtype=np.uint32), sol.total, sol.stats
+
+
+def assert_same(gpu, ora):
+    route, cost, st = gpu
+    rc, oroute, ocost, ost = ora
+    assert rc == 0
+    assert route.tolist() == oroute.tolist(), "tour differs from the oracle"
+    assert np.float32(cost).tobytes() == np.float32(ocost).tobytes()
+    assert st["moves"] == ost["moves"] and st["sweeps"] == ost["sweeps"] and st["candidates"] == ost["candidates"]
+
+
+def test_reference_unit_cases(ctx):
+    import teeline_amd as TA
+    square = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+    tsp5 = np.array([[0.0, 0.0], [0.0, 0.5], [0.0, 1.0], [1.0, 1.0], [1.0, 0.0]], np.float32)
+    assert TA.three_opt.find_best_move(problem(square, None, 4), [0, 1, 2, 3], ctx=ctx) is None      # three_opt.rs:333-339
+    mv = TA.three_opt.find_best_move(problem(tsp5, None, 5), [0, 2, 4, 1, 3], ctx=ctx)               # :341-362
+    omv = O.three_opt_find_best_move(tsp5, None, [0, 2, 4, 1, 3])
+    assert mv is not None and mv[:4] == omv[:4] and mv[4].tobytes() == omv[4].tobytes()
+    for pts in (square, tsp5):                                                                       # :416-457
+        route, cost, st = gpu_three_opt(ctx, pts, None, len(pts))
+        assert abs(cost - 4.0) < 1e-4 and O.validate_tour(route)
+        assert_same((route, cost, st), O.three_opt(pts, None, len(pts)))
+    route, cost, st = gpu_three_opt(ctx, tsp5, None, 5, init=[0, 1, 2, 3, 4])                       # :266-277
+    assert route.tolist() == [0, 1, 2, 3, 4]
+    for n in (2, 3):                                                                                 # :25-28 n < 4
+        route, cost, st = gpu_three_opt(ctx, tsp5[:n], None, n, init=list(range(n))[::-1])
+        assert route.tolist() == list(range(n))
+        assert cost == O.tour_length(tsp5[:n], None, np.arange(n))
+
+
+@pytest.mark.parametrize("name", ["berlin52", "att48"])
+def test_tsplib_matches_goldens(ctx, name, tsplib_dir, goldens):
+    d = T.parse_tsplib(os.path.join(tsplib_dir, f"{name}.tsp"))
+    xy, n, ids = d["xy"], d["n"], d["ids"]
+    rc, nn, _ = O.nearest_neighbor(xy, None, n, 3)
+    for key, init in (("nn_three_opt", nn), ("identity_three_opt", None)):
+        g = gpu_three_opt(ctx, xy, None, n, init)
+        assert f5(g[1]) == goldens[name][key]["cost"]
+        assert ids[g[0]].tolist() == goldens[name][key]["route_ids"]
+        assert g[2]["moves"] == goldens[name][key]["stats"]["moves"]
+        assert g[2]["candidates"] == goldens[name][key]["stats"]["candidates"]
+    if name == "berlin52":
+        assert f5(gpu_three_opt(ctx, xy, None, n, nn)[1]) == "7742.64697"  # docs/benchmarks.md:29 publishes 7742.65
+
+
+@pytest.mark.parametrize("name", ["gr17", "ring6_explicit", "bays29"])
+def test_explicit_matrix(ctx, name, tsplib_dir, goldens):
+    d = T.parse_tsplib(os.path.join(tsplib_dir, f"{name}.tsp"))
+    g = gpu_three_opt(ctx, None, d["packed"], d["n"])
+    assert_same(g, O.three_opt(None, d["packed"], d["n"]))
+    assert g[0].tolist() == goldens[name]["identity_three_opt"]["route_pos"]
+
+
+@pytest.mark.parametrize("n,seed", [(4, 1), (5, 2), (6, 3), (7, 4), (17, 5), (64, 6), (65, 7), (120, 8)])
+def test_full_solve_small_sizes(ctx, n, seed):
+    xy = O.synth_xy(n, seed=seed)
+    assert_same(gpu_three_opt(ctx, xy, None, n), O.three_opt(xy, None, n))
+    rp = O.restart_perm(n, 9, seed)
+    assert_same(gpu_three_opt(ctx, xy, None, n, rp), O.three_opt(xy, None, n, init=rp))
+
+
+def test_ties_on_a_lattice(ctx):
+    # many exactly equal savings: the reference keeps the FIRST (i,j,k) in loop order and the lowest case per triple
+    g = np.stack(np.meshgrid(np.arange(7, dtype=np.float32), np.arange(7, dtype=np.float32)), -1).reshape(-1, 2)
+    rng = np.random.default_rng(3)
+    pts = np.ascontiguousarray(g[rng.permutation(len(g))])
+    import teeline_amd as TA
+    mv = TA.three_opt.find_best_move(problem(pts, None, len(pts)), np.arange(len(pts)), ctx=ctx)
+    omv = O.three_opt_find_best_move(pts, None, np.arange(len(pts)))
+    assert mv[:4] == omv[:4] and mv[4].tobytes() == omv[4].tobytes()
+    assert_same(gpu_three_opt(ctx, pts, None, len(pts)), O.three_opt(pts, None, len(pts)))
+
+
+@pytest.mark.parametrize("n", [300, 1002])
+def test_find_best_move_large(ctx, n):
+    # one full O(n^3) scan (1.67e8 triples at n = 1002) against the oracle: same move, same f32 savings
+    import teeline_amd as TA
+    xy = O.synth_xy(n)
+    rc, nn, _ = O.nearest_neighbor(xy, None, n, 3)
+    for path in (nn, O.restart_perm(n, 4, 0)):
+        mv = TA.three_opt.find_best_move(problem(xy, None, n), path, ctx=ctx)
+        omv = O.three_opt_find_best_move(xy, None, path)
+        assert mv is not None and mv[:4] == omv[:4] and mv[4].tobytes() == omv[4].tobytes()
+    # matrix form gives the same move
+    packed = O.dm_build_packed(xy)
+    mv2 = TA.three_opt.find_best_move(problem(None, packed, n), nn, ctx=ctx)
+    assert mv2[:4] == omv[:4] or True
+    omv_nn = O.three_opt_find_best_move(xy, None, nn)
+    assert mv2[:4] == omv_nn[:4] and mv2[4].tobytes() == omv_nn[4].tobytes()
