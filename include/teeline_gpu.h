@@ -141,6 +141,17 @@ int tl_three_opt_find_best_move(tl_ctx *ctx, const float *xy, uint32_t n, const 
 int tl_lk(tl_ctx *ctx, const float *xy, uint32_t n, const uint32_t *init_pos, const tl_lk_opts *opts,
           uint64_t seed, uint32_t *out_pos, float *out_cost, tl_stats *stats);
 
+/* ---- LK candidate lists: replaces lin_kernighan::build_candidates (lin_kernighan.rs:12-27) -- */
+/* out: n x min(k, n-1) u32, ascending f32 distance, ties -> lowest position (the reference's kd-tree tie
+ * order is implementation-defined, kdtree.rs:63). */
+int tl_build_candidates(tl_ctx *ctx, const float *xy, uint32_t n, uint32_t k, uint32_t *out);
+
+/* ---- NN seed: replaces nearest_neighbor::solve (nearest_neighbor.rs:8-76), EUC_2D ------------- */
+/* First unvisited among the n_nearest closest (stable ties, mod.rs:1848-1855), else the globally
+ * nearest unvisited (tie -> lowest position; the reference iterates a HashSet there). */
+int tl_nearest_neighbor(tl_ctx *ctx, const float *xy, uint32_t n, uint32_t n_nearest, uint32_t *out_pos,
+                        float *out_cost);
+
 /* ---- multi-start 2-opt (north-star config 4; no counterpart in the reference) ---------------- */
 /* Runs restarts [first, first+count) — restart r starts from the Fisher–Yates permutation drawn
  * from splitmix64(seed + r) (specification: DESIGN.md / oracle tlo_restart_perm) — one descent per

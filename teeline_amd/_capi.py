@@ -24,7 +24,7 @@ SYMBOLS = [
     "tl_abi_version", "tl_version", "tl_create", "tl_destroy", "tl_last_error", "tl_device_info",
     "tl_two_opt_lds_max_n", "tl_dm_build", "tl_tour_length", "tl_two_opt", "tl_three_opt",
     "tl_three_opt_find_best_move", "tl_lk", "tl_two_opt_multistart", "tl_pack_cost_key",
-    "tl_two_opt_batch_dev", "tl_last_kernel_ms", "tl_dm_build_dev",
+    "tl_two_opt_batch_dev", "tl_last_kernel_ms", "tl_dm_build_dev", "tl_build_candidates", "tl_nearest_neighbor",
 ]
 
 
@@ -89,5 +89,7 @@ def load():
     L.tl_two_opt_batch_dev.argtypes = [vp, vp, u32, vp, u64, u32, u32, i32, vp, vp, vp, vp]
     L.tl_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_double)]
     L.tl_dm_build_dev.argtypes = [vp, vp, u32, i32, i32, vp, vp]
+    L.tl_build_candidates.argtypes = [vp, vp, u32, u32, vp]
+    L.tl_nearest_neighbor.argtypes = [vp, vp, u32, u32, vp, f32p]
     _lib = L
     return L

@@ -1,0 +1,501 @@
+// lk.hip — Lin–Kernighan (reference: src/tsp/lin_kernighan.rs), candidate lists and the NN seed.
+//
+//   k_knn        build_candidates (lin_kernighan.rs:12-27) and DistanceMatrix::nearest (distance_matrix.rs:259-280):
+//                k nearest cities per city, ascending f32 distance, stable on ties in position order — the
+//                k-buffer rule of NearestResult::add (mod.rs:1839-1860).  Brute force, one thread per city,
+//                coordinates streamed through LDS tiles; exact (correctly rounded) distances because ties are
+//                decided on the rounded values.  The reference's kd-tree visits points in an
+//                implementation-defined order (kdtree.rs:63), so its tie order is unspecified; ours is
+//                "lowest position first" (known divergences).
+//   k_nn_seed    nearest_neighbor::solve (nearest_neighbor.rs:8-76): first unvisited among the n_nearest
+//                closest, else the globally nearest unvisited (tie: lowest position).  One workgroup; lane 0
+//                walks the candidate lists, the whole group does the O(n) fallback scans.
+//   k_lk_solve   lin_kernighan::solve (lin_kernighan.rs:35-100) as ONE persistent workgroup: lk_pass
+//                (:454-481) scans the (t1, orientation) pairs in the reference's order 1024 at a time — every
+//                lane runs the depth-limited sequential chain search find_lk_chain (:265-340) for its pair,
+//                checks the closed chain for a single Hamiltonian cycle, and the lowest pair index with a
+//                valid chain wins (ds_min) — then the group applies the chain (apply_lk_chain, :397-450) by
+//                copying tour arcs, and rescans from the start exactly like find_lk_move does.  The ILS loop
+//                (double_bridge kicks :485-499, accept-if-shorter, plateau stop :75-97) runs on-device too.
+//
+// The reference checks chain validity and applies chains by rebuilding adjacency lists and tracing n cities
+// (:181-250, :397-450).  Here both are O(k): the k removed edges cut the tour into k arcs; walking arcs through
+// the k added edges visits all k arcs iff the result is one cycle (the new graph is 2-regular), and the new flat
+// tour is those arcs copied in walk order starting at tour[0] — forward if the edge (tour[0],tour[1]) survives,
+// else backward, which is what the reference's trace from `adj[start][0]` does.
+#include "tl_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace tl {
+
+namespace {
+
+constexpr float kLkEps = 1e-6f;  // lin_kernighan.rs:252
+constexpr int kLkNT = 1024;
+
+// ---------------------------------------------------------------------------------------------- k-NN
+template <int KMAX>
+__global__ __launch_bounds__(256) void k_knn(const float2 *__restrict__ xy, uint32_t n, uint32_t k, uint32_t *__restrict__ cand)
+{
+    __shared__ float2 tile[256];
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    const float2 pc = xy[c < n ? c : 0u];
+    float bd[KMAX];
+    uint32_t bp[KMAX];
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t) { bd[t] = __builtin_inff(); bp[t] = 0xFFFFFFFFu; }
+    float radius = __builtin_inff();
+    for (uint32_t base = 0; base < n; base += 256u) {
+        __syncthreads();
+        if (base + threadIdx.x < n) tile[threadIdx.x] = xy[base + threadIdx.x];
+        __syncthreads();
+        const uint32_t lim = (n - base) < 256u ? (n - base) : 256u;
+        for (uint32_t t = 0; t < lim; ++t) {
+            const uint32_t p = base + t;
+            if (p == c) continue;                    // self excluded (mod.rs:1840-1842)
+            const float d = dist(tile[t], pc);       // kdtree.rs:194 self.point.distance(target)
+            // insert iff d < search_radius (INF until the buffer holds k, then the k-th kept distance), at
+            // partition_point(r.distance <= d): AFTER equal distances, then truncate to k
+            if (d < radius) {
+                float cd = d;
+                uint32_t cp = p;
+                bool shifting = false;
+#pragma unroll
+                for (int s = 0; s < KMAX; ++s) {
+                    if ((uint32_t)s < k && (shifting || cd < bd[s])) {
+                        const float td = bd[s];
+                        const uint32_t tp = bp[s];
+                        bd[s] = cd;
+                        bp[s] = cp;
+                        cd = td;
+                        cp = tp;
+                        shifting = true;
+                    }
+                }
+                radius = __builtin_inff();
+#pragma unroll
+                for (int s = 0; s < KMAX; ++s)
+                    if ((uint32_t)s + 1u == k) radius = bd[s];
+            }
+        }
+    }
+    if (c < n) {
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t)
+            if ((uint32_t)t < k) cand[(size_t)c * k + t] = bp[t];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- NN seed
+__global__ __launch_bounds__(kLkNT) void k_nn_seed(const float2 *__restrict__ xy, uint32_t n, const uint32_t *__restrict__ cand,
+                                                   uint32_t k, uint32_t *__restrict__ path, unsigned char *__restrict__ visited)
+{
+    __shared__ uint32_t s_len, s_cur;
+    __shared__ unsigned long long s_best;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t p = tid; p < n; p += kLkNT) visited[p] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        path[0] = 0;  // :28 start = cities[0]
+        visited[0] = 1;
+        s_len = 1;
+        s_cur = 0;
+    }
+    __syncthreads();
+    while (true) {
+        if (tid == 0) {
+            uint32_t len = s_len, cur = s_cur;
+            while (len < n) {  // :44-49 first unvisited among the n_nearest closest
+                uint32_t nx = 0xFFFFFFFFu;
+                for (uint32_t t = 0; t < k; ++t) {
+                    const uint32_t q = cand[(size_t)cur * k + t];
+                    if (q != 0xFFFFFFFFu && !visited[q]) { nx = q; break; }
+                }
+                if (nx == 0xFFFFFFFFu) break;
+                path[len++] = nx;
+                visited[nx] = 1;
+                cur = nx;
+            }
+            s_len = len;
+            s_cur = cur;
+            s_best = ~0ULL;
+        }
+        __syncthreads();
+        if (s_len >= n) break;
+        // :50-63 fallback: globally nearest unvisited; ties -> lowest position (the reference iterates a HashSet)
+        const uint32_t cur = s_cur;
+        const float2 pc = xy[cur];
+        unsigned long long best = ~0ULL;
+        for (uint32_t p = tid; p < n; p += kLkNT) {
+            if (visited[p]) continue;
+            const float d = dist(pc, xy[p]);
+            const unsigned long long key = ((unsigned long long)__builtin_bit_cast(uint32_t, d) << 32) | p;
+            best = key < best ? key : best;
+        }
+        if (best != ~0ULL) atomicMin(&s_best, best);
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t nx = (uint32_t)(s_best & 0xFFFFFFFFu);
+            path[s_len] = nx;
+            visited[nx] = 1;
+            s_len = s_len + 1;
+            s_cur = nx;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- LK
+struct LkView {
+    const float2 *xy;
+    const uint32_t *cand;
+    const uint32_t *next;
+    const uint32_t *prev;
+    uint32_t k;
+    uint32_t max_depth;
+};
+
+constexpr int kLkMaxDepth = 6;                       // compile-time recursion bound (default max_depth = 5)
+constexpr int kLkMaxChain = 2 * kLkMaxDepth + 2;
+
+template <int LEN>
+__device__ __forceinline__ bool in_chain(const uint32_t (&chain)[kLkMaxChain], uint32_t x)
+{
+    bool f = false;
+#pragma unroll
+    for (int t = 0; t < LEN; ++t) f |= (chain[t] == x);
+    return f;
+}
+
+// lin_kernighan.rs:265-340 find_lk_chain; DEPTH is the reference's `depth`, chain holds 2*DEPTH+2 cities on entry.
+template <int DEPTH>
+__device__ bool lk_chain(const LkView &V, uint32_t (&chain)[kLkMaxChain], uint32_t &clen, const float2 p1,
+                         const uint32_t t_open, const float2 p_open, const float gain)
+{
+    if (DEPTH >= 1) {
+        const float close_gain = gain - dist(p_open, p1);  // :280-283
+        if (close_gain > kLkEps) {
+            clen = 2 * DEPTH + 2;
+            return true;
+        }
+    }
+    if ((uint32_t)DEPTH >= V.max_depth) return false;  // :286-288
+    if constexpr (DEPTH < kLkMaxDepth) {
+        for (uint32_t q = 0; q < V.k; ++q) {
+            const uint32_t t_next = V.cand[(size_t)t_open * V.k + q];
+            const float2 p_next = V.xy[t_next];
+            const float g1 = gain - dist(p_open, p_next);
+            if (g1 <= kLkEps) break;                                   // :292-295 candidates are sorted
+            if (in_chain<2 * DEPTH + 2>(chain, t_next)) continue;      // used[t_next]
+            if (V.next[t_open] == t_next || V.prev[t_open] == t_next) continue;  // is_tour_edge
+            const uint32_t t_break = V.next[t_next];                   // :305 regime A
+            if (in_chain<2 * DEPTH + 2>(chain, t_break)) continue;     // used[t_break]
+            const float2 p_break = V.xy[t_break];
+            const float g2 = g1 + dist(p_next, p_break);
+            chain[2 * DEPTH + 2] = t_next;
+            chain[2 * DEPTH + 3] = t_break;
+            if (lk_chain<DEPTH + 1>(V, chain, clen, p1, t_break, p_break, g2)) return true;
+        }
+    }
+    return false;
+}
+
+// Arc model of a closed chain c[0..2k): removed edges (c[2i],c[2i+1]), added edges (c[2i+1],c[2i+2]) and (c[2k-1],c[0]).
+struct Arcs {
+    uint32_t lo[kLkMaxDepth + 1];  // sorted: removed edge m joins positions lo[m] and lo[m]+1 (mod n)
+    uint32_t k;
+};
+
+__device__ __forceinline__ void arcs_build(const uint32_t (&chain)[kLkMaxChain], uint32_t clen, const uint32_t *pos, uint32_t n, Arcs &A)
+{
+    A.k = clen / 2;
+    for (uint32_t m = 0; m < A.k; ++m) {
+        const uint32_t pu = pos[chain[2 * m]], pv = pos[chain[2 * m + 1]];
+        // adjacent positions: the edge sits after the one whose successor is the other
+        A.lo[m] = ((pu + 1u == pv) || (pu == n - 1u && pv == 0u)) ? pu : pv;
+    }
+    for (uint32_t a = 1; a < A.k; ++a) {  // insertion sort, k <= 7
+        const uint32_t v = A.lo[a];
+        uint32_t b = a;
+        while (b > 0 && A.lo[b - 1] > v) { A.lo[b] = A.lo[b - 1]; --b; }
+        A.lo[b] = v;
+    }
+}
+
+// endpoint city at position p: is its removed edge behind it (p is an arc START) and where is the arc's other end
+__device__ __forceinline__ bool arc_is_start(const Arcs &A, uint32_t p, uint32_t n)
+{
+    const uint32_t before = p == 0u ? n - 1u : p - 1u;
+    for (uint32_t m = 0; m < A.k; ++m)
+        if (A.lo[m] == before) return true;
+    return false;
+}
+__device__ __forceinline__ uint32_t arc_end_from_start(const Arcs &A, uint32_t p)
+{
+    // smallest lo >= p, else (wrap) the smallest lo
+    for (uint32_t m = 0; m < A.k; ++m)
+        if (A.lo[m] >= p) return A.lo[m];
+    return A.lo[0];
+}
+__device__ __forceinline__ uint32_t arc_start_from_end(const Arcs &A, uint32_t p, uint32_t n)
+{
+    // largest lo < p, +1; else (wrap) largest lo + 1
+    uint32_t best = 0xFFFFFFFFu;
+    for (uint32_t m = 0; m < A.k; ++m)
+        if (A.lo[m] < p) best = A.lo[m];
+    if (best == 0xFFFFFFFFu) best = A.lo[A.k - 1];
+    return best + 1u == n ? 0u : best + 1u;
+}
+__device__ __forceinline__ uint32_t chain_partner(const uint32_t (&chain)[kLkMaxChain], uint32_t clen, uint32_t city)
+{
+    // the city joined to `city` by an added edge
+    for (uint32_t t = 0; t < clen; ++t) {
+        if (chain[t] == city) {
+            if (t == 0u) return chain[clen - 1u];
+            if (t == clen - 1u) return chain[0];
+            return (t & 1u) ? chain[t + 1u] : chain[t - 1u];
+        }
+    }
+    return 0xFFFFFFFFu;
+}
+
+// chain_is_valid_tour (lin_kernighan.rs:181-250): one Hamiltonian cycle <=> the arc walk sees all k arcs
+__device__ bool chain_valid(const uint32_t (&chain)[kLkMaxChain], uint32_t clen, const uint32_t *tour, const uint32_t *pos, uint32_t n)
+{
+    if (clen < 4) return false;
+    Arcs A;
+    arcs_build(chain, clen, pos, n, A);
+    uint32_t city = chain[0], arcs = 0;
+    do {
+        const uint32_t p = pos[city];
+        const uint32_t other = arc_is_start(A, p, n) ? arc_end_from_start(A, p) : arc_start_from_end(A, p, n);
+        ++arcs;
+        if (arcs > A.k) return false;
+        city = chain_partner(chain, clen, tour[other]);
+    } while (city != chain[0]);
+    return arcs == A.k;
+}
+
+struct LkSeg {
+    uint32_t src, len, dst;
+    int dir;
+};
+
+}  // namespace
+
+__global__ __launch_bounds__(kLkNT) void k_lk_solve(LkArgs G)
+{
+    __shared__ uint32_t s_key, s_clen, s_nseg, s_flag;
+    __shared__ uint32_t s_chain[kLkMaxChain];
+    __shared__ LkSeg s_seg[2 * (kLkMaxDepth + 2)];
+    __shared__ float s_part[kLkNT];
+    const uint32_t tid = threadIdx.x, n = G.n;
+    uint32_t *tour = G.tour, *alt = G.alt, *pos = G.pos, *next = G.next, *prev = G.prev;
+    uint32_t *city_ids = G.city_ids, *best = G.best;
+    const float2 *__restrict__ xy = G.xy;
+    uint64_t scans = 0, searches = 0, moves = 0, exchanged = 0;
+
+    auto rebuild = [&](const uint32_t *t) {  // make_pos + flat_to_next_prev (:110-145)
+        for (uint32_t r = tid; r < n; r += kLkNT) {
+            const uint32_t c = t[r];
+            pos[c] = r;
+            next[c] = t[r + 1u == n ? 0u : r + 1u];
+            prev[c] = t[r == 0u ? n - 1u : r - 1u];
+        }
+        __syncthreads();
+    };
+
+    // tour_distance (:118-122): (0..n).map(d(t[i], t[(i+1)%n])).sum() — sequential f32 from 0, closing edge last
+    auto tour_distance = [&](const uint32_t *t) -> float {
+        float total = 0.0f;
+        for (uint32_t base = 0; base < n; base += kLkNT) {
+            const uint32_t r = base + tid;
+            if (r < n) {
+                const uint32_t a = t[r], b = t[r + 1u == n ? 0u : r + 1u];
+                s_part[tid] = a == b ? 0.0f : dist(xy[a], xy[b]);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                const uint32_t cnt = (n - base) < (uint32_t)kLkNT ? (n - base) : (uint32_t)kLkNT;
+                for (uint32_t q = 0; q < cnt; ++q) total += s_part[q];
+            }
+            __syncthreads();
+        }
+        if (tid == 0) s_part[0] = total;
+        __syncthreads();
+        const float r = s_part[0];
+        __syncthreads();
+        return r;
+    };
+
+    // lk_pass (:454-481) on `tour` (which must be G.tour); returns nothing, leaves the improved tour in G.tour
+    auto lk_pass = [&]() {
+        for (uint32_t r = tid; r < n; r += kLkNT) city_ids[r] = tour[r];  // :466 fixed for the whole pass
+        __syncthreads();
+        while (true) {
+            rebuild(tour);  // :470
+            LkView V{xy, G.cand, next, prev, G.k, G.max_depth};
+            bool found_any = false;
+            for (uint32_t base = 0; base < 2u * n; base += kLkNT) {  // find_lk_move (:345-389) in its own order
+                if (tid == 0) s_key = 0xFFFFFFFFu;
+                __syncthreads();
+                const uint32_t idx = base + tid;
+                uint32_t chain[kLkMaxChain];
+                uint32_t clen = 0;
+                bool ok = false;
+                if (idx < 2u * n) {
+                    const uint32_t t1 = city_ids[idx >> 1];
+                    const uint32_t t2 = (idx & 1u) ? prev[t1] : next[t1];  // :359 [next[t1], prev[t1]]
+                    const float2 p1 = xy[t1], p2 = xy[t2];
+                    chain[0] = t1;
+                    chain[1] = t2;
+                    const float g0 = t1 == t2 ? 0.0f : dist(p1, p2);
+                    if (lk_chain<0>(V, chain, clen, p1, t2, p2, g0)) ok = chain_valid(chain, clen, tour, pos, n);
+                }
+                if (ok) atomicMin(&s_key, idx);
+                __syncthreads();
+                const uint32_t key = s_key;
+                if (key != 0xFFFFFFFFu) {
+                    if (idx == key) {
+                        s_clen = clen;
+                        for (uint32_t t = 0; t < clen; ++t) s_chain[t] = chain[t];
+                    }
+                    searches += (uint64_t)key + 1u;
+                    found_any = true;
+                    __syncthreads();
+                    break;
+                }
+                __syncthreads();
+            }
+            ++scans;
+            if (!found_any) {
+                searches += 2ull * n;
+                break;
+            }
+            // ---- apply_lk_chain (:397-450): arcs copied in walk order from tour[0]
+            if (tid == 0) {
+                uint32_t chain[kLkMaxChain];
+                const uint32_t clen = s_clen;
+                for (uint32_t t = 0; t < clen; ++t) chain[t] = s_chain[t];
+                Arcs A;
+                arcs_build(chain, clen, pos, n, A);
+                bool first_removed = false;  // is the edge (tour[0], tour[1]) one of the removed ones?
+                for (uint32_t m = 0; m < A.k; ++m) first_removed |= (A.lo[m] == 0u);
+                uint32_t nseg = 0, emitted = 0;
+                uint32_t p = 0;
+                int dir = first_removed ? -1 : +1;
+                while (emitted < n && nseg < 2 * (kLkMaxDepth + 2)) {
+                    // run from p in direction dir to the end of the arc
+                    uint32_t endp;
+                    if (dir > 0) endp = arc_end_from_start(A, p);   // first removed edge at or after p
+                    else endp = arc_start_from_end(A, p, n);        // first position after the previous removed edge
+                    // length of the run p -> endp in direction dir, cyclic
+                    uint32_t len = dir > 0 ? (endp >= p ? endp - p + 1u : endp + n - p + 1u)
+                                           : (p >= endp ? p - endp + 1u : p + n - endp + 1u);
+                    if (len > n - emitted) len = n - emitted;  // the arc we started inside is finished at the very end
+                    s_seg[nseg].src = p;
+                    s_seg[nseg].len = len;
+                    s_seg[nseg].dst = emitted;
+                    s_seg[nseg].dir = dir;
+                    ++nseg;
+                    emitted += len;
+                    if (emitted >= n) break;
+                    const uint32_t city = chain_partner(chain, clen, tour[endp]);
+                    p = pos[city];
+                    dir = arc_is_start(A, p, n) ? +1 : -1;
+                }
+                s_nseg = nseg;
+            }
+            __syncthreads();
+            const uint32_t nseg = s_nseg;
+            for (uint32_t sidx = 0; sidx < nseg; ++sidx) {
+                const LkSeg sg = s_seg[sidx];
+                for (uint32_t t = tid; t < sg.len; t += kLkNT) {
+                    uint32_t sp = sg.dir > 0 ? sg.src + t : sg.src + n - t;
+                    if (sp >= n) sp -= n;
+                    alt[sg.dst + t] = tour[sp];
+                }
+            }
+            __syncthreads();
+            for (uint32_t r = tid; r < n; r += kLkNT) tour[r] = alt[r];
+            ++moves;
+            exchanged += (uint64_t)(s_clen / 2u);
+            __syncthreads();
+        }
+    };
+
+    // ---- lin_kernighan::solve (:35-100)
+    if (n >= 4) {
+        lk_pass();                                                   // :61-68
+        for (uint32_t r = tid; r < n; r += kLkNT) best[r] = tour[r];
+        __syncthreads();
+        float best_dist = tour_distance(best);                       // :70
+        uint32_t platoo = 0;
+        uint64_t draws = 0;
+        for (uint32_t e = 0; e < G.epochs; ++e) {                    // :75
+            // double_bridge (:485-499) with seeded draws r = splitmix64 % (n/4)
+            if (n < 8) {
+                for (uint32_t r = tid; r < n; r += kLkNT) tour[r] = best[r];
+            } else {
+                const uint32_t qn = n / 4u;
+                const uint32_t r1 = (uint32_t)(splitmix64_at(G.seed, draws) % qn), r2 = (uint32_t)(splitmix64_at(G.seed, draws + 1) % qn),
+                               r3 = (uint32_t)(splitmix64_at(G.seed, draws + 2) % qn);
+                draws += 3;
+                const uint32_t p1 = 1u + r1, p2 = p1 + 1u + r2, p3 = p2 + 1u + r3;
+                for (uint32_t w = tid; w < n; w += kLkNT) {
+                    uint32_t src;
+                    if (w < p1) src = w;                                  // tour[0..p1]
+                    else if (w < p1 + (p3 - p2)) src = p2 + (w - p1);     // tour[p2..p3]
+                    else if (w < p3) src = p1 + (w - p1 - (p3 - p2));     // tour[p1..p2]
+                    else src = w;                                         // tour[p3..n]
+                    tour[w] = best[src];
+                }
+            }
+            __syncthreads();
+            lk_pass();
+            const float dcur = tour_distance(tour);
+            if (dcur < best_dist) {                                  // :86
+                for (uint32_t r = tid; r < n; r += kLkNT) best[r] = tour[r];
+                __syncthreads();
+                best_dist = dcur;
+                platoo = 0;
+            } else {
+                if (++platoo >= G.platoo_epochs) break;              // :92-95
+            }
+        }
+    } else {
+        for (uint32_t r = tid; r < n; r += kLkNT) best[r] = tour[r];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        G.counters[0] = scans;
+        G.counters[1] = searches;
+        G.counters[2] = moves;
+        G.counters[3] = exchanged;
+        (void)s_flag;
+    }
+}
+
+hipError_t launch_knn(const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, hipStream_t s)
+{
+    const uint32_t grid = (n + 255u) / 256u;
+    if (k <= 4) hipLaunchKernelGGL(k_knn<4>, dim3(grid), dim3(256), 0, s, xy, n, k, cand);
+    else if (k <= 8) hipLaunchKernelGGL(k_knn<8>, dim3(grid), dim3(256), 0, s, xy, n, k, cand);
+    else hipLaunchKernelGGL(k_knn<16>, dim3(grid), dim3(256), 0, s, xy, n, k, cand);
+    return hipGetLastError();
+}
+
+hipError_t launch_nn_seed(const float2 *xy, uint32_t n, const uint32_t *cand, uint32_t k, uint32_t *path, unsigned char *visited, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_nn_seed, dim3(1), dim3(kLkNT), 0, s, xy, n, cand, k, path, visited);
+    return hipGetLastError();
+}
+
+hipError_t launch_lk_solve(const LkArgs &G, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_lk_solve, dim3(1), dim3(kLkNT), 0, s, G);
+    return hipGetLastError();
+}
+
+}  // namespace tl

@@ -576,7 +576,133 @@ extern "C" int tl_three_opt(tl_ctx *c, const float *xy, uint32_t n, const float 
     return TL_OK;
 }
 
-extern "C" int tl_lk(tl_ctx *c, const float *, uint32_t, const uint32_t *, const tl_lk_opts *, uint64_t, uint32_t *, float *, tl_stats *)
+// ------------------------------------------------------------------------------------------------
+// candidate lists, NN seed, Lin-Kernighan
+// ------------------------------------------------------------------------------------------------
+extern "C" int tl_build_candidates(tl_ctx *c, const float *xy, uint32_t n, uint32_t k, uint32_t *out)
 {
-    return fail(c, TL_ERR_UNSUPPORTED, "tl_lk: not built yet");
+    if (!c || !xy || !out) return fail(c, TL_ERR_BADARG, "tl_build_candidates: NULL argument");
+    if (n == 0) return fail(c, TL_ERR_BADARG, "tl_build_candidates: n == 0");
+    if (k > n - 1) k = n - 1;  // lin_kernighan.rs:14
+    if (k == 0) return TL_OK;
+    if (k > 16) return fail(c, TL_ERR_UNSUPPORTED, "tl_build_candidates: k=%u > 16", k);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->misc, (size_t)n * k * 4))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_knn((const float2 *)c->xy.p, n, k, (uint32_t *)c->misc.p, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, c->misc.p, (size_t)n * k * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return TL_OK;
+}
+
+// device-side NN seed into d_path (n u32); candidate lists are rebuilt with k = n_nearest in c->misc
+static int nn_seed_dev(tl_ctx *c, const float2 *d_xy, uint32_t n, uint32_t n_nearest, uint32_t *d_path)
+{
+    uint32_t k = n_nearest > n - 1 ? n - 1 : n_nearest;
+    if (k > 16) return fail(c, TL_ERR_UNSUPPORTED, "nearest_neighbor: n_nearest=%u > 16", n_nearest);
+    int rc;
+    const size_t cand_b = ((size_t)n * (k ? k : 1) * 4 + 255) & ~(size_t)255;
+    if ((rc = ensure(c, c->misc, cand_b + n))) return rc;
+    uint32_t *d_cand = (uint32_t *)c->misc.p;
+    unsigned char *d_vis = (unsigned char *)c->misc.p + cand_b;
+    if (k) HIPCHK(c, launch_knn(d_xy, n, k, d_cand, c->stream));
+    HIPCHK(c, launch_nn_seed(d_xy, n, d_cand, k, d_path, d_vis, c->stream));
+    return TL_OK;
+}
+
+extern "C" int tl_nearest_neighbor(tl_ctx *c, const float *xy, uint32_t n, uint32_t n_nearest, uint32_t *out_pos, float *out_cost)
+{
+    if (!c || !xy || !out_pos) return fail(c, TL_ERR_BADARG, "tl_nearest_neighbor: NULL argument");
+    if (n == 0) return fail(c, TL_ERR_REF_PANICS, "nearest_neighbor: cities[0] on an empty problem (nearest_neighbor.rs:28)");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->out_pos, (size_t)n * 4)) || (rc = ensure(c, c->out_cost, 4))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if ((rc = nn_seed_dev(c, (const float2 *)c->xy.p, n, n_nearest, (uint32_t *)c->out_pos.p))) return rc;
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    c->ev_valid = true;
+    HIPCHK(c, hipMemcpyAsync(out_pos, c->out_pos.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (out_cost) {
+        HIPCHK(c, launch_tour_length((const float2 *)c->xy.p, nullptr, n, (const uint32_t *)c->out_pos.p, (float *)c->out_cost.p, c->stream));
+        HIPCHK(c, hipMemcpyAsync(out_cost, c->out_cost.p, 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return TL_OK;
+}
+
+extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const uint32_t *init_pos, const tl_lk_opts *opts, uint64_t seed,
+                     uint32_t *out_pos, float *out_cost, tl_stats *stats)
+{
+    if (!c || !xy || !out_pos) return fail(c, TL_ERR_BADARG, "tl_lk: NULL argument");
+    if (n == 0) return fail(c, TL_ERR_BADARG, "tl_lk: n == 0");
+    tl_lk_opts o{100, 10, 5, 5};  // LKOptions::default(), mod.rs:1255-1267
+    if (opts) o = *opts;
+    if (o.n_nearest == 0) return fail(c, TL_ERR_BADARG, "n_nearest must be >= 1");   // mod.rs:677-682
+    if (o.max_depth == 0) return fail(c, TL_ERR_BADARG, "max_depth must be >= 1");   // mod.rs:1270-1276
+    if (o.max_depth > 6) return fail(c, TL_ERR_UNSUPPORTED, "tl_lk: max_depth=%u > 6 (compile-time recursion bound)", o.max_depth);
+    if (o.n_nearest > 16) return fail(c, TL_ERR_UNSUPPORTED, "tl_lk: n_nearest=%u > 16", o.n_nearest);
+    if (init_pos && !is_permutation(init_pos, n)) return fail(c, TL_ERR_BADARG, "tl_lk: init tour is not a permutation of 0..n-1");
+    const auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    const uint32_t k = o.n_nearest > n - 1 ? n - 1 : o.n_nearest;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t arr = up((size_t)n * 4);
+    const size_t o_cand = 0, o_tour = up((size_t)n * (k ? k : 1) * 4), o_alt = o_tour + arr, o_pos = o_alt + arr, o_next = o_pos + arr,
+                 o_prev = o_next + arr, o_ids = o_prev + arr, o_best = o_ids + arr, o_cnt = o_best + arr, total = o_cnt + 256;
+    if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->work, total)) || (rc = ensure(c, c->out_cost, 4))) return rc;
+    unsigned char *w = (unsigned char *)c->work.p;
+    HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (init_pos) {
+        HIPCHK(c, hipMemcpyAsync(w + o_tour, init_pos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    } else {
+        // lin_kernighan.rs:47-55: nearest_neighbor::solve with HeuristicOptions::default() (n_nearest = 3)
+        if ((rc = nn_seed_dev(c, (const float2 *)c->xy.p, n, 3, (uint32_t *)(w + o_tour)))) return rc;
+    }
+    if (k) HIPCHK(c, launch_knn((const float2 *)c->xy.p, n, k, (uint32_t *)(w + o_cand), c->stream));  // :43 build_candidates
+    HIPCHK(c, hipMemsetAsync(w + o_cnt, 0, 64, c->stream));
+    LkArgs G{};
+    G.xy = (const float2 *)c->xy.p;
+    G.cand = (const uint32_t *)(w + o_cand);
+    G.tour = (uint32_t *)(w + o_tour);
+    G.alt = (uint32_t *)(w + o_alt);
+    G.pos = (uint32_t *)(w + o_pos);
+    G.next = (uint32_t *)(w + o_next);
+    G.prev = (uint32_t *)(w + o_prev);
+    G.city_ids = (uint32_t *)(w + o_ids);
+    G.best = (uint32_t *)(w + o_best);
+    G.counters = (uint64_t *)(w + o_cnt);
+    G.seed = seed;
+    G.n = n;
+    G.k = k;
+    G.max_depth = o.max_depth;
+    G.epochs = o.epochs;
+    G.platoo_epochs = o.platoo_epochs;
+    HIPCHK(c, launch_lk_solve(G, c->stream));
+    // lin_kernighan.rs:99 Solution::new -> total through tour_length (closing edge first)
+    HIPCHK(c, launch_tour_length(G.xy, nullptr, n, G.best, (float *)c->out_cost.p, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    c->ev_valid = true;
+    uint64_t cnt[4] = {0, 0, 0, 0};
+    float cost = 0.f;
+    HIPCHK(c, hipMemcpyAsync(out_pos, G.best, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cnt, G.counters, 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&cost, c->out_cost.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (out_cost) *out_cost = cost;
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->sweeps = cnt[0];
+        stats->candidates = cnt[1];
+        stats->moves = cnt[2];
+        stats->reversed = cnt[3];
+        double kms = 0;
+        tl_last_kernel_ms(c, &kms);
+        stats->kernel_ms = kms;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return TL_OK;
 }

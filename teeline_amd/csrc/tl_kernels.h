@@ -73,6 +73,25 @@ struct ThreeOptArgs {
 size_t three_opt_scan_lds_bytes(uint32_t n);
 hipError_t launch_three_opt_pass(const ThreeOptArgs &A, uint32_t nblocks, bool dm, int apply, hipStream_t s);
 
+// lk.hip
+struct LkArgs {
+    const float2 *xy;
+    const uint32_t *cand;   // [n][k] candidate lists, ascending distance
+    uint32_t *tour;         // [n] working tour (in: initial tour)
+    uint32_t *alt;          // [n] scratch for chain application
+    uint32_t *pos;          // [n] rank of city
+    uint32_t *next;         // [n]
+    uint32_t *prev;         // [n]
+    uint32_t *city_ids;     // [n] scan order snapshot of a pass
+    uint32_t *best;         // [n] out: best tour
+    uint64_t *counters;     // scans, searches, moves, exchanged edges
+    uint64_t seed;
+    uint32_t n, k, max_depth, epochs, platoo_epochs;
+};
+hipError_t launch_knn(const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, hipStream_t s);
+hipError_t launch_nn_seed(const float2 *xy, uint32_t n, const uint32_t *cand, uint32_t k, uint32_t *path, unsigned char *visited, hipStream_t s);
+hipError_t launch_lk_solve(const LkArgs &G, hipStream_t s);
+
 // dm_build.hip
 hipError_t launch_dm_build(const float2 *xy, uint32_t n, int dist, int layout, float *out, hipStream_t s);
 hipError_t launch_tour_length(const float2 *xy, const float *dm, uint32_t n, const uint32_t *perm,

@@ -23,3 +23,15 @@ def solve(problem, opts=None, progress_tx=None, init_tour=None, *, ctx=None, see
     if progress_tx is not None:
         progress_tx("PathUpdate", ([int(v) for v in route], float(cost.value)))
     return Solution(cost.value, route, problem, st.as_dict())
+
+
+def build_candidates(problem, k, *, ctx=None):
+    """lin_kernighan::build_candidates (lin_kernighan.rs:12-27) in POSITIONS: n x min(k, n-1) array."""
+    from . import default_context
+    ctx = ctx or default_context()
+    n = len(problem)
+    kk = min(int(k), n - 1)
+    out = np.empty((n, max(kk, 1)), dtype=np.uint32)
+    ctx.check(ctx.lib.tl_build_candidates(ctx.handle, problem.xy.ctypes.data_as(C.c_void_p), n, int(k),
+                                          out.ctypes.data_as(C.c_void_p)))
+    return out[:, :kk]

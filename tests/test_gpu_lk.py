@@ -1,0 +1,116 @@
+"""GPU parity tests for the LK row (-m gpu): candidate lists, NN seed and lin_kernighan::solve through the C ABI
+against the oracle (reference: src/tsp/lin_kernighan.rs, nearest_neighbor.rs).  Kicks are seeded (same splitmix64
+stream in both), so tours are bit-identical, not just costs."""
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as O
+import _tsplib as T
+
+pytestmark = pytest.mark.gpu
+
+
+def f5(x):
+    return f"{float(x):.5f}"
+
+
+def prob(xy):
+    import teeline_amd as TA
+    return TA.TspProblem(np.arange(len(xy)), xy)
+
+
+def lattice(m, seed):
+    g = np.stack(np.meshgrid(np.arange(m, dtype=np.float32), np.arange(m, dtype=np.float32)), -1).reshape(-1, 2)
+    return np.ascontiguousarray(g[np.random.default_rng(seed).permutation(len(g))])
+
+
+@pytest.mark.parametrize("k", [1, 3, 5, 10])
+def test_candidate_lists(ctx, k, tsplib_dir):
+    import teeline_amd as TA
+    sets = [T.parse_tsplib(os.path.join(tsplib_dir, "berlin52.tsp"))["xy"], O.synth_xy(1000, seed=3), lattice(9, 1),
+            O.synth_xy(4, seed=2)]
+    for xy in sets:
+        got = TA.lin_kernighan.build_candidates(prob(xy), k, ctx=ctx)
+        want = O.build_candidates(xy, k)
+        assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_nearest_neighbor_seed(ctx, tsplib_dir):
+    import teeline_amd as TA
+    want = {"berlin52": "8980.91797", "att532": "112099.42188", "a280": "3148.10962"}  # bench/baseline-solvers.tsv:2-16
+    for name, cost in want.items():
+        d = T.parse_tsplib(os.path.join(tsplib_dir, f"{name}.tsp"))
+        sol = TA.nearest_neighbor.solve(TA.TspProblem(d["ids"], d["xy"]), ctx=ctx)
+        rc, route, c = O.nearest_neighbor(d["xy"], None, d["n"], 3)
+        assert f5(sol.total) == cost == f5(c)
+        assert list(sol.route()) == d["ids"][route].tolist()
+    for xy, k in ((O.synth_xy(10000), 3), (lattice(12, 4), 3), (O.synth_xy(300, seed=9), 1), (O.synth_xy(300, seed=9), 7)):
+        sol = TA.nearest_neighbor.solve(prob(xy), TA.HeuristicOptions(n_nearest=k), ctx=ctx)
+        rc, route, c = O.nearest_neighbor(xy, None, len(xy), k)
+        assert list(sol.route()) == route.tolist() and np.float32(sol.total).tobytes() == np.float32(c).tobytes()
+
+
+def gpu_lk(ctx, xy, init=None, seed=1, **kw):
+    import teeline_amd as TA
+    h = TA.HeuristicOptions(epochs=kw.get("epochs", 100), platoo_epochs=kw.get("platoo_epochs", 10), n_nearest=kw.get("n_nearest", 5))
+    sol = TA.lin_kernighan.solve(prob(xy), TA.LKOptions(h, kw.get("max_depth", 5)), None,
+                                 None if init is None else [int(v) for v in init], ctx=ctx, seed=seed)
+    return np.asarray(sol.route(), dtype=np.uint32), sol.total, sol.stats
+
+
+def assert_same(g, o):
+    route, cost, st = g
+    rc, oroute, ocost, ost = o
+    assert rc == 0 and route.tolist() == oroute.tolist(), "tour differs from the oracle"
+    assert np.float32(cost).tobytes() == np.float32(ocost).tobytes()
+    assert (st["sweeps"], st["candidates"], st["moves"], st["reversed"]) == (ost["sweeps"], ost["candidates"], ost["moves"], ost["reversed"])
+
+
+def test_lk_structural_cases(ctx):
+    # lin_kernighan.rs:519-926: crossed square improves at depth 1; tiny inputs are returned as they are
+    sq = np.array([[0, 0], [1, 1], [1, 0], [0, 1]], np.float32)  # visiting order 0,1,2,3 crosses
+    g = gpu_lk(ctx, sq, init=[0, 1, 2, 3], max_depth=1, epochs=0)
+    assert_same(g, O.lin_kernighan(sq, init=[0, 1, 2, 3], epochs=0, max_depth=1))
+    assert abs(g[1] - 4.0) < 1e-5
+    tri = np.array([[0, 0], [1, 0], [0.5, 1]], np.float32)
+    g = gpu_lk(ctx, tri, init=[2, 0, 1])
+    assert g[0].tolist() == [2, 0, 1]  # :57-59 len < 4
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
+def test_lk_berlin52_default_options(ctx, seed, tsplib_dir):
+    xy = T.parse_tsplib(os.path.join(tsplib_dir, "berlin52.tsp"))["xy"]
+    assert_same(gpu_lk(ctx, xy, seed=seed), O.lin_kernighan(xy, seed=seed))
+
+
+def test_lk_berlin52_cli_options_reach_published_optimum(ctx, tsplib_dir):
+    # CLI defaults (mod.rs:596-613,1321-1325): epochs 10000, platoo 500, n_nearest 3, depth 5; bench/baseline-solvers.tsv:17-21
+    xy = T.parse_tsplib(os.path.join(tsplib_dir, "berlin52.tsp"))["xy"]
+    kw = dict(epochs=10000, platoo_epochs=500, n_nearest=3)
+    g = gpu_lk(ctx, xy, seed=1, **kw)
+    assert_same(g, O.lin_kernighan(xy, seed=1, **kw))
+    assert f5(g[1]) == "7544.36572"
+
+
+@pytest.mark.parametrize("case", ["a280", "synth1000", "lattice", "random_start", "depth_limits"])
+def test_lk_other_instances(ctx, case, tsplib_dir):
+    if case == "a280":
+        xy = T.parse_tsplib(os.path.join(tsplib_dir, "a280.tsp"))["xy"]
+        assert_same(gpu_lk(ctx, xy, seed=7, epochs=30), O.lin_kernighan(xy, seed=7, epochs=30))
+    elif case == "synth1000":
+        xy = O.synth_xy(1000, seed=5)
+        assert_same(gpu_lk(ctx, xy, seed=3, epochs=12), O.lin_kernighan(xy, seed=3, epochs=12))
+    elif case == "lattice":
+        xy = lattice(10, 2)
+        assert_same(gpu_lk(ctx, xy, seed=11, epochs=40), O.lin_kernighan(xy, seed=11, epochs=40))
+    elif case == "random_start":
+        xy = O.synth_xy(600, seed=8)
+        init = O.restart_perm(600, 5, 0)
+        assert_same(gpu_lk(ctx, xy, init=init, seed=2, epochs=5), O.lin_kernighan(xy, init=init, seed=2, epochs=5))
+    else:
+        xy = O.synth_xy(200, seed=4)
+        for depth, k in ((1, 5), (2, 3), (3, 8), (6, 5)):
+            assert_same(gpu_lk(ctx, xy, seed=1, epochs=20, max_depth=depth, n_nearest=k),
+                        O.lin_kernighan(xy, seed=1, epochs=20, max_depth=depth, n_nearest=k))
