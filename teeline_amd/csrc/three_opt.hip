@@ -167,7 +167,7 @@ __global__ __launch_bounds__(1024) void k_three_opt_pick(ThreeOptArgs A, uint32_
     uint32_t *tmp = reinterpret_cast<uint32_t *>(smem);  // n entries
     __shared__ float r_s[16];
     __shared__ uint32_t r_ij[16], r_kc[16];
-    const uint32_t tid = threadIdx.x, n = A.n;
+    const uint32_t tid = threadIdx.x;
     float bs = 0.0f;
     uint32_t bij = 0xFFFFFFFFu, bkc = 0xFFFFFFFFu;
     for (uint32_t b = tid; b < nblocks; b += 1024u) {

@@ -34,7 +34,7 @@ namespace {
 
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 #ifndef TL_RMAX
-#define TL_RMAX 16
+#define TL_RMAX 32
 #endif
 #ifndef TL_DENSE_ROWS
 #define TL_DENSE_ROWS 8.0f
@@ -44,7 +44,7 @@ constexpr uint32_t kQCap = 128;       // per-wave survivor queue entries (power 
 constexpr int kMaxGroups = 4;         // 64-tile groups: n_pad <= 4 * 64 * 64 = 16384
 
 #ifdef TL_PROFILE
-#define TL_STAMP(var) do { if (tid == 0) { const uint64_t _t = __builtin_amdgcn_s_memtime(); prof[var] += _t - tlast; tlast = _t; } } while (0)
+#define TL_STAMP(var) do { if (tid == 0) { const uint64_t _t = __builtin_amdgcn_s_memtime(); prof[(var) + (pmode ? 8 : 0)] += _t - tlast; tlast = _t; } } while (0)
 #else
 #define TL_STAMP(var) do { } while (0)
 #endif
@@ -164,6 +164,78 @@ __device__ __forceinline__ void scan_tile(const float2 *P, uint32_t n, uint32_t 
     }
 }
 
+
+constexpr uint32_t kMaxChainHits = 16;  // hits one wave may chain inside its tile before handing back
+
+// Dense mode, one row (a, b) against one 64-wide j tile held in registers, decided inline (no queue).
+// All improving moves of the reference's scan INSIDE this tile are chained here without leaving the wave:
+// after a hit at lane l the row's b becomes the old P[j] (two_opt.rs:50 reverses p[i+1..=j], so p[i+1] := p[j]),
+// positions > j are untouched, hence lanes > l are simply re-decided against the new b.  Hits are recorded in
+// `hl` (hl[0] = count, hl[1] = column at which the scan resumes, hl[2..] = hit columns); the first one is posted
+// to the key slot.  Only the list of the wave that owns the globally first hit is used afterwards.
+template <bool PRUNE>
+__device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint32_t i, uint32_t tb, uint32_t jmin,
+                                               float ax, float ay, float bx, float by, uint32_t *hl,
+                                               uint32_t *keyslot, int lane)
+{
+    const uint32_t j = tb + (uint32_t)lane;
+    const float2 c = P[j], e = P[j + 1u];
+    const float sqce = sqdist(c, e);
+    float dx = ax - c.x, dy = ay - c.y;
+    const float s1 = dx * dx + dy * dy;
+    const bool inrange = j + 2u <= n;
+    const float dac_a = __builtin_amdgcn_sqrtf(s1), dce_a = __builtin_amdgcn_sqrtf(sqce);
+    uint32_t from = jmin, nh = 0;
+    for (;;) {
+        dx = ax - bx;
+        dy = ay - by;
+        const float sqab = dx * dx + dy * dy;
+        dx = bx - e.x;
+        dy = by - e.y;
+        const float s2 = dx * dx + dy * dy;
+        bool test = inrange & (j >= from);
+        if (PRUNE) test = test & ((s1 < sqab) | (s2 < sqce));  // L1
+        if (!__builtin_amdgcn_ballot_w64(test)) break;
+        bool imp;
+        if (PRUNE) {
+            // L2: hardware sqrt decides unless the margin is within ~3x the accumulated error
+            const float neu_a = dac_a + __builtin_amdgcn_sqrtf(s2);
+            const float cur_a = __builtin_amdgcn_sqrtf(sqab) + dce_a;
+            const float margin = cur_a * 1.9073486e-6f;  // 2^-19
+            const float smin = fminf(fminf(s1, s2), fminf(sqab, sqce));
+            imp = test & (neu_a < cur_a - margin);
+            const bool tie = test & !imp & ((neu_a <= cur_a + margin) | (smin < 1e-30f) | !(cur_a < 3.0e38f));
+            if (__builtin_amdgcn_ballot_w64(tie)) {  // L3
+                const float neu = sqrt_rn(s1) + sqrt_rn(s2);
+                const float cur = sqrt_rn(sqab) + sqrt_rn(sqce);
+                imp = tie ? (neu < cur) : imp;
+            }
+        } else {
+            const float neu = sqrt_rn(s1) + sqrt_rn(s2);
+            const float cur = sqrt_rn(sqab) + sqrt_rn(sqce);
+            imp = test & (neu < cur);  // two_opt.rs:35-49
+        }
+        const uint64_t m = __builtin_amdgcn_ballot_w64(imp);
+        if (m == 0) break;
+        const int l = __builtin_ffsll((long long)m) - 1;
+        const uint32_t jh = tb + (uint32_t)l;
+        if (lane == 0) {
+            if (nh == 0) atomicMin(keyslot, (i << 16) | jh);
+            hl[2u + nh] = jh;
+        }
+        ++nh;
+        bx = readlane_f(c.x, l);  // new p[i+1] = old p[j]
+        by = readlane_f(c.y, l);
+        from = jh + 1u;
+        if (nh >= kMaxChainHits || l == 63) break;
+    }
+    if (nh && lane == 0) {
+        hl[0] = nh;
+        hl[1] = (nh >= kMaxChainHits) ? from : (tb + 64u);  // tile exhausted unless the chain was cut short
+    }
+    return nh;
+}
+
 }  // namespace
 
 template <int NT, bool PRUNE>
@@ -180,8 +252,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     unsigned char *tailp = smem + (size_t)npad * 10;
     float4 *tbox = reinterpret_cast<float4 *>(tailp);                        // kMaxGroups*64 entries
     float *tmsq = reinterpret_cast<float *>(tailp + kMaxGroups * 64 * 16);     // kMaxGroups*64
-    uint64_t *masks = reinterpret_cast<uint64_t *>(tailp + kMaxGroups * 64 * 20);  // 64 rows x kMaxGroups
-    Ctl *ctl = reinterpret_cast<Ctl *>(tailp + kMaxGroups * 64 * 20 + 64 * kMaxGroups * 8);
+    Ctl *ctl = reinterpret_cast<Ctl *>(tailp + kMaxGroups * 64 * 20);
     // survivor queues (NW x kQCap u32) during the descent; reused as NT floats for the cost sum
     uint32_t *queues = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(ctl) + 64);
     float *scratch = reinterpret_cast<float *>(queues);
@@ -240,9 +311,10 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     uint32_t *q = queues + (uint32_t)wave * kQCap;
     uint32_t dirty_lo = 0xFFFFFFFFu, dirty_hi = 0;               // tiles whose L0 metadata is stale
 #ifdef TL_PROFILE
-    uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bool pmode = false;
+    uint64_t nsteps_pruned = 0, nmoves_pruned = 0;
     uint64_t tlast = __builtin_amdgcn_s_memtime();
-    const uint64_t t_begin = tlast, rt_begin = __builtin_amdgcn_s_memrealtime();
     uint64_t rows_total = 0, livetiles = 0;
 #endif
 
@@ -261,6 +333,10 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             if ((uint32_t)R > nrows - i0) R = (int)(nrows - i0);
         }
         const bool pruned = PRUNE && R > 1;
+#ifdef TL_PROFILE
+        pmode = pruned;
+        nsteps_pruned += pruned ? 1 : 0;
+#endif
 
         // lane-resident row table: lane l holds P[i0+l] and sq(P[i0+l], P[i0+l+1])
         const float2 rp = P[i0 + (uint32_t)lane];
@@ -276,7 +352,9 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 dirty_hi = 0;
                 __syncthreads();
             }
-            // ---- phase A: L0 tile bounds; wave w takes rows w, w+16, ...; lanes = tiles of group gI
+            // ---- pruned mode: wave w owns rows w, w+16, ... of the block.  L0 (lanes = tiles) yields the live-tile
+            // mask of the row in SGPRs, L1 (lanes = j) runs on those tiles right away — no exchange between waves,
+            // and every row has its diagonal tile live, so the rows are naturally balanced.
             float4 box[kMaxGroups];
             float msq[kMaxGroups];
 #pragma unroll
@@ -287,86 +365,51 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 }
             }
             for (int r = wave; r < R; r += NW) {
+                const uint32_t i = i0 + (uint32_t)r;
+                if (r >= NW) {  // a hit in an earlier row makes this one moot
+                    const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot);
+                    if (kb != kNoKey && (kb >> 16) < i) break;
+                }
                 const float ax = readlane_f(rp.x, r), ay = readlane_f(rp.y, r);
                 const float bx = readlane_f(rp.x, r + 1), by = readlane_f(rp.y, r + 1);
                 const float sqab = readlane_f(rowsq, r);
-                const uint32_t jmin = (r == 0) ? j0 : (i0 + (uint32_t)r + 2u);
+                const uint32_t jmin = (r == 0) ? j0 : (i + 2u);
                 const uint32_t tmin = jmin >> 6;
 #pragma unroll
                 for (int gI = 0; gI < kMaxGroups; ++gI) {
                     if (gI < G) {
-                        const uint32_t t = ((uint32_t)gI << 6) + (uint32_t)lane;
-                        const bool live = (t >= tmin) && ((box_lb(ax, ay, box[gI]) < sqab) || (box_lb(bx, by, box[gI]) < msq[gI]));
-                        const uint64_t m = __builtin_amdgcn_ballot_w64(live);
-                        if (lane == 0) masks[r * kMaxGroups + gI] = m;
+                        const uint32_t tl = ((uint32_t)gI << 6) + (uint32_t)lane;
+                        const bool live = (tl >= tmin) && ((box_lb(ax, ay, box[gI]) < sqab) || (box_lb(bx, by, box[gI]) < msq[gI]));
+                        uint64_t m = __builtin_amdgcn_ballot_w64(live);
+                        while (m) {
+                            const uint32_t t = ((uint32_t)gI << 6) + (uint32_t)(__builtin_ffsll((long long)m) - 1);
+                            m &= m - 1;
+#ifdef TL_PROFILE
+                            ++livetiles;
+#endif
+                            scan_tile<PRUNE>(P, n, i, t << 6, jmin, ax, ay, bx, by, sqab, q, qhead, qtail, keyslot, lane);
+                        }
                     }
+                }
+                if (qtail != qhead) {  // decide this row's survivors before looking at a later row
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    flush_survivors(P, q, qhead, qtail - qhead, keyslot, lane);
+                    qhead = qtail;
                 }
             }
             TL_STAMP(0);
-            __syncthreads();
-            TL_STAMP(1);
-
-            // ---- phase B: L1 on the live (row, tile) pairs; tile t belongs to wave t % 16.
-            // The R x kMaxGroups mask words are lane-resident (entry e = r*kMaxGroups + g in lane e%64 of
-            // word e/64); a ballot picks the entries that hold work for this wave.
-            const int nent = R * kMaxGroups;
-            for (int w0 = 0; w0 < nent; w0 += 64) {
-                const int e = w0 + lane;
-                // pair (row r, tile t) belongs to wave (t + r) % 16: the diagonal tile, live for ~64 consecutive
-                // rows, is spread over all waves instead of piling up on one
-                const uint64_t rbits = 0x0001000100010001ULL << (((uint32_t)wave - (uint32_t)(e / kMaxGroups)) & 15u);
-                const uint64_t mine = (e < nent && (e % kMaxGroups) < G) ? (masks[e] & rbits) : 0ULL;
-                uint64_t em = __builtin_amdgcn_ballot_w64(mine != 0ULL);
-                while (em) {
-                    const int el = __builtin_ffsll((long long)em) - 1;
-                    em &= em - 1;
-                    const int ent = w0 + el;
-                    const int r = ent / kMaxGroups, gI = ent % kMaxGroups;
-                    uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(mine >> 32), el) << 32) |
-                                 (uint32_t)__builtin_amdgcn_readlane((int)mine, el);
-                    const uint32_t i = i0 + (uint32_t)r;
-                    const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot);
-                    if (kb != kNoKey && (kb >> 16) < i) {  // a hit in an earlier row makes the rest moot
-                        em = 0;
-                        break;
-                    }
-                    const float ax = readlane_f(rp.x, r), ay = readlane_f(rp.y, r);
-                    const float bx = readlane_f(rp.x, r + 1), by = readlane_f(rp.y, r + 1);
-                    const float sqab = readlane_f(rowsq, r);
-                    const uint32_t jmin = (r == 0) ? j0 : (i + 2u);
-                    while (m) {
-                        const uint32_t t = ((uint32_t)gI << 6) + (uint32_t)(__builtin_ffsll((long long)m) - 1);
-                        m &= m - 1;
-#ifdef TL_PROFILE
-                        ++livetiles;
-#endif
-                        scan_tile<PRUNE>(P, n, i, t << 6, jmin, ax, ay, bx, by, sqab, q, qhead, qtail, keyslot, lane);
-                    }
-                    if (qtail != qhead) {  // decide this row's survivors before looking at later rows
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        flush_survivors(P, q, qhead, qtail - qhead, keyslot, lane);
-                        qhead = qtail;
-                    }
-                }
-            }
         } else {
             // ---- dense mode: one row, every tile from the resume column on; tile t belongs to wave t % 16
             const uint32_t i = i0;
             const float ax = readlane_f(rp.x, 0), ay = readlane_f(rp.y, 0);
             const float bx = readlane_f(rp.x, 1), by = readlane_f(rp.y, 1);
-            const float sqab = readlane_f(rowsq, 0);
             for (uint32_t t = (j0 >> 6) + (((uint32_t)wave - (j0 >> 6)) & 15u); t <= last_tile; t += NW) {
                 const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot);
                 if (kb != kNoKey && (kb & 0xFFFFu) < (t << 6)) break;  // an earlier column already improves
 #ifdef TL_PROFILE
                 ++livetiles;
 #endif
-                scan_tile<PRUNE>(P, n, i, t << 6, j0, ax, ay, bx, by, sqab, q, qhead, qtail, keyslot, lane);
-                if (PRUNE && qtail != qhead) {  // decide right away so a hit stops the other tiles early
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    flush_survivors(P, q, qhead, qtail - qhead, keyslot, lane);
-                    qhead = qtail;
-                }
+                if (dense_tile<PRUNE>(P, n, i, t << 6, j0, ax, ay, bx, by, q, keyslot, lane)) break;
             }
         }
         TL_STAMP(2);
@@ -383,19 +426,54 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             j0 = i0 + 2u;
         } else {
             const uint32_t is = key >> 16, js = key & 0xFFFFu;
-            // two_opt.rs:50,69-79  swap_2opt(path, i+1, j)
-            const uint32_t lo = is + 1u, hi = js;
-            const uint32_t half = (hi - lo + 1u) >> 1;
-            for (uint32_t t = tid; t < half; t += NT) {
-                const float2 x = P[lo + t], y = P[hi - t];
-                P[lo + t] = y;
-                P[hi - t] = x;
-                const uint16_t u = perm[lo + t], v = perm[hi - t];
-                perm[lo + t] = v;
-                perm[hi - t] = u;
+            // hits to apply: pruned mode found one; in dense mode the wave owning the first hit chained every
+            // improving move inside its tile (dense_tile) and left the list in its queue slot
+            uint32_t nh = 1, resume = js + 1u;
+            const uint32_t *hl = queues + (((js >> 6) & 15u) * kQCap);
+            if (!pruned) {
+                nh = (uint32_t)__builtin_amdgcn_readfirstlane((int)hl[0]);
+                resume = (uint32_t)__builtin_amdgcn_readfirstlane((int)hl[1]);
+            }
+            const uint32_t lo = is + 1u;
+            uint32_t hi = js, prev_hit = j0;
+            since += (float)(is - i0) * rowlen;
+            for (uint32_t h = 0; h < nh; ++h) {
+                if (h > 0) hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hl[2u + h]);
+                // two_opt.rs:50,69-79  swap_2opt(path, i+1, j); two pairs per thread in flight
+                const uint32_t half = (hi - lo + 1u) >> 1;
+                for (uint32_t t = tid; t < half; t += 2 * NT) {
+                    const uint32_t t2 = t + NT;
+                    const bool two = t2 < half;
+                    const float2 x = P[lo + t], y = P[hi - t];
+                    const uint16_t u = perm[lo + t], v = perm[hi - t];
+                    float2 x2 = x, y2 = y;
+                    uint16_t u2 = u, v2 = v;
+                    if (two) {
+                        x2 = P[lo + t2];
+                        y2 = P[hi - t2];
+                        u2 = perm[lo + t2];
+                        v2 = perm[hi - t2];
+                    }
+                    P[lo + t] = y;
+                    P[hi - t] = x;
+                    perm[lo + t] = v;
+                    perm[hi - t] = u;
+                    if (two) {
+                        P[lo + t2] = y2;
+                        P[hi - t2] = x2;
+                        perm[lo + t2] = v2;
+                        perm[hi - t2] = u2;
+                    }
+                }
+                __syncthreads();
+                ++moves;
+                reversed += (uint64_t)(hi - is);
+                since += (float)(hi - prev_hit);
+                gap_est = 0.5f * (gap_est + since);
+                since = 0.0f;
+                prev_hit = hi;
             }
             TL_STAMP(4);
-            __syncthreads();
             // L0 metadata of every tile that saw a changed position or tour-edge (j = lo-1 .. hi) is now stale
             {
                 const uint32_t t0 = (lo - 1u) >> 6, t1 = hi >> 6;
@@ -404,13 +482,11 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             }
             TL_STAMP(6);
             improved = true;
-            ++moves;
-            reversed += (uint64_t)(js - is);
-            since += (float)(is - i0) * rowlen + (float)(js - j0);
-            gap_est = 0.5f * (gap_est + since);
-            since = 0.0f;
+#ifdef TL_PROFILE
+            nmoves_pruned += pruned ? nh : 0;
+#endif
             i0 = is;
-            j0 = js + 1u;
+            j0 = resume;
             if (j0 > n - 2u) {
                 ++i0;
                 j0 = i0 + 2u;
@@ -466,11 +542,20 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         st[3] = status;
         st[4] = step;
 #ifdef TL_PROFILE
-        for (int qd = 0; qd < 7; ++qd) st[5 + qd] = prof[qd];
-        st[12] = __builtin_amdgcn_s_memtime() - t_begin;
-        st[13] = __builtin_amdgcn_s_memrealtime() - rt_begin;
-        st[14] = rows_total;
-        st[15] = livetiles;
+        // dense: [5]=setup+scan [6]=wait [7]=apply [8]=apply-barrier ; pruned: [9]=setup+phaseA [10]=barrier [11]=phaseB [12]=wait [13]=apply+barrier
+        st[5] = prof[0] + prof[1] + prof[2];
+        st[6] = prof[3];
+        st[7] = prof[4];
+        st[8] = prof[6];
+        st[9] = prof[8];
+        st[10] = prof[9];
+        st[11] = prof[10];
+        st[12] = prof[11];
+        st[13] = prof[12] + prof[14];
+        st[14] = nsteps_pruned;
+        st[15] = nmoves_pruned;
+        (void)rows_total;
+        (void)livetiles;
 #endif
     }
 }
@@ -483,7 +568,7 @@ size_t two_opt_ref_lds_bytes(uint32_t n, uint32_t *n_pad_out, int nt)
     const uint32_t n_pad = ((n + 64u + 63u) / 64u) * 64u;  // P[j+1] of any lane of the last tile is in range
     if (n_pad_out) *n_pad_out = n_pad;
     if (n_pad > (uint32_t)kMaxGroups * 64u * 64u) return ~(size_t)0;  // beyond the tile-table capacity
-    const size_t meta = (size_t)kMaxGroups * 64 * 20 + (size_t)64 * kMaxGroups * 8 + 64;
+    const size_t meta = (size_t)kMaxGroups * 64 * 20 + 64;
     const size_t tail = (size_t)(nt / 64) * kQCap * 4;  // survivor queues, >= nt floats of scratch
     return (size_t)n_pad * 10 + meta + (tail > (size_t)nt * 4 ? tail : (size_t)nt * 4);
 }
