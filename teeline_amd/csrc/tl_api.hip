@@ -410,11 +410,77 @@ extern "C" int tl_two_opt_multistart(tl_ctx *c, const float *xy, uint32_t n, uin
 }
 
 // ------------------------------------------------------------------------------------------------
-// not yet built in this revision
+// 2-opt, TL_MODE_BEST_SWEEP (this build's own mode; specification: oracle tlo_two_opt_best)
 // ------------------------------------------------------------------------------------------------
-static int two_opt_best_sweep(tl_ctx *c, const float *, uint32_t, const float *, const uint32_t *, uint32_t *, float *, tl_stats *)
+static int two_opt_best_sweep(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
+                              uint32_t *out_pos, float *out_cost, tl_stats *stats)
 {
-    return fail(c, TL_ERR_UNSUPPORTED, "TL_MODE_BEST_SWEEP: not built yet");
+    if (dm_packed || !xy) return fail(c, TL_ERR_UNSUPPORTED, "TL_MODE_BEST_SWEEP needs EUC_2D coordinates (dm_packed must be NULL)");
+    if (n > 65535) return fail(c, TL_ERR_UNSUPPORTED, "TL_MODE_BEST_SWEEP: n=%u > 65535 (packed (i,j) key)", n);
+    const auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(c, hipSetDevice(c->device));
+    if (stats) memset(stats, 0, sizeof(*stats));
+    int rc;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const uint32_t n_pad = ((n + 64u + 63u) / 64u) * 64u, ntile_cap = (((n_pad >> 6) + 63u) / 64u) * 64u;
+    const uint32_t nblocks = n >= 4 ? best_sweep_scan_blocks(n) : 1;
+    const size_t o_perm = 0, o_P = up((size_t)n * 4), o_box = up(o_P + (size_t)(n_pad + 1) * 8), o_msq = up(o_box + (size_t)ntile_cap * 16),
+                 o_par = up(o_msq + (size_t)ntile_cap * 4), o_cnt = up(o_par + (size_t)nblocks * 8), total = o_cnt + 256;
+    if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->work, total)) || (rc = ensure(c, c->out_cost, 4))) return rc;
+    unsigned char *w = (unsigned char *)c->work.p;
+    std::vector<uint32_t> ident;
+    if (!init_pos) {
+        ident.resize(n);
+        for (uint32_t i = 0; i < n; ++i) ident[i] = i;
+        init_pos = ident.data();
+    }
+    HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(w + o_perm, init_pos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(w + o_cnt, 0, 64, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    BestSweepArgs A{};
+    A.xy = (const float2 *)c->xy.p;
+    A.perm = (uint32_t *)(w + o_perm);
+    A.P = (float2 *)(w + o_P);
+    A.tbox = (float4 *)(w + o_box);
+    A.tmsq = (float *)(w + o_msq);
+    A.partials = (unsigned long long *)(w + o_par);
+    A.counters = (uint64_t *)(w + o_cnt);
+    A.n = n;
+    A.n_pad = n_pad;
+    A.ntile_cap = ntile_cap;
+    uint64_t cnt[4] = {1, 0, 1, 0};  // n == 3: one empty sweep
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (n >= 4) {
+        HIPCHK(c, launch_best_sweep_init(A, c->stream));
+        const uint64_t cap = 64ull * n + 1024;
+        for (;;) {
+            for (int r = 0; r < 32; ++r) HIPCHK(c, launch_best_sweep_round(A, c->stream));  // kernels no-op once done
+            HIPCHK(c, hipMemcpyAsync(cnt, A.counters, 32, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (cnt[2]) break;
+            if (cnt[0] > cap) return fail(c, TL_ERR_NO_CONVERGE, "two_opt (BEST_SWEEP): sweep cap reached");
+        }
+    }
+    HIPCHK(c, launch_tour_length(A.xy, nullptr, n, A.perm, (float *)c->out_cost.p, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    c->ev_valid = true;
+    float cost = 0.f;
+    HIPCHK(c, hipMemcpyAsync(out_pos, A.perm, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&cost, c->out_cost.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (out_cost) *out_cost = cost;
+    if (stats) {
+        stats->sweeps = cnt[0];
+        stats->moves = cnt[1];
+        stats->reversed = cnt[3];
+        stats->candidates = cnt[0] * (n >= 4 ? (uint64_t)(n - 3) * (n - 2) / 2 : 0);
+        double kms = 0;
+        tl_last_kernel_ms(c, &kms);
+        stats->kernel_ms = kms;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return TL_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -40,15 +40,17 @@ hipError_t launch_two_opt_ref_dm(const TwoOptBatchArgs &A, uint32_t count, hipSt
 // two_opt_best.hip — BEST_SWEEP mode (whole chip per sweep)
 struct BestSweepArgs {
     const float2 *xy;
-    const float *dm;      // nullptr = on-the-fly
-    uint32_t *perm;       // [n] in/out (device)
-    float2 *P;            // [n_pad] tour-ordered coords workspace
-    unsigned long long *key;  // packed argmin key, device
-    uint32_t n;
+    uint32_t *perm;                // [n] in/out (device)
+    float2 *P;                     // [n_pad + 1] tour-ordered coordinates
+    float4 *tbox;                  // [ntile_cap] L0 boxes
+    float *tmsq;                   // [ntile_cap]
+    unsigned long long *partials;  // one packed key per scan workgroup
+    uint64_t *counters;            // sweeps, moves, done, reversed
+    uint32_t n, n_pad, ntile_cap, phase;
 };
-hipError_t launch_best_sweep_gather(const BestSweepArgs &A, hipStream_t s);
-hipError_t launch_best_sweep_scan(const BestSweepArgs &A, hipStream_t s);
-hipError_t launch_best_sweep_apply(const BestSweepArgs &A, uint64_t *counters, hipStream_t s);
+hipError_t launch_best_sweep_init(const BestSweepArgs &A, hipStream_t s);
+hipError_t launch_best_sweep_round(const BestSweepArgs &A, hipStream_t s);
+uint32_t best_sweep_scan_blocks(uint32_t n);
 
 // three_opt.hip
 struct ThreeOptBest {

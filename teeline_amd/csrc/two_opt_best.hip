@@ -1,0 +1,175 @@
+// two_opt_best.hip — TL_MODE_BEST_SWEEP: best-improvement 2-opt (this build's own throughput mode; NOT the
+// reference's algorithm — the reference is first-improvement, src/tsp/two_opt.rs:26-61).  Specification =
+// oracle/tlo_two_opt_best: per sweep every (i,j) of the same open-path candidate set is decided, the move with the
+// lowest f32 delta (new - cur) < 0 wins, lowest (i,j) on ties; apply; repeat until a sweep finds none.
+//
+// Unlike REF_ORDER a sweep has no sequential dependency, so the whole chip works on it:
+//   k_bs_init    tour-ordered coordinates P[k] = xy[perm[k]] and per-tile L0 metadata, in HBM (L2-resident)
+//   k_bs_scan    one wave per row i.  L0 (lanes = tiles) -> live-tile mask, L1 (lanes = j) on live tiles, L2 hardware
+//                sqrt to discard the clearly non-improving, exact delta for the rest.  Argmin by wavefront DPP/shuffle
+//                reduction of a packed 64-bit key (~delta bits << 32 | i << 16 | j), then per workgroup.
+//   k_bs_apply   one workgroup: reduces the per-workgroup keys, applies swap_2opt(path, i+1, j) on P and perm,
+//                rebuilds the L0 metadata of the touched tiles, bumps the counters / sets the done flag.
+// The host enqueues scan+apply pairs in batches and reads the done flag once per batch.
+#include "tl_kernels.h"
+#include "two_opt_common.h"
+
+#pragma clang fp contract(off)
+
+namespace tl {
+
+namespace {
+
+constexpr unsigned long long kNoKey64 = ~0ULL;
+constexpr int kBsWaves = 4;  // rows per scan workgroup
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_down(v, off);
+        v = o < v ? o : v;
+    }
+    return __shfl(v, 0);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_bs_init(BestSweepArgs A)
+{
+    const uint32_t n = A.n, npad = A.n_pad, ntile = npad >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (A.phase == 0) {
+        for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k <= npad; k += gridDim.x * 256u)
+            A.P[k] = k < n ? A.xy[A.perm[k]] : make_float2(0.f, 0.f);
+        return;
+    }
+    for (uint32_t t = blockIdx.x * 4u + wave; t < A.ntile_cap; t += gridDim.x * 4u) {
+        if (t < ntile) build_tile_meta(A.P, n, t, (int)lane, A.tbox, A.tmsq);
+        else if (lane == 0) {
+            const float inf = __builtin_inff();
+            A.tbox[t] = make_float4(inf, inf, -inf, -inf);
+            A.tmsq[t] = -1.0f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBsWaves * 64) void k_bs_scan(BestSweepArgs A)
+{
+    __shared__ unsigned long long s_key[kBsWaves];
+    const uint32_t n = A.n;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t i = blockIdx.x * kBsWaves + (uint32_t)wave;  // row
+    unsigned long long best = kNoKey64;
+    if (A.counters[2] == 0 && i + 3u < n) {  // not done; rows i in [0, n-3)
+        const float2 *__restrict__ P = A.P;
+        const float2 a = P[i], b = P[i + 1u];
+        const float sqab = sqdist(a, b);
+        const float dab_a = __builtin_amdgcn_sqrtf(sqab);
+        const uint32_t jmin = i + 2u, tmin = jmin >> 6;
+        const uint32_t ngroups = ((A.n_pad >> 6) + 63u) >> 6;
+        for (uint32_t g = 0; g < ngroups; ++g) {
+            const uint32_t tl = (g << 6) + (uint32_t)lane;
+            const float4 box = A.tbox[tl];
+            const float msq = A.tmsq[tl];
+            const bool live = (tl >= tmin) && ((box_lb(a.x, a.y, box) < sqab) || (box_lb(b.x, b.y, box) < msq));  // L0
+            uint64_t m = __builtin_amdgcn_ballot_w64(live);
+            while (m) {
+                const uint32_t t = (g << 6) + (uint32_t)(__builtin_ffsll((long long)m) - 1);
+                m &= m - 1;
+                const uint32_t j = (t << 6) + (uint32_t)lane;
+                const float2 c = P[j], e = P[j + 1u];
+                const float sqce = sqdist(c, e), s1 = sqdist(a, c), s2 = sqdist(b, e);
+                bool test = (j >= jmin) & (j + 2u <= n) & ((s1 < sqab) | (s2 < sqce));  // L1
+                if (!__builtin_amdgcn_ballot_w64(test)) continue;
+                // L2: discard what the hardware sqrt already shows to be non-improving by a safe margin
+                const float neu_a = __builtin_amdgcn_sqrtf(s1) + __builtin_amdgcn_sqrtf(s2);
+                const float cur_a = dab_a + __builtin_amdgcn_sqrtf(sqce);
+                test = test & !(neu_a > cur_a + cur_a * 1.9073486e-6f);
+                if (!__builtin_amdgcn_ballot_w64(test)) continue;
+                const float neu = sqrt_rn(s1) + sqrt_rn(s2);
+                const float cur = sqrt_rn(sqab) + sqrt_rn(sqce);
+                if (test & (neu < cur)) {
+                    const float delta = neu - cur;
+                    const unsigned long long key = ((unsigned long long)(~__builtin_bit_cast(uint32_t, delta)) << 32) | (i << 16) | j;
+                    best = key < best ? key : best;
+                }
+            }
+        }
+    }
+    best = wave_min_u64(best);
+    if (lane == 0) s_key[wave] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long k = s_key[0];
+        for (int w = 1; w < kBsWaves; ++w) k = s_key[w] < k ? s_key[w] : k;
+        A.partials[blockIdx.x] = k;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_bs_apply(BestSweepArgs A, uint32_t nblocks)
+{
+    __shared__ unsigned long long s_key[16];
+    const uint32_t tid = threadIdx.x, n = A.n;
+    const int lane = tid & 63, wave = tid >> 6;
+    if (A.counters[2] != 0) return;  // done in an earlier sweep of this batch
+    unsigned long long best = kNoKey64;
+    for (uint32_t b = tid; b < nblocks; b += 1024u) {
+        const unsigned long long k = A.partials[b];
+        best = k < best ? k : best;
+    }
+    best = wave_min_u64(best);
+    if (lane == 0) s_key[wave] = best;
+    __syncthreads();
+    best = s_key[0];
+    for (int w = 1; w < 16; ++w) best = s_key[w] < best ? s_key[w] : best;
+    if (best == kNoKey64) {
+        if (tid == 0) {
+            A.counters[0] += 1;  // the final, move-less sweep
+            A.counters[2] = 1;   // done
+        }
+        return;
+    }
+    const uint32_t is = (uint32_t)((best >> 16) & 0xFFFFu), js = (uint32_t)(best & 0xFFFFu);
+    const uint32_t lo = is + 1u, hi = js, half = (hi - lo + 1u) >> 1;
+    float2 *P = A.P;
+    uint32_t *perm = A.perm;
+    for (uint32_t t = tid; t < half; t += 1024u) {  // swap_2opt(path, i+1, j)
+        const float2 x = P[lo + t], y = P[hi - t];
+        P[lo + t] = y;
+        P[hi - t] = x;
+        const uint32_t u = perm[lo + t], v = perm[hi - t];
+        perm[lo + t] = v;
+        perm[hi - t] = u;
+    }
+    __syncthreads();
+    for (uint32_t t = ((lo - 1u) >> 6) + (uint32_t)wave; t <= (hi >> 6); t += 16u) build_tile_meta(P, n, t, lane, A.tbox, A.tmsq);
+    if (tid == 0) {
+        A.counters[0] += 1;                       // sweeps
+        A.counters[1] += 1;                       // moves
+        A.counters[3] += (uint64_t)(js - is);     // reversed elements
+    }
+}
+
+hipError_t launch_best_sweep_init(const BestSweepArgs &A, hipStream_t s)
+{
+    BestSweepArgs B = A;
+    B.phase = 0;
+    hipLaunchKernelGGL(k_bs_init, dim3((A.n_pad + 256u) / 256u), dim3(256), 0, s, B);
+    B.phase = 1;
+    hipLaunchKernelGGL(k_bs_init, dim3((A.ntile_cap + 3u) / 4u), dim3(256), 0, s, B);
+    return hipGetLastError();
+}
+
+hipError_t launch_best_sweep_round(const BestSweepArgs &A, hipStream_t s)
+{
+    const uint32_t rows = A.n - 3u;
+    const uint32_t nblocks = (rows + kBsWaves - 1) / kBsWaves;
+    hipLaunchKernelGGL(k_bs_scan, dim3(nblocks), dim3(kBsWaves * 64), 0, s, A);
+    hipLaunchKernelGGL(k_bs_apply, dim3(1), dim3(1024), 0, s, A, nblocks);
+    return hipGetLastError();
+}
+
+uint32_t best_sweep_scan_blocks(uint32_t n) { return (n - 3u + kBsWaves - 1) / kBsWaves; }
+
+}  // namespace tl
