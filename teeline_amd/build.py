@@ -56,5 +56,23 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
     return LIB_OUT
 
 
+CLI = os.path.join(HERE, "teeline-gpu")
+CLI_SRC = os.path.join(HERE, "host_cpp", "teeline_gpu_cli.cpp")
+CLI_HDR = os.path.join(HERE, "host_cpp", "teeline_gpu.hpp")
+
+
+def build_cli(force=False):
+    """C++ host mirror + CLI façade (g++, links the in-tree libteeline_gpu.so through an $ORIGIN rpath)."""
+    build()
+    deps = [CLI_SRC, CLI_HDR, os.path.join(ROOT, "include", "teeline_gpu.h"), LIB]
+    if not force and os.path.exists(CLI) and all(os.path.getmtime(d) <= os.path.getmtime(CLI) for d in deps):
+        return CLI
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), CLI_SRC, "-o", CLI,
+           "-L", HERE, "-lteeline_gpu", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return CLI
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_cli(force="--force" in sys.argv))

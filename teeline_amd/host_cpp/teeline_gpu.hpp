@@ -1,0 +1,389 @@
+// teeline_gpu.hpp — C++ host-side mirror of the reference's solver interface for the 2-opt / 3-opt / LK path,
+// over the C ABI of libteeline_gpu.so (include/teeline_gpu.h).  Header-only; no torch, no Python.
+//
+// The reference is Rust and no Rust toolchain exists in the build image, so this is the compiled-language mirror of
+//   src/tsp/kdtree.rs:248-252        KDPoint
+//   src/tsp/distance_matrix.rs       DistanceMatrix (packed strict lower triangle)
+//   src/tsp/mod.rs:1731-1814         TspProblem, Solution
+//   src/tsp/mod.rs:596-613,1249-1267 HeuristicOptions, LKOptions
+//   src/tsp/tsplib.rs:101-255        tsplib::read_from_file
+//   src/tsp/{two_opt,three_opt,lin_kernighan,nearest_neighbor}.rs  solve(problem, opts, progress, init_tour)
+//   src/tsp/pipeline.rs:53-80        run_pipeline_stages (warm start + validate_tour)
+// Same names, argument meaning and error behaviour: dispatcher-level failures throw std::runtime_error (the
+// reference returns Err(String), mod.rs:1661), inputs on which the reference panics throw teeline::ReferencePanic.
+#pragma once
+#include <teeline_gpu.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <fstream>
+#include <functional>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace teeline {
+
+struct ReferencePanic : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+class Context {  // one tl_ctx per thread (teeline-api calls solvers from spawn_blocking, tsp_service.rs:295)
+  public:
+    explicit Context(int device = 0, uint32_t flags = TL_FLAG_NONE)
+    {
+        if (tl_create(device, flags, &h_) != TL_OK) throw std::runtime_error(tl_last_error(nullptr));
+    }
+    ~Context() { tl_destroy(h_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    tl_ctx *get() const { return h_; }
+    void check(int rc) const
+    {
+        if (rc == TL_OK) return;
+        if (rc == TL_ERR_REF_PANICS) throw ReferencePanic(tl_last_error(h_));
+        throw std::runtime_error(std::string("teeline-gpu: ") + tl_last_error(h_));
+    }
+
+  private:
+    tl_ctx *h_ = nullptr;
+};
+
+namespace tsp {
+
+struct KDPoint {  // kdtree.rs:248-252
+    size_t id;
+    float coords[2];
+};
+
+enum class DistanceType { Euc2D, Geo, Explicit };  // mod.rs DistanceType
+
+class DistanceMatrix {  // distance_matrix.rs:82-212
+  public:
+    DistanceMatrix() = default;
+    DistanceMatrix(size_t n, std::vector<float> items, const std::vector<KDPoint> &cities, DistanceType kind)
+        : n_(n), items_(std::move(items)), kind_(kind)
+    {
+        if (items_.size() != n * (n - 1) / 2) throw std::runtime_error("distances length != n*(n-1)/2");  // :100-107
+        for (size_t p = 0; p < cities.size(); ++p) city_idx_[cities[p].id] = p;
+        if (city_idx_.size() != n) throw std::runtime_error("city_idx size differs from n cities");  // :99
+    }
+    // DistanceMatrix::build (:122-153) on the GPU
+    static DistanceMatrix build(Context &ctx, const std::vector<KDPoint> &cities, DistanceType dt)
+    {
+        if (cities.size() < 2) throw std::runtime_error("distance matrix requires at least 2 points");
+        if (dt == DistanceType::Explicit)
+            throw std::runtime_error("cannot build distance matrix from coordinates for EXPLICIT type — use DistanceMatrix::new() with precomputed distances");
+        std::vector<float> xy;
+        for (auto &c : cities) { xy.push_back(c.coords[0]); xy.push_back(c.coords[1]); }
+        const size_t n = cities.size();
+        std::vector<float> items(n * (n - 1) / 2);
+        ctx.check(tl_dm_build(ctx.get(), xy.data(), (uint32_t)n, dt == DistanceType::Geo ? TL_DIST_GEO : TL_DIST_EUC2D,
+                              TL_DM_PACKED_LOWER, items.data(), nullptr));
+        return DistanceMatrix(n, std::move(items), cities, dt);
+    }
+    size_t num_cities() const { return n_; }
+    const std::vector<float> &distances() const { return items_; }
+    DistanceType kind() const { return kind_; }
+    float distance_by_pos(size_t p, size_t q) const  // :177-191
+    {
+        if (p == q) return 0.0f;
+        if (p >= n_ || q >= n_) throw std::out_of_range("position out of range");
+        const size_t from = std::max(p, q), to = std::min(p, q);
+        return items_.at(from * (from - 1) / 2 + to);
+    }
+    float distance_between(size_t id1, size_t id2) const  // :197-212
+    {
+        if (id1 == id2) return 0.0f;
+        return distance_by_pos(city_idx_.at(id1), city_idx_.at(id2));
+    }
+    bool city_id2pos(size_t id, size_t &pos) const
+    {
+        auto it = city_idx_.find(id);
+        if (it == city_idx_.end()) return false;
+        pos = it->second;
+        return true;
+    }
+
+  private:
+    size_t n_ = 0;
+    std::vector<float> items_;
+    DistanceType kind_ = DistanceType::Euc2D;
+    std::unordered_map<size_t, size_t> city_idx_;
+};
+
+struct TspProblem {  // mod.rs:1731-1741
+    std::vector<KDPoint> cities;
+    DistanceMatrix distances;  // may be empty for plain EUC_2D: the kernels compute the identical f32 values on the fly
+    DistanceType distance_type = DistanceType::Euc2D;
+
+    std::vector<float> xy() const
+    {
+        std::vector<float> v;
+        v.reserve(cities.size() * 2);
+        for (auto &c : cities) { v.push_back(c.coords[0]); v.push_back(c.coords[1]); }
+        return v;
+    }
+    const float *explicit_packed() const { return distance_type == DistanceType::Euc2D ? nullptr : distances.distances().data(); }
+    std::vector<uint32_t> positions_of(const std::vector<size_t> &tour) const
+    {
+        std::unordered_map<size_t, uint32_t> idx;
+        for (size_t p = 0; p < cities.size(); ++p) idx[cities[p].id] = (uint32_t)p;
+        std::vector<uint32_t> out;
+        for (size_t id : tour) {
+            auto it = idx.find(id);
+            if (it == idx.end()) throw ReferencePanic("two_opt: invalid city pair");  // two_opt.rs:37-47 .expect(...)
+            out.push_back(it->second);
+        }
+        return out;
+    }
+};
+
+struct HeuristicOptions {  // mod.rs:596-613
+    size_t epochs = 10000, platoo_epochs = 500, n_nearest = 3;
+    bool verbose = false;
+};
+struct LKOptions {  // mod.rs:1249-1267
+    HeuristicOptions heuristic{100, 10, 5, false};
+    size_t max_depth = 5;
+};
+
+struct Solution {  // mod.rs:1753-1814
+    float total = 0.0f;
+    std::vector<size_t> route_;
+    tl_stats stats{};
+    const std::vector<size_t> &route() const { return route_; }
+};
+
+enum class ProgressKind { PathUpdate, CityChange, Done };
+using ProgressFn = std::function<void(ProgressKind, const std::vector<size_t> &, float)>;  // progress.rs ProgressMessage
+
+inline bool validate_tour(const std::vector<size_t> &tour, const std::vector<KDPoint> &cities)  // mod.rs:1620-1634
+{
+    if (tour.size() != cities.size()) return false;
+    std::vector<size_t> a(tour), b;
+    for (auto &c : cities) b.push_back(c.id);
+    std::sort(a.begin(), a.end());
+    std::sort(b.begin(), b.end());
+    return a == b;
+}
+
+namespace detail {
+inline Solution finish(const TspProblem &p, const std::vector<uint32_t> &pos, float cost, const tl_stats &st, const ProgressFn *tx)
+{
+    Solution s;
+    s.total = cost;
+    s.stats = st;
+    for (uint32_t q : pos) s.route_.push_back(p.cities[q].id);
+    if (tx && *tx) {
+        (*tx)(ProgressKind::PathUpdate, s.route_, cost);
+        (*tx)(ProgressKind::Done, s.route_, cost);
+    }
+    return s;
+}
+}  // namespace detail
+
+namespace two_opt {  // two_opt.rs:7-67
+inline Solution solve(Context &ctx, const TspProblem &problem, const HeuristicOptions & /*_opts*/, const ProgressFn *progress_tx,
+                      const std::vector<size_t> *init_tour, int mode = TL_MODE_REF_ORDER)
+{
+    const auto xy = problem.xy();
+    const uint32_t n = (uint32_t)problem.cities.size();
+    std::vector<uint32_t> init, out(n);
+    if (init_tour) init = problem.positions_of(*init_tour);
+    float cost = 0.f;
+    tl_stats st{};
+    ctx.check(tl_two_opt(ctx.get(), xy.data(), n, problem.explicit_packed(), init_tour ? init.data() : nullptr, mode, out.data(), &cost, &st));
+    return detail::finish(problem, out, cost, st, progress_tx);
+}
+}  // namespace two_opt
+
+namespace three_opt {  // three_opt.rs:16-51
+inline Solution solve(Context &ctx, const TspProblem &problem, const HeuristicOptions &, const ProgressFn *progress_tx,
+                      const std::vector<size_t> *init_tour)
+{
+    const auto xy = problem.xy();
+    const uint32_t n = (uint32_t)problem.cities.size();
+    std::vector<uint32_t> init, out(n);
+    if (init_tour) init = problem.positions_of(*init_tour);
+    float cost = 0.f;
+    tl_stats st{};
+    ctx.check(tl_three_opt(ctx.get(), xy.data(), n, problem.explicit_packed(), init_tour ? init.data() : nullptr, out.data(), &cost, &st));
+    return detail::finish(problem, out, cost, st, progress_tx);
+}
+}  // namespace three_opt
+
+namespace nearest_neighbor {  // nearest_neighbor.rs:8-76
+inline Solution solve(Context &ctx, const TspProblem &problem, const HeuristicOptions &opts, const ProgressFn *progress_tx,
+                      const std::vector<size_t> * /*_init_tour*/)
+{
+    if (problem.explicit_packed()) throw std::runtime_error("nearest_neighbor on the GPU needs EUC_2D coordinates");
+    const auto xy = problem.xy();
+    const uint32_t n = (uint32_t)problem.cities.size();
+    std::vector<uint32_t> out(n);
+    float cost = 0.f;
+    ctx.check(tl_nearest_neighbor(ctx.get(), xy.data(), n, (uint32_t)opts.n_nearest, out.data(), &cost));
+    return detail::finish(problem, out, cost, tl_stats{}, progress_tx);
+}
+}  // namespace nearest_neighbor
+
+namespace lin_kernighan {  // lin_kernighan.rs:35-100
+inline Solution solve(Context &ctx, const TspProblem &problem, const LKOptions &opts, const ProgressFn *progress_tx,
+                      const std::vector<size_t> *init_tour, uint64_t seed = 1)
+{
+    if (opts.heuristic.n_nearest == 0) throw std::runtime_error("n_nearest must be >= 1");  // mod.rs:677-682
+    if (opts.max_depth == 0) throw std::runtime_error("max_depth must be >= 1");            // mod.rs:1270-1276
+    const auto xy = problem.xy();
+    const uint32_t n = (uint32_t)problem.cities.size();
+    std::vector<uint32_t> init, out(n);
+    if (init_tour) init = problem.positions_of(*init_tour);
+    tl_lk_opts o{(uint32_t)opts.heuristic.epochs, (uint32_t)opts.heuristic.platoo_epochs, (uint32_t)opts.heuristic.n_nearest, (uint32_t)opts.max_depth};
+    float cost = 0.f;
+    tl_stats st{};
+    ctx.check(tl_lk(ctx.get(), xy.data(), n, init_tour ? init.data() : nullptr, &o, seed, out.data(), &cost, &st));
+    return detail::finish(problem, out, cost, st, progress_tx);
+}
+}  // namespace lin_kernighan
+
+namespace tsplib {  // tsplib.rs:142-255
+
+struct TspLibData {
+    std::string name, comment;
+    std::vector<KDPoint> cities;
+    size_t dimension = 0;
+    std::vector<float> raw_distances;
+    bool has_raw = false;
+    DistanceType distance_type = DistanceType::Euc2D;
+
+    TspProblem problem(Context &ctx) const  // TspLibData::distance_matrix (:84-98) + TspProblem::new
+    {
+        TspProblem p;
+        p.cities = cities;
+        if (has_raw) {
+            p.distances = DistanceMatrix(cities.size(), raw_distances, cities, DistanceType::Explicit);
+            p.distance_type = DistanceType::Explicit;
+        } else if (distance_type == DistanceType::Geo) {
+            p.distances = DistanceMatrix::build(ctx, cities, DistanceType::Geo);
+            p.distance_type = DistanceType::Geo;
+        }
+        return p;
+    }
+};
+
+inline bool parse_f32(const std::string &t, float &v)
+{
+    char *end = nullptr;
+    v = std::strtof(t.c_str(), &end);  // f32::from_str: parse straight to f32, not strtod + cast
+    return end && *end == '\0' && end != t.c_str();
+}
+
+inline TspLibData read_from_string(const std::string &text)
+{
+    std::map<std::string, std::string> meta;
+    TspLibData d;
+    std::vector<float> weights;
+    enum { Start, In, Out, End } state = Start;
+    std::string section, raw;
+    std::istringstream in(text);
+    size_t line_no = 1;
+    auto is_section = [](const std::string &l) {
+        if (l.empty() || !(std::isupper((unsigned char)l[0]) || l[0] == '_')) return false;
+        for (char ch : l)
+            if (!(std::isalnum((unsigned char)ch) || ch == '_')) return false;
+        return true;
+    };
+    while (std::getline(in, raw)) {
+        size_t b = raw.find_first_not_of(" \t\r\n"), e = raw.find_last_not_of(" \t\r\n");
+        std::string line = b == std::string::npos ? "" : raw.substr(b, e - b + 1);
+        for (auto &ch : line) ch = (char)std::toupper((unsigned char)ch);
+        ++line_no;
+        if (state == End) break;
+        if (is_section(line)) {
+            if (line == "EOF") state = End;
+            else { state = In; section = line; }
+            continue;
+        }
+        std::istringstream ls(line);
+        std::vector<std::string> tok;
+        for (std::string t; ls >> t;) tok.push_back(t);
+        if (state == Start) {
+            size_t c = line.find(':');
+            if (c == std::string::npos) throw std::runtime_error("Failed to extract meta data on line." + std::to_string(line_no));
+            auto trim = [](std::string s) {
+                size_t b2 = s.find_first_not_of(" \t"), e2 = s.find_last_not_of(" \t");
+                return b2 == std::string::npos ? std::string() : s.substr(b2, e2 - b2 + 1);
+            };
+            meta[trim(line.substr(0, c))] = trim(line.substr(c + 1));
+        } else if (state == In && (section == "NODE_COORD_SECTION" || section == "DISPLAY_DATA_SECTION")) {
+            float f;
+            if (tok.empty() || !parse_f32(tok[0], f)) throw std::runtime_error("Failed to extract coordinates on line." + std::to_string(line_no));
+            if (tok.size() < 3) throw std::runtime_error("KDPoint requires at least 2 coordinates");
+            KDPoint p{};
+            p.id = (size_t)std::stoull(tok[0]);
+            if (!parse_f32(tok[1], p.coords[0]) || !parse_f32(tok[2], p.coords[1]))
+                throw std::runtime_error("Error on line." + std::to_string(line_no) + " - invalid number");
+            d.cities.push_back(p);
+        } else if (state == In && section == "EDGE_WEIGHT_SECTION") {
+            for (auto &t : tok) {
+                float f;
+                if (parse_f32(t, f)) weights.push_back(f);
+            }
+        }
+    }
+    if (meta.count("TYPE") && meta["TYPE"] == "ATSP") throw std::runtime_error("ATSP (asymmetric TSP) is not supported");
+    const std::string ewt = meta.count("EDGE_WEIGHT_TYPE") ? meta["EDGE_WEIGHT_TYPE"] : "";
+    d.distance_type = ewt == "GEO" ? DistanceType::Geo : (ewt == "EXPLICIT" ? DistanceType::Explicit : DistanceType::Euc2D);  // unknown -> EUC_2D (:199-202)
+    d.dimension = meta.count("DIMENSION") ? (size_t)std::strtoull(meta["DIMENSION"].c_str(), nullptr, 10) : 0;
+    if (!weights.empty()) {
+        const size_t n = d.dimension;
+        const std::string fmt = meta.count("EDGE_WEIGHT_FORMAT") ? meta["EDGE_WEIGHT_FORMAT"] : "";
+        std::vector<float> full(n * n, 0.0f);
+        if (fmt == "FULL_MATRIX") {
+            if (weights.size() != n * n) throw std::runtime_error("FULL_MATRIX: expected " + std::to_string(n * n) + " tokens, got " + std::to_string(weights.size()));
+            full = weights;
+        } else if (fmt == "UPPER_ROW") {
+            if (weights.size() != n * (n - 1) / 2) throw std::runtime_error("UPPER_ROW: wrong token count");
+            size_t k = 0;
+            for (size_t i = 0; i + 1 < n; ++i)
+                for (size_t j = i + 1; j < n; ++j) full[i * n + j] = full[j * n + i] = weights[k++];
+        } else if (fmt == "LOWER_DIAG_ROW") {
+            if (weights.size() != n * (n + 1) / 2) throw std::runtime_error("LOWER_DIAG_ROW: wrong token count");
+            size_t k = 0;
+            for (size_t i = 0; i < n; ++i)
+                for (size_t j = 0; j <= i; ++j) full[i * n + j] = weights[k++];
+        } else {
+            throw std::runtime_error("Unsupported EDGE_WEIGHT_FORMAT: " + fmt);
+        }
+        for (size_t i = 1; i < n; ++i)
+            for (size_t j = 0; j < i; ++j) d.raw_distances.push_back(full[i * n + j]);
+        d.has_raw = true;
+    }
+    if (d.cities.empty() && d.has_raw) {  // grid placeholder coordinates (:246-258)
+        const size_t cols = (size_t)std::ceil(std::sqrt((double)d.dimension));
+        for (size_t i = 0; i < d.dimension; ++i) d.cities.push_back(KDPoint{i + 1, {(float)(i % cols), (float)(i / cols)}});
+    }
+    if (d.cities.empty()) throw std::runtime_error("Found no valid city coordinates");
+    auto lower = [](std::string s) { for (auto &ch : s) ch = (char)std::tolower((unsigned char)ch); return s; };
+    d.name = lower(meta.count("NAME") ? meta["NAME"] : "unspecified");
+    d.comment = lower(meta.count("COMMENT") ? meta["COMMENT"] : "unspecified");
+    return d;
+}
+
+inline TspLibData read_from_file(const std::string &path)
+{
+    std::ifstream f(path);
+    if (!f) throw std::runtime_error("tsplib: failed to read file");
+    std::stringstream ss;
+    ss << f.rdbuf();
+    return read_from_string(ss.str());
+}
+
+}  // namespace tsplib
+}  // namespace tsp
+}  // namespace teeline

@@ -96,3 +96,16 @@ def test_host_mirror_tsplib_and_types(tsplib_dir):
     assert T.validate_tour([3, 1, 2], p) and not T.validate_tour([3, 1, 1], p)
     with pytest.raises(ValueError):
         T.LKOptions(max_depth=0).validate()
+
+
+def test_cpp_host_mirror_builds_and_fails_loudly_without_gpu(tsplib_dir):
+    import torch
+    from teeline_amd import build
+    cli = build.build_cli()
+    assert os.path.exists(cli)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([cli, "solve", "2opt", "-i", os.path.join(tsplib_dir, "berlin52.tsp")], capture_output=True, text=True)
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr and r.stdout == ""
+    r = subprocess.run([cli, "bogus"], capture_output=True, text=True)
+    assert r.returncode == 2
