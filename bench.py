@@ -185,9 +185,11 @@ def main():
     }
     # traffic from a committed PMC pass, if one exists for this round
     tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and n == 10000 and R == 256:
         try:
-            out["roofline"]["traffic"] = json.load(open(tpath)).get("traffic_bytes_per_launch")
+            tj = json.load(open(tpath))
+            out["roofline"]["traffic"] = tj.get("traffic_bytes_per_launch")
+            out["roofline"]["traffic_source"] = tj.get("source")
         except Exception:
             pass
 
@@ -199,6 +201,16 @@ def main():
         extras["single_descent_random_start"] = {"candidates_per_s": sol.stats["candidates"] / (sol.stats["kernel_ms"] * 1e-3),
                                                  "kernel_ms": sol.stats["kernel_ms"], "cost": float(sol.total),
                                                  "moves": sol.stats["moves"], "sweeps": sol.stats["sweeps"]}
+        rc_nn = TA.nearest_neighbor.solve(prob, ctx=ctx)
+        sol_g = TA.two_opt.solve(prob, None, None, rc_nn.route(), ctx=ctx)
+        extras["single_descent_nn_start"] = {"candidates_per_s": sol_g.stats["candidates"] / (sol_g.stats["kernel_ms"] * 1e-3),
+                                             "kernel_ms": sol_g.stats["kernel_ms"], "cost": float(sol_g.total), "nn_cost": float(rc_nn.total),
+                                             "moves": sol_g.stats["moves"], "sweeps": sol_g.stats["sweeps"],
+                                             "note": "BASELINE configs[2]: one REF_ORDER descent from the NN seed on ONE CU; expected cost 77647.55469"}
+        sol_b = TA.two_opt.solve(prob, None, None, rc_nn.route(), ctx=ctx, mode=TA.TL_MODE_BEST_SWEEP)
+        extras["best_sweep_nn_start"] = {"candidates_per_s": sol_b.stats["candidates"] / (sol_b.stats["kernel_ms"] * 1e-3),
+                                         "kernel_ms": sol_b.stats["kernel_ms"], "cost": float(sol_b.total), "sweeps": sol_b.stats["sweeps"],
+                                         "note": "TL_MODE_BEST_SWEEP (own mode, whole chip per sweep), single descent"}
         with TA.Context(local, TA.TL_FLAG_NO_PRUNE) as c2:
             s2 = TA.two_opt.multistart(prob, R, seed=a.seed, first=0, ctx=c2)
             extras["no_prune_multistart"] = {"candidates_per_s": s2.stats["candidates"] / (s2.stats["kernel_ms"] * 1e-3),
@@ -209,6 +221,14 @@ def main():
         gb = n * (n - 1) / 2 * 4 / 1e9
         extras["dm_build_packed"] = {"kernel_ms": ms, "GBps": gb / (ms * 1e-3), "frac_of_hbm_peak": gb / (ms * 1e-3) / HBM_PEAK_GBPS,
                                      "bytes": n * (n - 1) // 2 * 4}
+        n3 = 1002
+        p3 = TA.TspProblem(np.arange(n3), TA.synth.synth_xy(n3))
+        nn3 = [int(v) for v in TA.nearest_neighbor.solve(p3, ctx=ctx).route()]
+        TA.three_opt.find_best_move(p3, nn3, ctx=ctx)
+        TA.three_opt.find_best_move(p3, nn3, ctx=ctx)
+        ms3 = ctx.last_kernel_ms()
+        tri = n3 * (n3 - 1) * (n3 - 2) // 6 - (n3 - 2)
+        extras["three_opt_scan_n1002"] = {"triples_per_s": tri / (ms3 * 1e-3), "kernel_ms": ms3, "triples": tri}
         out["extras"] = extras
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n, a.seed, xy)
