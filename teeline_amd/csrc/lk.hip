@@ -477,6 +477,242 @@ __global__ __launch_bounds__(kLkNT) void k_lk_solve(LkArgs G)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Multi-CU variant for large n: the same algorithm as k_lk_solve, cut at its only grid-wide seam.
+//   k_lk_scan     every (t1, orientation) pair of find_lk_move at once, one lane each, over all CUs; lanes with a
+//                 valid chain store it in their slot and atomicMin the pair index — the reference's "first in
+//                 order" is the minimum.
+//   k_lk_control  one workgroup, a device-side state machine: apply the winning chain and rescan, or — when the scan
+//                 found nothing, i.e. the lk_pass is over — evaluate the tour, accept/reject, kick (double_bridge)
+//                 or finish.  The host only enqueues (scan, control) pairs in batches and polls `finished`.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lk_scan(LkArgs G)
+{
+    LkState *S = G.state;
+    if (S->finished) return;
+    const uint32_t n = G.n, idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= 2u * n) return;
+    LkView V{G.xy, G.cand, G.next, G.prev, G.k, G.max_depth};
+    uint32_t chain[kLkMaxChain];
+    uint32_t clen = 0;
+    const uint32_t t1 = G.city_ids[idx >> 1];
+    const uint32_t t2 = (idx & 1u) ? G.prev[t1] : G.next[t1];
+    const float2 p1 = G.xy[t1], p2 = G.xy[t2];
+    chain[0] = t1;
+    chain[1] = t2;
+    const float g0 = t1 == t2 ? 0.0f : dist(p1, p2);
+    if (lk_chain<0>(V, chain, clen, p1, t2, p2, g0) && chain_valid(chain, clen, G.tour, G.pos, n)) {
+        uint32_t *slot = G.chains + (size_t)idx * (kLkMaxChain + 2);
+        slot[0] = clen;
+        for (uint32_t t = 0; t < clen; ++t) slot[1 + t] = chain[t];
+        atomicMin(&S->key, idx);
+    }
+}
+
+__global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
+{
+    __shared__ uint32_t s_nseg;
+    __shared__ LkSeg s_seg[2 * (kLkMaxDepth + 2)];
+    __shared__ float s_part[kLkNT];
+    LkState *S = G.state;
+    if (S->finished) return;
+    const uint32_t tid = threadIdx.x, n = G.n;
+    uint32_t *tour = G.tour, *alt = G.alt, *pos = G.pos, *next = G.next, *prev = G.prev, *best = G.best;
+    const float2 *__restrict__ xy = G.xy;
+
+    auto rebuild = [&]() {
+        for (uint32_t r = tid; r < n; r += kLkNT) {
+            const uint32_t c = tour[r];
+            pos[c] = r;
+            next[c] = tour[r + 1u == n ? 0u : r + 1u];
+            prev[c] = tour[r == 0u ? n - 1u : r - 1u];
+        }
+    };
+    auto tour_distance = [&](const uint32_t *t) -> float {  // lin_kernighan.rs:118-122
+        float total = 0.0f;
+        for (uint32_t base = 0; base < n; base += kLkNT) {
+            const uint32_t r = base + tid;
+            if (r < n) {
+                const uint32_t a = t[r], b = t[r + 1u == n ? 0u : r + 1u];
+                s_part[tid] = a == b ? 0.0f : dist(xy[a], xy[b]);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                const uint32_t cnt = (n - base) < (uint32_t)kLkNT ? (n - base) : (uint32_t)kLkNT;
+                for (uint32_t q = 0; q < cnt; ++q) total += s_part[q];
+            }
+            __syncthreads();
+        }
+        if (tid == 0) s_part[0] = total;
+        __syncthreads();
+        const float r = s_part[0];
+        __syncthreads();
+        return r;
+    };
+
+    const uint32_t key = S->key;
+    __syncthreads();
+    if (key != 0xFFFFFFFFu) {
+        // ---- apply_lk_chain (:397-450), then rescan (lk_pass loop :468-478)
+        const uint32_t *slot = G.chains + (size_t)key * (kLkMaxChain + 2);
+        const uint32_t clen = slot[0];
+        if (tid == 0) {
+            uint32_t chain[kLkMaxChain];
+            for (uint32_t t = 0; t < clen; ++t) chain[t] = slot[1 + t];
+            Arcs A;
+            arcs_build(chain, clen, pos, n, A);
+            bool first_removed = false;
+            for (uint32_t m = 0; m < A.k; ++m) first_removed |= (A.lo[m] == 0u);
+            uint32_t nseg = 0, emitted = 0, p = 0;
+            int dir = first_removed ? -1 : +1;
+            while (emitted < n && nseg < 2 * (kLkMaxDepth + 2)) {
+                const uint32_t endp = dir > 0 ? arc_end_from_start(A, p) : arc_start_from_end(A, p, n);
+                uint32_t len = dir > 0 ? (endp >= p ? endp - p + 1u : endp + n - p + 1u) : (p >= endp ? p - endp + 1u : p + n - endp + 1u);
+                if (len > n - emitted) len = n - emitted;
+                s_seg[nseg].src = p;
+                s_seg[nseg].len = len;
+                s_seg[nseg].dst = emitted;
+                s_seg[nseg].dir = dir;
+                ++nseg;
+                emitted += len;
+                if (emitted >= n) break;
+                const uint32_t city = chain_partner(chain, clen, tour[endp]);
+                p = pos[city];
+                dir = arc_is_start(A, p, n) ? +1 : -1;
+            }
+            s_nseg = nseg;
+        }
+        __syncthreads();
+        const uint32_t nseg = s_nseg;
+        for (uint32_t sidx = 0; sidx < nseg; ++sidx) {
+            const LkSeg sg = s_seg[sidx];
+            for (uint32_t t = tid; t < sg.len; t += kLkNT) {
+                uint32_t sp = sg.dir > 0 ? sg.src + t : sg.src + n - t;
+                if (sp >= n) sp -= n;
+                alt[sg.dst + t] = tour[sp];
+            }
+        }
+        __syncthreads();
+        for (uint32_t r = tid; r < n; r += kLkNT) tour[r] = alt[r];
+        __syncthreads();
+        rebuild();
+        if (tid == 0) {
+            S->scans += 1;
+            S->searches += (uint64_t)key + 1u;
+            S->moves += 1;
+            S->exchanged += clen / 2u;
+            S->key = 0xFFFFFFFFu;
+        }
+        return;
+    }
+    // ---- the scan found nothing: this lk_pass is over (:472-473)
+    if (tid == 0) {
+        S->scans += 1;
+        S->searches += 2ull * n;
+    }
+    bool kick = false;
+    if (S->stage == 0) {                       // initial pass done (:61-70)
+        for (uint32_t r = tid; r < n; r += kLkNT) best[r] = tour[r];
+        __syncthreads();
+        const float bd = tour_distance(best);
+        if (tid == 0) {
+            S->best_dist = bd;
+            S->stage = 1;
+            S->epoch = 0;
+            S->platoo = 0;
+        }
+        kick = G.epochs > 0;
+    } else {                                    // an epoch's pass done (:85-96)
+        const float dcur = tour_distance(tour);
+        const bool better = dcur < S->best_dist;
+        __syncthreads();
+        bool stop = false;
+        if (better) {
+            for (uint32_t r = tid; r < n; r += kLkNT) best[r] = tour[r];
+        }
+        uint32_t platoo = S->platoo, epoch = S->epoch;
+        __syncthreads();
+        if (better) platoo = 0;
+        else if (++platoo >= G.platoo_epochs) stop = true;
+        ++epoch;
+        if (tid == 0) {
+            if (better) S->best_dist = dcur;
+            S->platoo = platoo;
+            S->epoch = epoch;
+        }
+        kick = !stop && epoch < G.epochs;
+    }
+    __syncthreads();
+    if (!kick) {
+        if (tid == 0) S->finished = 1;
+        return;
+    }
+    // ---- double_bridge (:485-499) into `tour`, then a fresh lk_pass: city_ids = tour (:466)
+    if (n < 8) {
+        for (uint32_t r = tid; r < n; r += kLkNT) tour[r] = best[r];
+    } else {
+        const uint64_t draws = S->draws;
+        const uint32_t qn = n / 4u;
+        const uint32_t r1 = (uint32_t)(splitmix64_at(G.seed, draws) % qn), r2 = (uint32_t)(splitmix64_at(G.seed, draws + 1) % qn),
+                       r3 = (uint32_t)(splitmix64_at(G.seed, draws + 2) % qn);
+        const uint32_t p1 = 1u + r1, p2 = p1 + 1u + r2, p3 = p2 + 1u + r3;
+        for (uint32_t w = tid; w < n; w += kLkNT) {
+            uint32_t src;
+            if (w < p1) src = w;
+            else if (w < p1 + (p3 - p2)) src = p2 + (w - p1);
+            else if (w < p3) src = p1 + (w - p1 - (p3 - p2));
+            else src = w;
+            tour[w] = best[src];
+        }
+        __syncthreads();
+        if (tid == 0) S->draws = draws + 3;
+    }
+    __syncthreads();
+    for (uint32_t r = tid; r < n; r += kLkNT) G.city_ids[r] = tour[r];
+    rebuild();
+    if (tid == 0) S->key = 0xFFFFFFFFu;
+}
+
+// first lk_pass of solve(): city_ids = tour, next/prev/pos from tour, state reset
+__global__ __launch_bounds__(kLkNT) void k_lk_begin(LkArgs G)
+{
+    const uint32_t tid = threadIdx.x, n = G.n;
+    for (uint32_t r = tid; r < n; r += kLkNT) {
+        const uint32_t c = G.tour[r];
+        G.city_ids[r] = c;
+        G.best[r] = c;
+        G.pos[c] = r;
+        G.next[c] = G.tour[r + 1u == n ? 0u : r + 1u];
+        G.prev[c] = G.tour[r == 0u ? n - 1u : r - 1u];
+    }
+    if (tid == 0) {
+        LkState *S = G.state;
+        S->key = 0xFFFFFFFFu;
+        S->finished = n < 4 ? 1u : 0u;  // :57-59
+        S->stage = 0;
+        S->epoch = 0;
+        S->platoo = 0;
+        S->best_dist = 0.0f;
+        S->draws = 0;
+        S->scans = S->searches = S->moves = S->exchanged = 0;
+    }
+}
+
+hipError_t launch_lk_begin(const LkArgs &G, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_lk_begin, dim3(1), dim3(kLkNT), 0, s, G);
+    return hipGetLastError();
+}
+
+hipError_t launch_lk_round(const LkArgs &G, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_lk_scan, dim3((2u * G.n + 255u) / 256u), dim3(256), 0, s, G);
+    hipLaunchKernelGGL(k_lk_control, dim3(1), dim3(kLkNT), 0, s, G);
+    return hipGetLastError();
+}
+
+size_t lk_chain_slot_words() { return (size_t)kLkMaxChain + 2; }
+
 hipError_t launch_knn(const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, hipStream_t s)
 {
     const uint32_t grid = (n + 255u) / 256u;

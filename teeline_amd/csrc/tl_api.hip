@@ -717,7 +717,11 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const uint32_t *ini
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t arr = up((size_t)n * 4);
     const size_t o_cand = 0, o_tour = up((size_t)n * (k ? k : 1) * 4), o_alt = o_tour + arr, o_pos = o_alt + arr, o_next = o_pos + arr,
-                 o_prev = o_next + arr, o_ids = o_prev + arr, o_best = o_ids + arr, o_cnt = o_best + arr, total = o_cnt + 256;
+                 o_prev = o_next + arr, o_ids = o_prev + arr, o_best = o_ids + arr, o_cnt = o_best + arr, o_state = o_cnt + 256,
+                 o_chains = o_state + 256;
+    // n below this runs the whole ILS in one persistent workgroup; above it the scan is spread over all CUs
+    const bool multi_cu = n >= (getenv("TL_LK_MULTI_MIN_N") ? (uint32_t)atoi(getenv("TL_LK_MULTI_MIN_N")) : 1500u);
+    const size_t total = o_chains + (multi_cu ? up((size_t)2 * n * lk_chain_slot_words() * 4) : 0);
     if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->work, total)) || (rc = ensure(c, c->out_cost, 4))) return rc;
     unsigned char *w = (unsigned char *)c->work.p;
     HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
@@ -747,15 +751,32 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const uint32_t *ini
     G.max_depth = o.max_depth;
     G.epochs = o.epochs;
     G.platoo_epochs = o.platoo_epochs;
-    HIPCHK(c, launch_lk_solve(G, c->stream));
+    G.state = (LkState *)(w + o_state);
+    G.chains = (uint32_t *)(w + o_chains);
+    uint64_t cnt[4] = {0, 0, 0, 0};
+    if (!multi_cu) {
+        HIPCHK(c, launch_lk_solve(G, c->stream));
+    } else {
+        HIPCHK(c, launch_lk_begin(G, c->stream));
+        LkState hs{};
+        for (;;) {
+            for (int r = 0; r < 64; ++r) HIPCHK(c, launch_lk_round(G, c->stream));  // kernels no-op once finished
+            HIPCHK(c, hipMemcpyAsync(&hs, G.state, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (hs.finished) break;
+        }
+        cnt[0] = hs.scans;
+        cnt[1] = hs.searches;
+        cnt[2] = hs.moves;
+        cnt[3] = hs.exchanged;
+    }
     // lin_kernighan.rs:99 Solution::new -> total through tour_length (closing edge first)
     HIPCHK(c, launch_tour_length(G.xy, nullptr, n, G.best, (float *)c->out_cost.p, c->stream));
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->ev_valid = true;
-    uint64_t cnt[4] = {0, 0, 0, 0};
     float cost = 0.f;
     HIPCHK(c, hipMemcpyAsync(out_pos, G.best, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(cnt, G.counters, 32, hipMemcpyDeviceToHost, c->stream));
+    if (!multi_cu) HIPCHK(c, hipMemcpyAsync(cnt, G.counters, 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(&cost, c->out_cost.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (out_cost) *out_cost = cost;

@@ -76,6 +76,15 @@ size_t three_opt_scan_lds_bytes(uint32_t n);
 hipError_t launch_three_opt_pass(const ThreeOptArgs &A, uint32_t nblocks, bool dm, int apply, hipStream_t s);
 
 // lk.hip
+struct LkState {             // device-side state machine of the multi-CU LK variant
+    uint32_t key;            // min pair index with a valid chain in the current scan (0xFFFFFFFF: none)
+    uint32_t finished;
+    uint32_t stage;          // 0: initial lk_pass, 1: ILS epochs
+    uint32_t epoch, platoo;
+    float best_dist;
+    uint64_t draws;
+    uint64_t scans, searches, moves, exchanged;
+};
 struct LkArgs {
     const float2 *xy;
     const uint32_t *cand;   // [n][k] candidate lists, ascending distance
@@ -87,12 +96,17 @@ struct LkArgs {
     uint32_t *city_ids;     // [n] scan order snapshot of a pass
     uint32_t *best;         // [n] out: best tour
     uint64_t *counters;     // scans, searches, moves, exchanged edges
+    LkState *state;         // multi-CU variant
+    uint32_t *chains;       // multi-CU variant: [2n][kLkMaxChain + 2] chain slots
     uint64_t seed;
     uint32_t n, k, max_depth, epochs, platoo_epochs;
 };
 hipError_t launch_knn(const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, hipStream_t s);
 hipError_t launch_nn_seed(const float2 *xy, uint32_t n, const uint32_t *cand, uint32_t k, uint32_t *path, unsigned char *visited, hipStream_t s);
 hipError_t launch_lk_solve(const LkArgs &G, hipStream_t s);
+hipError_t launch_lk_begin(const LkArgs &G, hipStream_t s);
+hipError_t launch_lk_round(const LkArgs &G, hipStream_t s);
+size_t lk_chain_slot_words();
 
 // dm_build.hip
 hipError_t launch_dm_build(const float2 *xy, uint32_t n, int dist, int layout, float *out, hipStream_t s);

@@ -114,3 +114,21 @@ def test_lk_other_instances(ctx, case, tsplib_dir):
         for depth, k in ((1, 5), (2, 3), (3, 8), (6, 5)):
             assert_same(gpu_lk(ctx, xy, seed=1, epochs=20, max_depth=depth, n_nearest=k),
                         O.lin_kernighan(xy, seed=1, epochs=20, max_depth=depth, n_nearest=k))
+
+
+def test_lk_multi_cu_variant_is_identical(ctx, tsplib_dir, monkeypatch):
+    # n >= 1500 spreads the scan over all CUs (k_lk_scan + k_lk_control state machine); forcing it on small
+    # instances must reproduce the persistent-workgroup results, i.e. the oracle's, bit for bit
+    xy = T.parse_tsplib(os.path.join(tsplib_dir, "berlin52.tsp"))["xy"]
+    monkeypatch.setenv("TL_LK_MULTI_MIN_N", "0")
+    for seed in (1, 2):
+        assert_same(gpu_lk(ctx, xy, seed=seed), O.lin_kernighan(xy, seed=seed))
+    lat = lattice(10, 2)
+    assert_same(gpu_lk(ctx, lat, seed=11, epochs=40), O.lin_kernighan(lat, seed=11, epochs=40))
+    sq = np.array([[0, 0], [1, 1], [1, 0], [0, 1]], np.float32)
+    assert_same(gpu_lk(ctx, sq, init=[0, 1, 2, 3], max_depth=1, epochs=0), O.lin_kernighan(sq, init=[0, 1, 2, 3], epochs=0, max_depth=1))
+    tri = np.array([[0, 0], [1, 0], [0.5, 1]], np.float32)
+    assert gpu_lk(ctx, tri, init=[2, 0, 1])[0].tolist() == [2, 0, 1]
+    monkeypatch.delenv("TL_LK_MULTI_MIN_N")
+    xy = O.synth_xy(2000, seed=6)  # default dispatch: multi-CU
+    assert_same(gpu_lk(ctx, xy, seed=5, epochs=8), O.lin_kernighan(xy, seed=5, epochs=8))
