@@ -229,3 +229,49 @@ def test_best_sweep_full_size_is_a_2opt_local_optimum(ctx):
     rc, again, c2, st2 = O.two_opt(xy, None, n, init=route, max_candidates=1)
     assert st2["moves"] == 0 and c2 == cost
     assert cost == O.tour_length(xy, None, route)
+
+
+def test_config5_size_and_lds_limit(ctx):
+    # n = 13 509 (usa13509 size; the file is not in the reference tree -> synthetic points, labelled) from the NN seed
+    import teeline_amd as TA
+    n = 13509
+    xy = O.synth_xy(n)
+    rc, nn, _ = O.nearest_neighbor(xy, None, n, 3)
+    assert_same(gpu_two_opt(ctx, xy, None, n, nn), O.two_opt(xy, None, n, init=nn), n)
+    nmax = ctx.two_opt_lds_max_n()
+    assert 13509 <= nmax < 16384
+    big = O.synth_xy(nmax + 1, seed=2)
+    with pytest.raises(TA.TeelineGpuError) as e:
+        gpu_two_opt(ctx, big, None, nmax + 1)
+    assert e.value.code == -6  # TL_ERR_UNSUPPORTED, loudly — never a CPU fallback
+    # the largest supported size still works (one sweep is enough to exercise the last tile / group logic)
+    xym = big[:nmax]
+    rc, nnm, _ = O.nearest_neighbor(xym, None, nmax, 3)
+    route, cost, st = gpu_two_opt(ctx, xym, None, nmax, nnm)
+    rc, again, c2, st2 = O.two_opt(xym, None, nmax, init=route, max_candidates=1)
+    assert st2["moves"] == 0 and c2 == cost and O.validate_tour(route)
+
+
+def test_device_resident_batch_entry_with_explicit_starts(ctx):
+    # tl_two_opt_batch_dev with caller-provided device buffers (what bench.py uses), explicit initial tours
+    import ctypes as C
+    import torch
+    from teeline_amd import _capi
+    n, R = 500, 5
+    xy = O.synth_xy(n, seed=13)
+    inits = np.stack([O.restart_perm(n, 21, r) for r in range(R)]).astype(np.int32)
+    dev = torch.device("cuda", 0)
+    d_xy, d_init = torch.from_numpy(xy).to(dev), torch.from_numpy(inits).to(dev)
+    d_pos = torch.empty((R, n), dtype=torch.int32, device=dev)
+    d_cost = torch.empty(R, dtype=torch.float32, device=dev)
+    d_stats = torch.zeros((R, _capi.TL_DEV_STATS_STRIDE), dtype=torch.int64, device=dev)
+    s = torch.cuda.current_stream()
+    ctx.check(ctx.lib.tl_two_opt_batch_dev(ctx.handle, d_xy.data_ptr(), n, d_init.data_ptr(), 0, 0, R, 0, d_pos.data_ptr(),
+                                           d_cost.data_ptr(), d_stats.data_ptr(), C.c_void_p(s.cuda_stream)))
+    torch.cuda.synchronize()
+    assert ctx.last_kernel_ms() > 0
+    for r in range(R):
+        rc, p, c, st = O.two_opt(xy, None, n, init=inits[r].astype(np.uint32))
+        assert d_pos[r].cpu().numpy().astype(np.uint32).tolist() == p.tolist()
+        assert np.float32(d_cost[r].item()).tobytes() == np.float32(c).tobytes()
+        assert (int(d_stats[r, 0]), int(d_stats[r, 1]), int(d_stats[r, 2]), int(d_stats[r, 3])) == (st["sweeps"], st["moves"], st["reversed"], 0)
