@@ -113,6 +113,10 @@ __device__ __forceinline__ void scan_tile(const float2 *P, uint32_t n, uint32_t 
 }
 
 
+#ifndef TL_DENSE_LEAD
+#define TL_DENSE_LEAD 4
+#endif
+constexpr uint32_t kDenseLead = TL_DENSE_LEAD;  // waves active in round 1 of a dense step
 constexpr uint32_t kMaxChainHits = 16;  // hits one wave may chain inside its tile before handing back
 
 // Dense mode, one row (a, b) against one 64-wide j tile held in registers, decided inline (no queue).
@@ -133,8 +137,10 @@ __device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint
     const float s1 = dx * dx + dy * dy;
     const bool inrange = j + 2u <= n;
     const float dac_a = __builtin_amdgcn_sqrtf(s1), dce_a = __builtin_amdgcn_sqrtf(sqce);
-    uint32_t from = jmin, nh = 0;
+    const float smin0 = fminf(s1, sqce);
+    uint32_t from = jmin, nh = 0, hitv = 0;  // lane h of hitv holds the h-th hit column
     for (;;) {
+        // one straight-line pass per value of b: L1, L2 and the rare L3 for the lanes at or after `from`
         dx = ax - bx;
         dy = ay - by;
         const float sqab = dx * dx + dy * dy;
@@ -142,18 +148,16 @@ __device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint
         dy = by - e.y;
         const float s2 = dx * dx + dy * dy;
         bool test = inrange & (j >= from);
-        if (PRUNE) test = test & ((s1 < sqab) | (s2 < sqce));  // L1
-        if (!__builtin_amdgcn_ballot_w64(test)) break;
         bool imp;
         if (PRUNE) {
-            // L2: hardware sqrt decides unless the margin is within ~3x the accumulated error
-            const float neu_a = dac_a + __builtin_amdgcn_sqrtf(s2);
+            test = test & ((s1 < sqab) | (s2 < sqce));                       // L1
+            if (!__builtin_amdgcn_ballot_w64(test)) break;                   // the common case late in a sweep
+            const float neu_a = dac_a + __builtin_amdgcn_sqrtf(s2);          // L2
             const float cur_a = __builtin_amdgcn_sqrtf(sqab) + dce_a;
-            const float margin = cur_a * 1.9073486e-6f;  // 2^-19
-            const float smin = fminf(fminf(s1, s2), fminf(sqab, sqce));
+            const float margin = cur_a * 1.9073486e-6f;                      // 2^-19
             imp = test & (neu_a < cur_a - margin);
-            const bool tie = test & !imp & ((neu_a <= cur_a + margin) | (smin < 1e-30f) | !(cur_a < 3.0e38f));
-            if (__builtin_amdgcn_ballot_w64(tie)) {  // L3
+            const bool tie = test & !imp & ((neu_a <= cur_a + margin) | (fminf(smin0, fminf(s2, sqab)) < 1e-30f) | !(cur_a < 3.0e38f));
+            if (__builtin_amdgcn_ballot_w64(tie)) {                          // L3
                 const float neu = sqrt_rn(s1) + sqrt_rn(s2);
                 const float cur = sqrt_rn(sqab) + sqrt_rn(sqce);
                 imp = tie ? (neu < cur) : imp;
@@ -167,19 +171,20 @@ __device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint
         if (m == 0) break;
         const int l = __builtin_ffsll((long long)m) - 1;
         const uint32_t jh = tb + (uint32_t)l;
-        if (lane == 0) {
-            if (nh == 0) atomicMin(keyslot, (i << 16) | jh);
-            hl[2u + nh] = jh;
-        }
+        hitv = ((uint32_t)lane == nh) ? jh : hitv;
+        if (nh == 0 && lane == 0) atomicMin(keyslot, (i << 16) | jh);  // post at once: it stops the other waves' scans
         ++nh;
         bx = readlane_f(c.x, l);  // new p[i+1] = old p[j]
         by = readlane_f(c.y, l);
         from = jh + 1u;
         if (nh >= kMaxChainHits || l == 63) break;
     }
-    if (nh && lane == 0) {
-        hl[0] = nh;
-        hl[1] = (nh >= kMaxChainHits) ? from : (tb + 64u);  // tile exhausted unless the chain was cut short
+    if (nh) {
+        if ((uint32_t)lane < nh) hl[2u + (uint32_t)lane] = hitv;
+        if (lane == 0) {
+            hl[0] = nh;
+            hl[1] = (nh >= kMaxChainHits) ? from : (tb + 64u);  // tile exhausted unless the chain was cut short
+        }
     }
     return nh;
 }
@@ -347,17 +352,30 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             }
             TL_STAMP(0);
         } else {
-            // ---- dense mode: one row, every tile from the resume column on; tile t belongs to wave t % 16
-            const uint32_t i = i0;
+            // ---- dense mode: one row, every tile from the resume column on.
+            // Round 1: only kDenseLead waves look at the first tiles (one per SIMD), everybody else parks at the barrier —
+            // moves come every few candidates here, and a wave chaining hits runs ~3x faster when it does not share
+            // its SIMD's issue slots with three busy neighbours.  Round 2 (no hit yet): all waves take the rest of the row.
+            const uint32_t i = i0, t0 = j0 >> 6;
             const float ax = readlane_f(rp.x, 0), ay = readlane_f(rp.y, 0);
             const float bx = readlane_f(rp.x, 1), by = readlane_f(rp.y, 1);
-            for (uint32_t t = (j0 >> 6) + (((uint32_t)wave - (j0 >> 6)) & 15u); t <= last_tile; t += NW) {
-                const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot);
-                if (kb != kNoKey && (kb & 0xFFFFu) < (t << 6)) break;  // an earlier column already improves
+            if ((uint32_t)wave < kDenseLead && t0 + (uint32_t)wave <= last_tile) {
+                const uint32_t t = t0 + (uint32_t)wave;
 #ifdef TL_PROFILE
                 ++livetiles;
 #endif
-                if (dense_tile<PRUNE>(P, n, i, t << 6, j0, ax, ay, bx, by, q, keyslot, lane)) break;
+                dense_tile<PRUNE>(P, n, i, t << 6, j0, ax, ay, bx, by, queues + (t & 15u) * kQCap, keyslot, lane);
+            }
+            __syncthreads();
+            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot) == kNoKey) {
+                for (uint32_t t = t0 + kDenseLead + (uint32_t)wave; t <= last_tile; t += NW) {
+                    const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot);
+                    if (kb != kNoKey && (kb & 0xFFFFu) < (t << 6)) break;  // an earlier column already improves
+#ifdef TL_PROFILE
+                    ++livetiles;
+#endif
+                    if (dense_tile<PRUNE>(P, n, i, t << 6, j0, ax, ay, bx, by, queues + (t & 15u) * kQCap, keyslot, lane)) break;
+                }
             }
         }
         TL_STAMP(2);
