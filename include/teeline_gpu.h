@@ -141,6 +141,14 @@ int tl_three_opt_find_best_move(tl_ctx *ctx, const float *xy, uint32_t n, const 
 int tl_lk(tl_ctx *ctx, const float *xy, uint32_t n, const uint32_t *init_pos, const tl_lk_opts *opts,
           uint64_t seed, uint32_t *out_pos, float *out_cost, tl_stats *stats);
 
+/* ---- Or-opt: replaces or_opt::solve (or_opt.rs:18-74) — SURVEY.md §8(f) "next" row ------------ */
+/* Best-improvement relocation of 1/2/3-city segments (forward and, for 2/3, reversed), threshold -1e-3 (:86). */
+int tl_or_opt(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
+              uint32_t *out_pos, float *out_cost, tl_stats *stats);
+/* One find_best_move scan (or_opt.rs:80-164): (delta, seg_start i, insert_after j, seg_len, reversed). */
+int tl_or_opt_find_best_move(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *path,
+                             int *found, float *delta, uint32_t *i, uint32_t *j, uint32_t *seg_len, int *reversed);
+
 /* ---- LK candidate lists: replaces lin_kernighan::build_candidates (lin_kernighan.rs:12-27) -- */
 /* out: n x min(k, n-1) u32, ascending f32 distance, ties -> lowest position (the reference's kd-tree tie
  * order is implementation-defined, kdtree.rs:63). */

@@ -530,3 +530,92 @@ void tlo_restart_perm(uint32_t n, uint64_t seed, uint64_t r, uint32_t *perm)
         perm[j] = t;
     }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Or-opt (reference: src/tsp/or_opt.rs) — SURVEY.md §8(f) "next" row 3                        */
+/* ------------------------------------------------------------------------------------------ */
+
+/* or_opt.rs:170-184 apply_relocation: drain path[i..i+seg_len], reinsert after original index j */
+int tlo_apply_relocation(uint32_t *tour, uint32_t n, uint32_t i, uint32_t seg_len, uint32_t j, int reversed)
+{
+    if (seg_len == 0 || seg_len > 3 || i + seg_len > n || j >= n) return TLO_ERR_BADARG;
+    uint32_t seg[3];
+    for (uint32_t t = 0; t < seg_len; ++t) seg[t] = tour[i + t];
+    /* drain */
+    for (uint32_t t = i; t + seg_len < n; ++t) tour[t] = tour[t + seg_len];
+    uint32_t m = n - seg_len;
+    uint32_t insert_at = (j >= i + seg_len) ? (j - seg_len + 1) : (j + 1);
+    if (insert_at > m) return TLO_ERR_BADARG;
+    for (uint32_t t = m; t > insert_at; --t) tour[t - 1 + seg_len] = tour[t - 1];
+    for (uint32_t t = 0; t < seg_len; ++t) tour[insert_at + t] = reversed ? seg[seg_len - 1 - t] : seg[t];
+    return TLO_OK;
+}
+
+/* or_opt.rs:80-164 find_best_move: returns 1 and (delta, i, j, seg_len, reversed) or 0 */
+static int or_find_best_move(const dsrc *s, uint32_t n, const uint32_t *path, float *odelta, uint32_t *oi, uint32_t *oj,
+                             uint32_t *oseg, int *orev, uint64_t *evals)
+{
+    float best_delta = -1e-3f; /* :86 */
+    int have = 0;
+    uint64_t ev = 0;
+    for (uint32_t seg_len = 1; seg_len <= 3; ++seg_len) {
+        if (n <= seg_len + 1) continue; /* :90-92 */
+        for (uint32_t i = 0; i < n; ++i) {
+            if (i + seg_len > n) continue; /* :98-100 */
+            uint32_t prev = i == 0 ? n - 1 : i - 1;
+            uint32_t after_seg = (i + seg_len) % n;
+            uint32_t a = path[prev], first_seg = path[i], last_seg = path[i + seg_len - 1], d = path[after_seg];
+            float remove_gain = D(s, a, first_seg) + D(s, last_seg, d) - D(s, a, d); /* :114-116 */
+            for (uint32_t j = 0; j < n; ++j) {
+                if (j == prev || (j >= i && j < i + seg_len)) continue; /* :123-125 */
+                uint32_t x = path[j], y = path[(j + 1) % n];
+                float edge_xy = D(s, x, y);
+                float fwd_delta = -remove_gain + D(s, x, first_seg) + D(s, last_seg, y) - edge_xy; /* :136-139 */
+                ++ev;
+                if (fwd_delta < best_delta) { best_delta = fwd_delta; *oi = i; *oj = j; *oseg = seg_len; *orev = 0; have = 1; }
+                if (seg_len > 1) {
+                    float rev_delta = -remove_gain + D(s, x, last_seg) + D(s, first_seg, y) - edge_xy; /* :148-151 */
+                    ++ev;
+                    if (rev_delta < best_delta) { best_delta = rev_delta; *oi = i; *oj = j; *oseg = seg_len; *orev = 1; have = 1; }
+                }
+            }
+        }
+    }
+    if (odelta) *odelta = best_delta;
+    if (evals) *evals += ev;
+    return have;
+}
+
+int tlo_or_opt_find_best_move(const float *xy, const float *packed, uint32_t n, const uint32_t *path, float *delta,
+                              uint32_t *i, uint32_t *j, uint32_t *seg_len, int *reversed)
+{
+    dsrc s = {xy, packed};
+    if (n < 4) return 0;
+    return or_find_best_move(&s, n, path, delta, i, j, seg_len, reversed, NULL);
+}
+
+/* or_opt.rs:18-74 solve */
+int tlo_or_opt(const float *xy, const float *packed, uint32_t n, const uint32_t *init, uint32_t *out, float *out_cost,
+               tlo_stats *st, uint64_t max_moves)
+{
+    if ((!xy && !packed) || !out) return TLO_ERR_BADARG;
+    dsrc s = {xy, packed};
+    uint64_t passes = 0, evals = 0, moves = 0;
+    if (n < 4) { /* :31-34 */
+        for (uint32_t t = 0; t < n; ++t) out[t] = t;
+    } else {
+        for (uint32_t t = 0; t < n; ++t) out[t] = init ? init[t] : t;
+        for (;;) {
+            uint32_t i = 0, j = 0, seg = 0;
+            int rev = 0;
+            ++passes;
+            if (!or_find_best_move(&s, n, out, NULL, &i, &j, &seg, &rev, &evals)) break;
+            tlo_apply_relocation(out, n, i, seg, j, rev);
+            ++moves;
+            if (max_moves && moves >= max_moves) break;
+        }
+    }
+    if (st) { st->sweeps = passes; st->candidates = evals; st->moves = moves; st->reversed = 0; }
+    if (out_cost) *out_cost = tlo_tour_length(xy, packed, n, out);
+    return TLO_OK;
+}

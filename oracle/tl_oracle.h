@@ -106,6 +106,16 @@ void tlo_synth_xy(uint32_t n, uint64_t seed, float *xy);
 /* Fisher–Yates `for i in (1..n).rev(): j = rng(0..=i); swap` from splitmix64(seed + r). */
 void tlo_restart_perm(uint32_t n, uint64_t seed, uint64_t r, uint32_t *perm);
 
+/* ---- Or-opt (or_opt.rs) ---- */
+/* or_opt.rs:170-184 */
+int tlo_apply_relocation(uint32_t *tour, uint32_t n, uint32_t i, uint32_t seg_len, uint32_t j, int reversed);
+/* or_opt.rs:80-164; returns 1 if an improving relocation (delta < -1e-3) exists */
+int tlo_or_opt_find_best_move(const float *xy, const float *packed, uint32_t n, const uint32_t *path, float *delta,
+                              uint32_t *i, uint32_t *j, uint32_t *seg_len, int *reversed);
+/* or_opt.rs:18-74 */
+int tlo_or_opt(const float *xy, const float *packed, uint32_t n, const uint32_t *init, uint32_t *out_perm,
+               float *out_cost, tlo_stats *stats, uint64_t max_moves);
+
 /* ---- Lin–Kernighan (lin_kernighan.rs) ---- */
 /* lin_kernighan.rs:12-27 via brute force; k' = min(k, n-1) ids per city, ascending distance,
  * ties -> lowest position (reference: kd-tree traversal order, implementation-defined). */

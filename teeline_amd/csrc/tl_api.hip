@@ -643,6 +643,143 @@ extern "C" int tl_three_opt(tl_ctx *c, const float *xy, uint32_t n, const float 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Or-opt (or_opt.rs)
+// ------------------------------------------------------------------------------------------------
+static int or_opt_setup(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *path, OrOptArgs &A, bool &dm)
+{
+    if ((uint64_t)3 * n * n * 2 > 0xFFFFFFFFull)
+        return fail(c, TL_ERR_UNSUPPORTED, "or_opt: n=%u too large for the packed loop-order key (n <= 26754)", n);
+    if ((size_t)n * 4 > (size_t)c->lds_bytes - 1024) return fail(c, TL_ERR_UNSUPPORTED, "or_opt: n=%u exceeds the LDS staging limit", n);
+    int rc;
+    dm = dm_packed != nullptr;
+    if (dm) {
+        const size_t b = (size_t)n * (n - 1) / 2 * 4;
+        if ((rc = ensure(c, c->dm, b))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->dm.p, dm_packed, b, hipMemcpyHostToDevice, c->stream));
+    } else {
+        if ((rc = ensure(c, c->xy, (size_t)n * 8))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const uint32_t nblocks = or_opt_scan_blocks(n);
+    const size_t o_perm = 0, o_pt = up((size_t)n * 4), o_e = up(o_pt + (size_t)n * 8), o_par = up(o_e + (size_t)n * 4),
+                 o_best = up(o_par + (size_t)nblocks * 8), total = o_best + 256;
+    if ((rc = ensure(c, c->work, total))) return rc;
+    unsigned char *w = (unsigned char *)c->work.p;
+    std::vector<uint32_t> ident;
+    if (!path) {
+        ident.resize(n);
+        for (uint32_t i = 0; i < n; ++i) ident[i] = i;
+        path = ident.data();
+    }
+    HIPCHK(c, hipMemcpyAsync(w + o_perm, path, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    A.xy = (const float2 *)c->xy.p;
+    A.dm = dm ? (const float *)c->dm.p : nullptr;
+    A.perm = (uint32_t *)(w + o_perm);
+    A.Pt = (float2 *)(w + o_pt);
+    A.E = (float *)(w + o_e);
+    A.partials = (unsigned long long *)(w + o_par);
+    A.best = (OrOptBest *)(w + o_best);
+    A.n = n;
+    return TL_OK;
+}
+
+extern "C" int tl_or_opt_find_best_move(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *path,
+                                        int *found, float *delta, uint32_t *oi, uint32_t *oj, uint32_t *seg_len, int *reversed)
+{
+    if (!c || (!xy && !dm_packed) || !path || !found) return fail(c, TL_ERR_BADARG, "tl_or_opt_find_best_move: NULL argument");
+    *found = 0;
+    if (n < 4) return TL_OK;
+    if (!is_permutation(path, n)) return fail(c, TL_ERR_BADARG, "tl_or_opt_find_best_move: path is not a permutation of 0..n-1");
+    HIPCHK(c, hipSetDevice(c->device));
+    OrOptArgs A{};
+    bool dm;
+    int rc;
+    if ((rc = or_opt_setup(c, xy, n, dm_packed, path, A, dm))) return rc;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    HIPCHK(c, launch_or_opt_pass(A, dm, 0, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    c->ev_valid = true;
+    OrOptBest b{};
+    HIPCHK(c, hipMemcpyAsync(&b, A.best, sizeof(b), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (b.found) {
+        *found = 1;
+        if (delta) memcpy(delta, &b.delta_bits, 4);
+        if (oi) *oi = b.i;
+        if (oj) *oj = b.j;
+        if (seg_len) *seg_len = b.seg_len;
+        if (reversed) *reversed = (int)b.reversed;
+    }
+    return TL_OK;
+}
+
+extern "C" int tl_or_opt(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
+                         uint32_t *out_pos, float *out_cost, tl_stats *stats)
+{
+    if (!c || (!xy && !dm_packed) || !out_pos) return fail(c, TL_ERR_BADARG, "tl_or_opt: NULL argument");
+    const auto t0 = std::chrono::steady_clock::now();
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (n < 4) {  // or_opt.rs:31-34: returns the cities order
+        for (uint32_t i = 0; i < n; ++i) out_pos[i] = i;
+        if (out_cost) {
+            if (n < 2) *out_cost = 0.0f;
+            else {
+                int rc = tl_tour_length(c, xy, dm_packed, n, out_pos, out_cost);
+                if (rc) return rc;
+            }
+        }
+        return TL_OK;
+    }
+    if (init_pos && !is_permutation(init_pos, n)) return fail(c, TL_ERR_BADARG, "tl_or_opt: init tour is not a permutation of 0..n-1");
+    HIPCHK(c, hipSetDevice(c->device));
+    OrOptArgs A{};
+    bool dm;
+    int rc;
+    if ((rc = or_opt_setup(c, xy, n, dm_packed, init_pos, A, dm))) return rc;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    uint64_t passes = 0, moves = 0;
+    const uint64_t cap = 64ull * n + 1024;
+    for (;;) {  // or_opt.rs:45 while let Some(best) = find_best_move(..)
+        HIPCHK(c, launch_or_opt_pass(A, dm, 1, c->stream));
+        OrOptBest b{};
+        HIPCHK(c, hipMemcpyAsync(&b, A.best, sizeof(b), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        ++passes;
+        if (!b.found) break;
+        ++moves;
+        if (passes > cap) return fail(c, TL_ERR_NO_CONVERGE, "or_opt: pass cap reached");
+    }
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    c->ev_valid = true;
+    HIPCHK(c, hipMemcpyAsync(out_pos, A.perm, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (out_cost) {
+        if ((rc = ensure(c, c->out_cost, 4))) return rc;
+        HIPCHK(c, launch_tour_length(dm ? nullptr : A.xy, A.dm, n, A.perm, (float *)c->out_cost.p, c->stream));
+        HIPCHK(c, hipMemcpyAsync(out_cost, c->out_cost.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (stats) {
+        stats->sweeps = passes;
+        stats->moves = moves;
+        // deltas evaluated per pass: seg_len 1: n(n-2) forward; seg_len 2: (n-1)(n-3) x 2; seg_len 3: (n-2)(n-4) x 2
+        const uint64_t nn = n;
+        uint64_t per = 0;
+        if (nn > 2) per += nn * (nn - 2);
+        if (nn > 3) per += 2 * (nn - 1) * (nn - 3);
+        if (nn > 4) per += 2 * (nn - 2) * (nn - 4);
+        stats->candidates = passes * per;
+        double kms = 0;
+        tl_last_kernel_ms(c, &kms);
+        stats->kernel_ms = kms;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return TL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // candidate lists, NN seed, Lin-Kernighan
 // ------------------------------------------------------------------------------------------------
 extern "C" int tl_build_candidates(tl_ctx *c, const float *xy, uint32_t n, uint32_t k, uint32_t *out)

@@ -75,6 +75,23 @@ struct ThreeOptArgs {
 size_t three_opt_scan_lds_bytes(uint32_t n);
 hipError_t launch_three_opt_pass(const ThreeOptArgs &A, uint32_t nblocks, bool dm, int apply, hipStream_t s);
 
+// or_opt.hip
+struct OrOptBest {
+    uint32_t found, delta_bits, i, j, seg_len, reversed;
+};
+struct OrOptArgs {
+    const float2 *xy;
+    const float *dm;               // packed matrix or nullptr
+    uint32_t *perm;                // [n] tour positions, updated in place by k_or_pick
+    float2 *Pt;                    // [n] tour-ordered coordinates
+    float *E;                      // [n] tour-edge lengths, E[n-1] = closing edge
+    unsigned long long *partials;  // one packed key per scan workgroup
+    OrOptBest *best;
+    uint32_t n;
+};
+hipError_t launch_or_opt_pass(const OrOptArgs &A, bool dm, int apply, hipStream_t s);
+uint32_t or_opt_scan_blocks(uint32_t n);
+
 // lk.hip
 struct LkState {             // device-side state machine of the multi-CU LK variant
     uint32_t key;            // min pair index with a valid chain in the current scan (0xFFFFFFFF: none)

@@ -7,7 +7,7 @@
 //   src/tsp/mod.rs:1731-1814         TspProblem, Solution
 //   src/tsp/mod.rs:596-613,1249-1267 HeuristicOptions, LKOptions
 //   src/tsp/tsplib.rs:101-255        tsplib::read_from_file
-//   src/tsp/{two_opt,three_opt,lin_kernighan,nearest_neighbor}.rs  solve(problem, opts, progress, init_tour)
+//   src/tsp/{two_opt,three_opt,or_opt,lin_kernighan,nearest_neighbor}.rs  solve(problem, opts, progress, init_tour)
 //   src/tsp/pipeline.rs:53-80        run_pipeline_stages (warm start + validate_tour)
 // Same names, argument meaning and error behaviour: dispatcher-level failures throw std::runtime_error (the
 // reference returns Err(String), mod.rs:1661), inputs on which the reference panics throw teeline::ReferencePanic.
@@ -218,6 +218,21 @@ inline Solution solve(Context &ctx, const TspProblem &problem, const HeuristicOp
     return detail::finish(problem, out, cost, st, progress_tx);
 }
 }  // namespace three_opt
+
+namespace or_opt {  // or_opt.rs:18-74
+inline Solution solve(Context &ctx, const TspProblem &problem, const HeuristicOptions &, const ProgressFn *progress_tx,
+                      const std::vector<size_t> *init_tour)
+{
+    const auto xy = problem.xy();
+    const uint32_t n = (uint32_t)problem.cities.size();
+    std::vector<uint32_t> init, out(n);
+    if (init_tour) init = problem.positions_of(*init_tour);
+    float cost = 0.f;
+    tl_stats st{};
+    ctx.check(tl_or_opt(ctx.get(), xy.data(), n, problem.explicit_packed(), init_tour ? init.data() : nullptr, out.data(), &cost, &st));
+    return detail::finish(problem, out, cost, st, progress_tx);
+}
+}  // namespace or_opt
 
 namespace nearest_neighbor {  // nearest_neighbor.rs:8-76
 inline Solution solve(Context &ctx, const TspProblem &problem, const HeuristicOptions &opts, const ProgressFn *progress_tx,

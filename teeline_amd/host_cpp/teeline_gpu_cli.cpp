@@ -2,7 +2,7 @@
 // `teeline pipeline --steps=nn,2opt -i file` of teeline-cli (teeline-cli/src/main.rs:371-530) for the solvers
 // this build accelerates.  Output format = print_solution (main.rs:645-652): "{:.5} {0|1}\n<ids…>\n".
 //
-//   teeline-gpu solve 2opt|3opt|lk|nn [-i file] [--no-seed] [--best-sweep] [--seed S] [--epochs E] [--platoo-epochs P]
+//   teeline-gpu solve 2opt|3opt|oropt|lk|nn [-i file] [--no-seed] [--best-sweep] [--seed S] [--epochs E] [--platoo-epochs P]
 //                                     [--n-nearest K] [--max-depth D] [--device N] [--stats]
 // Like the reference, 2opt/3opt/lk are auto-seeded with a nearest-neighbour stage (mod.rs:129-139) unless --no-seed.
 #include "teeline_gpu.hpp"
@@ -18,7 +18,7 @@ int main(int argc, char **argv)
 {
     try {
         if (argc < 3 || (std::string(argv[1]) != "solve")) {
-            std::fprintf(stderr, "usage: teeline-gpu solve 2opt|3opt|lk|nn -i file.tsp [--no-seed] [--best-sweep] [--seed S] [--stats]\n");
+            std::fprintf(stderr, "usage: teeline-gpu solve 2opt|3opt|oropt|lk|nn -i file.tsp [--no-seed] [--best-sweep] [--seed S] [--stats]\n");
             return 2;
         }
         const std::string solver = argv[2];
@@ -65,9 +65,10 @@ int main(int argc, char **argv)
         Solution sol;
         if (solver == "2opt") sol = two_opt::solve(ctx, problem, h, nullptr, init, best ? TL_MODE_BEST_SWEEP : TL_MODE_REF_ORDER);
         else if (solver == "3opt") sol = three_opt::solve(ctx, problem, h, nullptr, init);
+        else if (solver == "oropt" || solver == "or_opt") sol = or_opt::solve(ctx, problem, h, nullptr, init);
         else if (solver == "lk") sol = lin_kernighan::solve(ctx, problem, lk, nullptr, init, seed);
         else if (solver == "nn") sol = nearest_neighbor::solve(ctx, problem, h, nullptr, nullptr);
-        else throw std::runtime_error("unknown solver `" + solver + "` (this build accelerates 2opt, 3opt, lk, nn)");
+        else throw std::runtime_error("unknown solver `" + solver + "` (this build accelerates 2opt, 3opt, oropt, lk, nn)");
         if (!validate_tour(sol.route(), problem.cities)) throw std::runtime_error("pipeline: solver produced an invalid tour");  // pipeline.rs:70-71
         std::printf("%.5f %d\n", sol.total, 0);
         for (size_t k = 0; k < sol.route().size(); ++k) std::printf(k ? " %zu" : "%zu", sol.route()[k]);

@@ -144,6 +144,37 @@ def three_opt(xy, packed, n, init=None, max_moves=0):
     return rc, out, np.float32(cost.value), st.as_dict()
 
 
+def apply_relocation(tour, i, seg_len, j, reversed):
+    tour = np.ascontiguousarray(tour, dtype=np.uint32).copy()
+    rc = lib().tlo_apply_relocation(_p(tour), C.c_uint32(len(tour)), C.c_uint32(i), C.c_uint32(seg_len), C.c_uint32(j),
+                                    C.c_int(int(reversed)))
+    return rc, tour
+
+
+def or_opt_find_best_move(xy, packed, path):
+    xy = _xy(xy)
+    path = np.ascontiguousarray(path, dtype=np.uint32)
+    d = C.c_float()
+    i, j, seg = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    rev = C.c_int()
+    found = lib().tlo_or_opt_find_best_move(_p(xy), _p(packed), C.c_uint32(len(path)), _p(path), C.byref(d), C.byref(i),
+                                            C.byref(j), C.byref(seg), C.byref(rev))
+    if not found:
+        return None
+    return (np.float32(d.value), i.value, j.value, seg.value, bool(rev.value))
+
+
+def or_opt(xy, packed, n, init=None, max_moves=0):
+    xy = _xy(xy)
+    init = _perm(init, n)
+    out = np.empty(n, dtype=np.uint32)
+    cost = C.c_float()
+    st = Stats()
+    rc = lib().tlo_or_opt(_p(xy), _p(packed), C.c_uint32(n), _p(init), _p(out), C.byref(cost), C.byref(st),
+                          C.c_uint64(max_moves))
+    return rc, out, np.float32(cost.value), st.as_dict()
+
+
 def nearest_neighbor(xy, packed, n, n_nearest=3):
     xy = _xy(xy)
     out = np.empty(n, dtype=np.uint32)

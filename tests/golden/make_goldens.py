@@ -38,6 +38,11 @@ def main():
         entry["nn_two_opt"] = {"cost": f5(c), "stats": st, "route_ids": ids[p].tolist()}
         rc, p, c, st = O.two_opt(xy, None, n)
         entry["identity_two_opt"] = {"cost": f5(c), "stats": st, "route_ids": ids[p].tolist()}
+        if n <= 300:
+            rc, p, c, st = O.or_opt(xy, None, n, init=nn)
+            entry["nn_or_opt"] = {"cost": f5(c), "stats": st, "route_ids": ids[p].tolist()}
+            rc, p, c, st = O.or_opt(xy, None, n)
+            entry["identity_or_opt"] = {"cost": f5(c), "stats": st, "route_ids": ids[p].tolist()}
         if n <= 60:
             rc, p, c, st = O.three_opt(xy, None, n, init=nn)
             entry["nn_three_opt"] = {"cost": f5(c), "stats": st, "route_ids": ids[p].tolist()}
@@ -54,6 +59,8 @@ def main():
         e = {"n": n, "identity_two_opt": {"cost": f5(c), "stats": st, "route_pos": p.tolist()}}
         rc, p, c, st = O.three_opt(None, packed, n)
         e["identity_three_opt"] = {"cost": f5(c), "stats": st, "route_pos": p.tolist()}
+        rc, p, c, st = O.or_opt(None, packed, n)
+        e["identity_or_opt"] = {"cost": f5(c), "stats": st, "route_pos": p.tolist()}
         out[name] = e
     d = T.parse_tsplib(os.path.join(HERE, "tsplib", "burma14.tsp"))
     packed = O.dm_build_packed(d["xy"], geo=True)

@@ -40,6 +40,8 @@ def test_cli_berlin52_matches_reference_numbers(cli, tsplib_dir, goldens):
     assert cost == "9368.31836" and route == g["identity_two_opt"]["route_ids"]
     cost, flag, route = run(cli, "solve", "3opt", "-i", f)                       # docs/benchmarks.md:29 (7742.65)
     assert cost == "7742.64697" and route == g["nn_three_opt"]["route_ids"]
+    cost, flag, route = run(cli, "solve", "oropt", "-i", f)                      # docs/benchmarks.md:48 (8 097.48)
+    assert cost == "8097.47607" and route == g["nn_or_opt"]["route_ids"]
     cost, flag, route = run(cli, "solve", "lk", "-i", f, "--seed", "1")          # bench/baseline-solvers.tsv:17-21
     assert cost == "7544.36572" and sorted(route) == list(range(1, 53))
 
