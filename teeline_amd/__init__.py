@@ -11,7 +11,8 @@ from . import _capi
 from ._capi import (TL_FLAG_NONE, TL_FLAG_NO_PRUNE, TL_MODE_BEST_SWEEP, TL_MODE_REF_ORDER,
                     ReferencePanics, TeelineGpuError)
 from .host import (Context, HeuristicOptions, KDPoint, LKOptions, Solution, TspProblem, default_context,
-                   distance_matrix, lin_kernighan, multistart, nearest_neighbor, or_opt, synth, three_opt, tsplib, two_opt,
+                   distance_matrix, lin_kernighan, multistart, nearest_neighbor, or_opt, pipeline, synth, three_opt, tsplib,
+                   two_opt,
                    validate_tour)
 
 __all__ = [

@@ -57,3 +57,16 @@ def test_cli_explicit_and_errors(cli, tsplib_dir, goldens):
     tiny = "NAME: t\nTYPE: TSP\nDIMENSION: 2\nEDGE_WEIGHT_TYPE: EUC_2D\nNODE_COORD_SECTION\n1 0 0\n2 1 1\nEOF\n"
     r = subprocess.run([cli, "solve", "2opt", "--no-seed"], input=tiny, capture_output=True, text=True)
     assert r.returncode == 101 and "panicked" in r.stderr  # the reference panics on n < 3 (two_opt.rs:17,29)
+
+
+def test_python_pipeline_facade(tsplib_dir, goldens):
+    # pipeline.rs:170-187 (nn -> 2opt never worse than nn) and the `fast` preset numbers (README.md:385)
+    import teeline_amd as TA
+    prob = TA.tsplib.read_from_file(os.path.join(tsplib_dir, "berlin52.tsp")).problem()
+    out = TA.pipeline.run_pipeline_stages(prob, ["nn", "2opt", "oropt"])
+    assert [o.name for o in out] == ["nn", "2opt", "oropt"]
+    assert f"{float(out[0].solution.total):.5f}" == "8980.91797" and f"{float(out[1].solution.total):.5f}" == "8384.18848"
+    assert out[1].solution.total <= out[0].solution.total * 1.001 and out[2].solution.total <= out[1].solution.total
+    assert all(TA.validate_tour(o.solution.route(), prob) and o.duration_ms >= 0 for o in out)
+    with pytest.raises(ValueError):
+        TA.pipeline.run_pipeline_stages(prob, ["sa"])
