@@ -38,7 +38,7 @@ constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 #define TL_RMAX 32
 #endif
 #ifndef TL_DENSE_ROWS
-#define TL_DENSE_ROWS 8.0f
+#define TL_DENSE_ROWS 12.0f
 #endif
 constexpr int kRMax = TL_RMAX;        // rows per speculative block in pruned mode (<= 63: lane-resident row table)
 constexpr uint32_t kQCap = 128;       // per-wave survivor queue entries (power of two, >= 2 * 64)
@@ -158,8 +158,12 @@ __device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint
             imp = test & (neu_a < cur_a - margin);
             const bool tie = test & !imp & ((neu_a <= cur_a + margin) | (fminf(smin0, fminf(s2, sqab)) < 1e-30f) | !(cur_a < 3.0e38f));
             if (__builtin_amdgcn_ballot_w64(tie)) {                          // L3
-                const float neu = sqrt_rn(s1) + sqrt_rn(s2);
-                const float cur = sqrt_rn(sqab) + sqrt_rn(sqce);
+                // the opaque copies keep the compiler from hoisting the loop-invariant exact sqrt of s1 / sqce into
+                // the tile prologue, where every tile would pay ~40 VALU for a path that almost never runs
+                float s1v = s1, scev = sqce;
+                asm volatile("" : "+v"(s1v), "+v"(scev));
+                const float neu = sqrt_rn(s1v) + sqrt_rn(s2);
+                const float cur = sqrt_rn(sqab) + sqrt_rn(scev);
                 imp = tie ? (neu < cur) : imp;
             }
         } else {
