@@ -41,7 +41,7 @@ constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 #define TL_DENSE_ROWS 12.0f
 #endif
 constexpr int kRMax = TL_RMAX;        // rows per speculative block in pruned mode (<= 63: lane-resident row table)
-constexpr uint32_t kQCap = 128;       // per-wave survivor queue entries (power of two, >= 2 * 64)
+constexpr uint32_t kQCap = 128;       // u32 words per tile slot of the chained-hit lists (also the cost-sum scratch)
 constexpr int kMaxGroups = 4;         // 64-tile groups: n_pad <= 4 * 64 * 64 = 16384
 
 #ifdef TL_PROFILE
@@ -54,78 +54,19 @@ struct Ctl {
     uint32_t keys[4];
 };
 
-// L2 + L3 for up to 64 queued survivors of L1, one per lane.
-__device__ __forceinline__ void flush_survivors(const float2 *P, const uint32_t *q, uint32_t head,
-                                                uint32_t count, uint32_t *keyslot, int lane)
-{
-    const bool act = (uint32_t)lane < count;
-    const uint32_t key = act ? q[(head + (uint32_t)lane) & (kQCap - 1u)] : 0u;
-    const uint32_t i = key >> 16, j = key & 0xFFFFu;
-    const float2 a = P[i], b = P[i + 1u], c = P[j], e = P[j + 1u];
-    const float s1 = sqdist(a, c), s2 = sqdist(b, e), sab = sqdist(a, b), sce = sqdist(c, e);
-    const float neu_a = __builtin_amdgcn_sqrtf(s1) + __builtin_amdgcn_sqrtf(s2);
-    const float cur_a = __builtin_amdgcn_sqrtf(sab) + __builtin_amdgcn_sqrtf(sce);
-    const float margin = cur_a * 1.9073486e-6f;  // 2^-19
-    const float smin = fminf(fminf(s1, s2), fminf(sab, sce));
-    bool imp = act & (neu_a < cur_a - margin);
-    const bool tie = act & !imp & ((neu_a <= cur_a + margin) | (smin < 1e-30f) | !(cur_a < 3.0e38f));
-    if (__builtin_amdgcn_ballot_w64(tie)) {
-        const float neu = sqrt_rn(s1) + sqrt_rn(s2);
-        const float cur = sqrt_rn(sab) + sqrt_rn(sce);
-        imp = act & (tie ? (neu < cur) : imp);  // two_opt.rs:35-49
-    }
-    if (imp) atomicMin(keyslot, key);
-}
-
-// L1 (or, for !PRUNE, L3 inline) for one row (a,b) against one 64-wide j tile.
-template <bool PRUNE>
-__device__ __forceinline__ void scan_tile(const float2 *P, uint32_t n, uint32_t i, uint32_t tb, uint32_t jmin,
-                                          float ax, float ay, float bx, float by, float sqab, uint32_t *q,
-                                          uint32_t &head, uint32_t &tail, uint32_t *keyslot, int lane)
-{
-    const uint32_t j = tb + (uint32_t)lane;
-    const float2 c = P[j], e = P[j + 1u];
-    const float sqce = sqdist(c, e);
-    float dx = ax - c.x, dy = ay - c.y;
-    const float s1 = dx * dx + dy * dy;
-    dx = bx - e.x;
-    dy = by - e.y;
-    const float s2 = dx * dx + dy * dy;
-    bool test = (j >= jmin) & (j + 2u <= n);
-    if (PRUNE) test = test & ((s1 < sqab) | (s2 < sqce));
-    const uint64_t m = __builtin_amdgcn_ballot_w64(test);
-    if (m == 0) return;
-    const uint32_t key = (i << 16) | j;
-    if (PRUNE) {
-        const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (test) q[(tail + off) & (kQCap - 1u)] = key;
-        tail += (uint32_t)__builtin_popcountll(m);
-        if (tail - head >= 64u) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            flush_survivors(P, q, head, 64u, keyslot, lane);
-            head += 64u;
-        }
-    } else {
-        const float neu = sqrt_rn(s1) + sqrt_rn(s2);
-        const float cur = sqrt_rn(sqab) + sqrt_rn(sqce);
-        if (test & (neu < cur)) atomicMin(keyslot, key);  // two_opt.rs:35-49
-    }
-}
-
-
 #ifndef TL_DENSE_LEAD
 #define TL_DENSE_LEAD 4
 #endif
 constexpr uint32_t kDenseLead = TL_DENSE_LEAD;  // waves active in round 1 of a dense step
 constexpr uint32_t kMaxChainHits = 16;  // hits one wave may chain inside its tile before handing back
 
-// Dense mode, one row (a, b) against one 64-wide j tile held in registers, decided inline (no queue).
+// One row (a, b) against one 64-wide j tile held in registers, decided inline by the L1 -> L2 -> L3 cascade.
 // All improving moves of the reference's scan INSIDE this tile are chained here without leaving the wave:
 // after a hit at lane l the row's b becomes the old P[j] (two_opt.rs:50 reverses p[i+1..=j], so p[i+1] := p[j]),
 // positions > j are untouched, hence lanes > l are simply re-decided against the new b.  Hits are recorded in
 // `hl` (hl[0] = count, hl[1] = column at which the scan resumes, hl[2..] = hit columns); the first one is posted
 // to the key slot.  Only the list of the wave that owns the globally first hit is used afterwards.
-template <bool PRUNE>
+template <bool PRUNE, bool CHAIN>
 __device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint32_t i, uint32_t tb, uint32_t jmin,
                                                float ax, float ay, float bx, float by, uint32_t *hl,
                                                uint32_t *keyslot, int lane)
@@ -136,7 +77,13 @@ __device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint
     float dx = ax - c.x, dy = ay - c.y;
     const float s1 = dx * dx + dy * dy;
     const bool inrange = j + 2u <= n;
-    const float dac_a = __builtin_amdgcn_sqrtf(s1), dce_a = __builtin_amdgcn_sqrtf(sqce);
+    // chain mode re-enters the loop body per hit, so the b-independent L2 terms are taken once up front; the
+    // single-shot (pruned) mode rarely gets past L1 and computes them only then
+    float dac_a = 0.f, dce_a = 0.f;
+    if (CHAIN) {
+        dac_a = __builtin_amdgcn_sqrtf(s1);
+        dce_a = __builtin_amdgcn_sqrtf(sqce);
+    }
     const float smin0 = fminf(s1, sqce);
     uint32_t from = jmin, nh = 0, hitv = 0;  // lane h of hitv holds the h-th hit column
     for (;;) {
@@ -152,6 +99,10 @@ __device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint
         if (PRUNE) {
             test = test & ((s1 < sqab) | (s2 < sqce));                       // L1
             if (!__builtin_amdgcn_ballot_w64(test)) break;                   // the common case late in a sweep
+            if (!CHAIN) {
+                dac_a = __builtin_amdgcn_sqrtf(s1);
+                dce_a = __builtin_amdgcn_sqrtf(sqce);
+            }
             const float neu_a = dac_a + __builtin_amdgcn_sqrtf(s2);          // L2
             const float cur_a = __builtin_amdgcn_sqrtf(sqab) + dce_a;
             const float margin = cur_a * 1.9073486e-6f;                      // 2^-19
@@ -178,6 +129,7 @@ __device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint
         hitv = ((uint32_t)lane == nh) ? jh : hitv;
         if (nh == 0 && lane == 0) atomicMin(keyslot, (i << 16) | jh);  // post at once: it stops the other waves' scans
         ++nh;
+        if (!CHAIN) return nh;  // pruned mode: the first improving column of this (row, tile) is all that is needed
         bx = readlane_f(c.x, l);  // new p[i+1] = old p[j]
         by = readlane_f(c.y, l);
         from = jh + 1u;
@@ -210,7 +162,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     float4 *tbox = reinterpret_cast<float4 *>(tailp);                        // kMaxGroups*64 entries
     float *tmsq = reinterpret_cast<float *>(tailp + kMaxGroups * 64 * 16);     // kMaxGroups*64
     Ctl *ctl = reinterpret_cast<Ctl *>(tailp + kMaxGroups * 64 * 20);
-    // survivor queues (NW x kQCap u32) during the descent; reused as NT floats for the cost sum
+    // chained-hit lists (one kQCap-word slot per tile index mod 16) during the descent; reused as NT floats for the cost sum
     uint32_t *queues = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(ctl) + 64);
     float *scratch = reinterpret_cast<float *>(queues);
 
@@ -265,7 +217,6 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     uint32_t sweeps = 1, step = 0, status = 0;
     uint64_t moves = 0, reversed = 0;
     float gap_est = 0.0f, since = 0.0f;
-    uint32_t *q = queues + (uint32_t)wave * kQCap;
     uint32_t dirty_lo = 0xFFFFFFFFu, dirty_hi = 0;               // tiles whose L0 metadata is stale
 #ifdef TL_PROFILE
     uint64_t prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -300,7 +251,6 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         const float2 rq = P[i0 + (uint32_t)lane + 1u];
         const float rowsq = sqdist(rp, rq);
 
-        uint32_t qhead = 0, qtail = 0;
         if (pruned) {
             // L0 metadata is rebuilt lazily: only tiles touched by reversals since the last pruned step
             if (dirty_lo <= dirty_hi) {
@@ -332,6 +282,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 const float sqab = readlane_f(rowsq, r);
                 const uint32_t jmin = (r == 0) ? j0 : (i + 2u);
                 const uint32_t tmin = jmin >> 6;
+                bool row_hit = false;
 #pragma unroll
                 for (int gI = 0; gI < kMaxGroups; ++gI) {
                     if (gI < G) {
@@ -344,15 +295,15 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #ifdef TL_PROFILE
                             ++livetiles;
 #endif
-                            scan_tile<PRUNE>(P, n, i, t << 6, jmin, ax, ay, bx, by, sqab, q, qhead, qtail, keyslot, lane);
+                            if (dense_tile<PRUNE, false>(P, n, i, t << 6, jmin, ax, ay, bx, by, nullptr, keyslot, lane)) {
+                                m = 0;  // later tiles of this row are later columns
+                                row_hit = true;
+                            }
                         }
                     }
+                    if (row_hit) break;
                 }
-                if (qtail != qhead) {  // decide this row's survivors before looking at a later row
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    flush_survivors(P, q, qhead, qtail - qhead, keyslot, lane);
-                    qhead = qtail;
-                }
+                if (row_hit) break;  // rows w+16, ... are later rows
             }
             TL_STAMP(0);
         } else {
@@ -368,7 +319,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #ifdef TL_PROFILE
                 ++livetiles;
 #endif
-                dense_tile<PRUNE>(P, n, i, t << 6, j0, ax, ay, bx, by, queues + (t & 15u) * kQCap, keyslot, lane);
+                dense_tile<PRUNE, true>(P, n, i, t << 6, j0, ax, ay, bx, by, queues + (t & 15u) * kQCap, keyslot, lane);
             }
             __syncthreads();
             if ((uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot) == kNoKey) {
@@ -378,7 +329,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #ifdef TL_PROFILE
                     ++livetiles;
 #endif
-                    if (dense_tile<PRUNE>(P, n, i, t << 6, j0, ax, ay, bx, by, queues + (t & 15u) * kQCap, keyslot, lane)) break;
+                    if (dense_tile<PRUNE, true>(P, n, i, t << 6, j0, ax, ay, bx, by, queues + (t & 15u) * kQCap, keyslot, lane)) break;
                 }
             }
         }
@@ -397,7 +348,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         } else {
             const uint32_t is = key >> 16, js = key & 0xFFFFu;
             // hits to apply: pruned mode found one; in dense mode the wave owning the first hit chained every
-            // improving move inside its tile (dense_tile) and left the list in its queue slot
+            // improving move inside its tile (dense_tile) and left the list in the tile's slot
             uint32_t nh = 1, resume = js + 1u;
             const uint32_t *hl = queues + (((js >> 6) & 15u) * kQCap);
             if (!pruned) {
@@ -539,7 +490,7 @@ size_t two_opt_ref_lds_bytes(uint32_t n, uint32_t *n_pad_out, int nt)
     if (n_pad_out) *n_pad_out = n_pad;
     if (n_pad > (uint32_t)kMaxGroups * 64u * 64u) return ~(size_t)0;  // beyond the tile-table capacity
     const size_t meta = (size_t)kMaxGroups * 64 * 20 + 64;
-    const size_t tail = (size_t)(nt / 64) * kQCap * 4;  // survivor queues, >= nt floats of scratch
+    const size_t tail = (size_t)(nt / 64) * kQCap * 4;  // hit-list slots, >= nt floats of scratch
     return (size_t)n_pad * 10 + meta + (tail > (size_t)nt * 4 ? tail : (size_t)nt * 4);
 }
 
