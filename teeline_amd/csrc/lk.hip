@@ -147,14 +147,15 @@ __global__ __launch_bounds__(kLkNT) void k_nn_seed(const float2 *__restrict__ xy
 }
 
 // ---------------------------------------------------------------------------------------------- LK
-struct LkView {
-    const float2 *xy;
+template <typename NextT>
+struct LkViewT {
+    const float2 *xy;      // global, or an LDS copy (k_lk_scan)
     const uint32_t *cand;
-    const uint32_t *next;
-    const uint32_t *prev;
+    const NextT *next;     // successor in the current tour; u16 LDS copy in k_lk_scan
     uint32_t k;
     uint32_t max_depth;
 };
+using LkView = LkViewT<uint32_t>;
 
 constexpr int kLkMaxDepth = 6;                       // compile-time recursion bound (default max_depth = 5)
 constexpr int kLkMaxChain = 2 * kLkMaxDepth + 2;
@@ -169,8 +170,8 @@ __device__ __forceinline__ bool in_chain(const uint32_t (&chain)[kLkMaxChain], u
 }
 
 // lin_kernighan.rs:265-340 find_lk_chain; DEPTH is the reference's `depth`, chain holds 2*DEPTH+2 cities on entry.
-template <int DEPTH>
-__device__ bool lk_chain(const LkView &V, uint32_t (&chain)[kLkMaxChain], uint32_t &clen, const float2 p1,
+template <int DEPTH, typename NextT>
+__device__ bool lk_chain(const LkViewT<NextT> &V, uint32_t (&chain)[kLkMaxChain], uint32_t &clen, const float2 p1,
                          const uint32_t t_open, const float2 p_open, const float gain)
 {
     if (DEPTH >= 1) {
@@ -188,14 +189,14 @@ __device__ bool lk_chain(const LkView &V, uint32_t (&chain)[kLkMaxChain], uint32
             const float g1 = gain - dist(p_open, p_next);
             if (g1 <= kLkEps) break;                                   // :292-295 candidates are sorted
             if (in_chain<2 * DEPTH + 2>(chain, t_next)) continue;      // used[t_next]
-            if (V.next[t_open] == t_next || V.prev[t_open] == t_next) continue;  // is_tour_edge
             const uint32_t t_break = V.next[t_next];                   // :305 regime A
+            if ((uint32_t)V.next[t_open] == t_next || t_break == t_open) continue;  // is_tour_edge: prev[a]==b <=> next[b]==a
             if (in_chain<2 * DEPTH + 2>(chain, t_break)) continue;     // used[t_break]
             const float2 p_break = V.xy[t_break];
             const float g2 = g1 + dist(p_next, p_break);
             chain[2 * DEPTH + 2] = t_next;
             chain[2 * DEPTH + 3] = t_break;
-            if (lk_chain<DEPTH + 1>(V, chain, clen, p1, t_break, p_break, g2)) return true;
+            if (lk_chain<DEPTH + 1, NextT>(V, chain, clen, p1, t_break, p_break, g2)) return true;
         }
     }
     return false;
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(kLkNT) void k_lk_solve(LkArgs G)
         __syncthreads();
         while (true) {
             rebuild(tour);  // :470
-            LkView V{xy, G.cand, next, prev, G.k, G.max_depth};
+            LkView V{xy, G.cand, next, G.k, G.max_depth};
             bool found_any = false;
             for (uint32_t base = 0; base < 2u * n; base += kLkNT) {  // find_lk_move (:345-389) in its own order
                 if (tid == 0) s_key = 0xFFFFFFFFu;
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(kLkNT) void k_lk_solve(LkArgs G)
                     chain[0] = t1;
                     chain[1] = t2;
                     const float g0 = t1 == t2 ? 0.0f : dist(p1, p2);
-                    if (lk_chain<0>(V, chain, clen, p1, t2, p2, g0)) ok = chain_valid(chain, clen, tour, pos, n);
+                    if (lk_chain<0, uint32_t>(V, chain, clen, p1, t2, p2, g0)) ok = chain_valid(chain, clen, tour, pos, n);
                 }
                 if (ok) atomicMin(&s_key, idx);
                 __syncthreads();
@@ -486,13 +487,25 @@ __global__ __launch_bounds__(kLkNT) void k_lk_solve(LkArgs G)
 //                 found nothing, i.e. the lk_pass is over — evaluate the tour, accept/reject, kick (double_bridge)
 //                 or finish.  The host only enqueues (scan, control) pairs in batches and polls `finished`.
 // ------------------------------------------------------------------------------------------------
+template <bool LDS>
 __global__ __launch_bounds__(256) void k_lk_scan(LkArgs G)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lk_smem[];
     LkState *S = G.state;
     if (S->finished) return;
     const uint32_t n = G.n, idx = blockIdx.x * 256u + threadIdx.x;
+    // The chain search is a divergent, latency-bound walk over xy[] and next[]: stage both in this CU's LDS
+    // (8 B + 2 B per city) so a node costs one L2 access (the candidate list) instead of four.
+    float2 *xyL = reinterpret_cast<float2 *>(lk_smem);
+    uint16_t *nextL = reinterpret_cast<uint16_t *>(lk_smem + (size_t)n * 8);
+    if (LDS) {
+        for (uint32_t c = threadIdx.x; c < n; c += 256u) {
+            xyL[c] = G.xy[c];
+            nextL[c] = (uint16_t)G.next[c];
+        }
+        __syncthreads();
+    }
     if (idx >= 2u * n) return;
-    LkView V{G.xy, G.cand, G.next, G.prev, G.k, G.max_depth};
     uint32_t chain[kLkMaxChain];
     uint32_t clen = 0;
     const uint32_t t1 = G.city_ids[idx >> 1];
@@ -501,7 +514,112 @@ __global__ __launch_bounds__(256) void k_lk_scan(LkArgs G)
     chain[0] = t1;
     chain[1] = t2;
     const float g0 = t1 == t2 ? 0.0f : dist(p1, p2);
-    if (lk_chain<0>(V, chain, clen, p1, t2, p2, g0) && chain_valid(chain, clen, G.tour, G.pos, n)) {
+    bool found;
+    if (LDS) {
+        LkViewT<uint16_t> V{xyL, G.cand, nextL, G.k, G.max_depth};
+        found = lk_chain<0, uint16_t>(V, chain, clen, p1, t2, p2, g0);
+    } else {
+        LkView V{G.xy, G.cand, G.next, G.k, G.max_depth};
+        found = lk_chain<0, uint32_t>(V, chain, clen, p1, t2, p2, g0);
+    }
+    if (found && chain_valid(chain, clen, G.tour, G.pos, n)) {
+        uint32_t *slot = G.chains + (size_t)idx * (kLkMaxChain + 2);
+        slot[0] = clen;
+        for (uint32_t t = 0; t < clen; ++t) slot[1 + t] = chain[t];
+        atomicMin(&S->key, idx);
+    }
+}
+
+// ---- split scan: the chain search of one (t1, orientation) pair is itself cut into k*(k+1) independent
+// sub-searches — branch q1 at depth 0 and, at depth 1, either the closing test (s = 0) or branch q2 = s-1 — so a
+// find_lk_move becomes 2n*k*(k+1) short walks (810 K lanes at n = 13 509, k = 5) instead of 2n long divergent ones.
+// Exactness: candidates are sorted by the same f32 distances, so g1 is non-increasing along a list and the
+// reference's `break` at g1 <= EPS (:292-295) is implied by each sub-search's own test; `used[]` depends only on the
+// chain.  The reference keeps the FIRST chain found in DFS order and drops the pair if that one is invalid (:373-381),
+// hence two steps: k_lk_scan_sub records the minimum (q1, s) with a chain per pair, k_lk_scan_pick re-derives that
+// chain, checks it, and posts the pair.
+template <typename NextT>
+__device__ bool lk_subsearch(const LkViewT<NextT> &V, uint32_t (&chain)[kLkMaxChain], uint32_t &clen, const float2 p1,
+                             const uint32_t t1, const uint32_t t2, const float2 p2, const float g0, const uint32_t q1, const uint32_t s)
+{
+    // depth 0 (find_lk_chain :290-337 with depth = 0)
+    const uint32_t t3 = V.cand[(size_t)t2 * V.k + q1];
+    const float2 p3 = V.xy[t3];
+    const float g1 = g0 - dist(p2, p3);
+    if (g1 <= kLkEps) return false;
+    if (t3 == t1 || t3 == t2) return false;
+    const uint32_t t4 = V.next[t3];
+    if ((uint32_t)V.next[t2] == t3 || t4 == t2) return false;
+    if (t4 == t1 || t4 == t2) return false;
+    const float2 p4 = V.xy[t4];
+    const float g2 = g1 + dist(p3, p4);
+    chain[2] = t3;
+    chain[3] = t4;
+    // depth 1
+    const float close_gain = g2 - dist(p4, p1);
+    if (s == 0u) {
+        if (close_gain > kLkEps) {
+            clen = 4;
+            return true;
+        }
+        return false;
+    }
+    if (close_gain > kLkEps) return false;  // the sequential search returned at s = 0
+    if (1u >= V.max_depth) return false;
+    const uint32_t t5 = V.cand[(size_t)t4 * V.k + (s - 1u)];
+    const float2 p5 = V.xy[t5];
+    const float g3 = g2 - dist(p4, p5);
+    if (g3 <= kLkEps) return false;
+    if (in_chain<4>(chain, t5)) return false;
+    const uint32_t t6 = V.next[t5];
+    if ((uint32_t)V.next[t4] == t5 || t6 == t4) return false;
+    if (in_chain<4>(chain, t6)) return false;
+    const float2 p6 = V.xy[t6];
+    const float g4 = g3 + dist(p5, p6);
+    chain[4] = t5;
+    chain[5] = t6;
+    return lk_chain<2, NextT>(V, chain, clen, p1, t6, p6, g4);
+}
+
+__global__ __launch_bounds__(256) void k_lk_scan_sub(LkArgs G)
+{
+    if (G.state->finished) return;
+    const uint32_t n = G.n, subs = G.k * (G.k + 1u);
+    const uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (g >= (uint64_t)2u * n * subs) return;
+    const uint32_t idx = (uint32_t)(g / subs), sub = (uint32_t)(g % subs);
+    const uint32_t t1 = G.city_ids[idx >> 1];
+    const uint32_t t2 = (idx & 1u) ? G.prev[t1] : G.next[t1];
+    const float2 p1 = G.xy[t1], p2 = G.xy[t2];
+    uint32_t chain[kLkMaxChain];
+    uint32_t clen = 0;
+    chain[0] = t1;
+    chain[1] = t2;
+    const float g0 = t1 == t2 ? 0.0f : dist(p1, p2);
+    LkView V{G.xy, G.cand, G.next, G.k, G.max_depth};
+    if (lk_subsearch<uint32_t>(V, chain, clen, p1, t1, t2, p2, g0, sub / (G.k + 1u), sub % (G.k + 1u))) atomicMin(&G.pairmin[idx], sub);
+}
+
+__global__ __launch_bounds__(256) void k_lk_scan_pick(LkArgs G)
+{
+    LkState *S = G.state;
+    if (S->finished) return;
+    const uint32_t n = G.n, idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= 2u * n) return;
+    const uint32_t sub = G.pairmin[idx];
+    if (sub == 0xFFFFFFFFu) return;
+    G.pairmin[idx] = 0xFFFFFFFFu;  // ready for the next scan
+    const uint32_t t1 = G.city_ids[idx >> 1];
+    const uint32_t t2 = (idx & 1u) ? G.prev[t1] : G.next[t1];
+    const float2 p1 = G.xy[t1], p2 = G.xy[t2];
+    uint32_t chain[kLkMaxChain];
+    uint32_t clen = 0;
+    chain[0] = t1;
+    chain[1] = t2;
+    const float g0 = t1 == t2 ? 0.0f : dist(p1, p2);
+    LkView V{G.xy, G.cand, G.next, G.k, G.max_depth};
+    if (lk_subsearch<uint32_t>(V, chain, clen, p1, t1, t2, p2, g0, sub / (G.k + 1u), sub % (G.k + 1u)) &&
+        chain_valid(chain, clen, G.tour, G.pos, n)) {
         uint32_t *slot = G.chains + (size_t)idx * (kLkMaxChain + 2);
         slot[0] = clen;
         for (uint32_t t = 0; t < clen; ++t) slot[1 + t] = chain[t];
@@ -706,7 +824,20 @@ hipError_t launch_lk_begin(const LkArgs &G, hipStream_t s)
 
 hipError_t launch_lk_round(const LkArgs &G, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_lk_scan, dim3((2u * G.n + 255u) / 256u), dim3(256), 0, s, G);
+    if (G.pairmin) {  // split scan
+        const uint64_t lanes = (uint64_t)2u * G.n * G.k * (G.k + 1u);
+        hipLaunchKernelGGL(k_lk_scan_sub, dim3((uint32_t)((lanes + 255u) / 256u)), dim3(256), 0, s, G);
+        hipLaunchKernelGGL(k_lk_scan_pick, dim3((2u * G.n + 255u) / 256u), dim3(256), 0, s, G);
+    } else {
+        const size_t lds = (size_t)G.n * 10;
+        if (G.n < 65536u && lds <= (size_t)G.lds_budget) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_lk_scan<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k_lk_scan<true>, dim3((2u * G.n + 255u) / 256u), dim3(256), lds, s, G);
+        } else {
+            hipLaunchKernelGGL(k_lk_scan<false>, dim3((2u * G.n + 255u) / 256u), dim3(256), 0, s, G);
+        }
+    }
     hipLaunchKernelGGL(k_lk_control, dim3(1), dim3(kLkNT), 0, s, G);
     return hipGetLastError();
 }

@@ -779,6 +779,8 @@ extern "C" int tl_or_opt(tl_ctx *c, const float *xy, uint32_t n, const float *dm
     return TL_OK;
 }
 
+static bool max_depth_ge2_split(uint32_t) { return true; }  // the split scan handles every max_depth >= 1
+
 // ------------------------------------------------------------------------------------------------
 // candidate lists, NN seed, Lin-Kernighan
 // ------------------------------------------------------------------------------------------------
@@ -856,9 +858,12 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const uint32_t *ini
     const size_t o_cand = 0, o_tour = up((size_t)n * (k ? k : 1) * 4), o_alt = o_tour + arr, o_pos = o_alt + arr, o_next = o_pos + arr,
                  o_prev = o_next + arr, o_ids = o_prev + arr, o_best = o_ids + arr, o_cnt = o_best + arr, o_state = o_cnt + 256,
                  o_chains = o_state + 256;
-    // n below this runs the whole ILS in one persistent workgroup; above it the scan is spread over all CUs
-    const bool multi_cu = n >= (getenv("TL_LK_MULTI_MIN_N") ? (uint32_t)atoi(getenv("TL_LK_MULTI_MIN_N")) : 1500u);
-    const size_t total = o_chains + (multi_cu ? up((size_t)2 * n * lk_chain_slot_words() * 4) : 0);
+    // default: scans spread over all CUs (faster at every size measured, berlin52 included); TL_LK_MULTI_MIN_N raises the
+    // size below which the whole ILS runs in one persistent workgroup instead (kept as a cross-check of the state machine)
+    const bool multi_cu = n >= (getenv("TL_LK_MULTI_MIN_N") ? (uint32_t)atoi(getenv("TL_LK_MULTI_MIN_N")) : 0u);
+    const size_t o_pairmin = o_chains + (multi_cu ? up((size_t)2 * n * lk_chain_slot_words() * 4) : 0);
+    const bool split_scan = multi_cu && max_depth_ge2_split(o.max_depth) && !getenv("TL_LK_NO_SPLIT");
+    const size_t total = o_pairmin + (split_scan ? up((size_t)2 * n * 4) : 0);
     if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->work, total)) || (rc = ensure(c, c->out_cost, 4))) return rc;
     unsigned char *w = (unsigned char *)c->work.p;
     HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
@@ -888,8 +893,11 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const uint32_t *ini
     G.max_depth = o.max_depth;
     G.epochs = o.epochs;
     G.platoo_epochs = o.platoo_epochs;
+    G.lds_budget = (uint32_t)c->lds_bytes;
     G.state = (LkState *)(w + o_state);
     G.chains = (uint32_t *)(w + o_chains);
+    G.pairmin = split_scan ? (uint32_t *)(w + o_pairmin) : nullptr;
+    if (split_scan) HIPCHK(c, hipMemsetAsync(G.pairmin, 0xFF, (size_t)2 * n * 4, c->stream));
     uint64_t cnt[4] = {0, 0, 0, 0};
     if (!multi_cu) {
         HIPCHK(c, launch_lk_solve(G, c->stream));

@@ -115,8 +115,10 @@ struct LkArgs {
     uint64_t *counters;     // scans, searches, moves, exchanged edges
     LkState *state;         // multi-CU variant
     uint32_t *chains;       // multi-CU variant: [2n][kLkMaxChain + 2] chain slots
+    uint32_t *pairmin;      // split scan: [2n] minimum sub-search index with a chain (0xFFFFFFFF: none); nullptr = unsplit scan
     uint64_t seed;
     uint32_t n, k, max_depth, epochs, platoo_epochs;
+    uint32_t lds_budget;    // LDS bytes a scan workgroup may use for its xy/next copies
 };
 hipError_t launch_knn(const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, hipStream_t s);
 hipError_t launch_nn_seed(const float2 *xy, uint32_t n, const uint32_t *cand, uint32_t k, uint32_t *path, unsigned char *visited, hipStream_t s);

@@ -116,19 +116,26 @@ def test_lk_other_instances(ctx, case, tsplib_dir):
                         O.lin_kernighan(xy, seed=1, epochs=20, max_depth=depth, n_nearest=k))
 
 
-def test_lk_multi_cu_variant_is_identical(ctx, tsplib_dir, monkeypatch):
-    # n >= 1500 spreads the scan over all CUs (k_lk_scan + k_lk_control state machine); forcing it on small
-    # instances must reproduce the persistent-workgroup results, i.e. the oracle's, bit for bit
+def test_lk_variants_are_identical(ctx, tsplib_dir, monkeypatch):
+    # default = scans spread over all CUs, each pair's chain search split into k*(k+1) sub-searches, device-side control
+    # state machine.  The unsplit scan and the single persistent workgroup must reproduce the same results (= the oracle's).
     xy = T.parse_tsplib(os.path.join(tsplib_dir, "berlin52.tsp"))["xy"]
-    monkeypatch.setenv("TL_LK_MULTI_MIN_N", "0")
-    for seed in (1, 2):
-        assert_same(gpu_lk(ctx, xy, seed=seed), O.lin_kernighan(xy, seed=seed))
     lat = lattice(10, 2)
-    assert_same(gpu_lk(ctx, lat, seed=11, epochs=40), O.lin_kernighan(lat, seed=11, epochs=40))
+    xy2 = O.synth_xy(200, seed=4)
     sq = np.array([[0, 0], [1, 1], [1, 0], [0, 1]], np.float32)
-    assert_same(gpu_lk(ctx, sq, init=[0, 1, 2, 3], max_depth=1, epochs=0), O.lin_kernighan(sq, init=[0, 1, 2, 3], epochs=0, max_depth=1))
     tri = np.array([[0, 0], [1, 0], [0.5, 1]], np.float32)
-    assert gpu_lk(ctx, tri, init=[2, 0, 1])[0].tolist() == [2, 0, 1]
-    monkeypatch.delenv("TL_LK_MULTI_MIN_N")
-    xy = O.synth_xy(2000, seed=6)  # default dispatch: multi-CU
-    assert_same(gpu_lk(ctx, xy, seed=5, epochs=8), O.lin_kernighan(xy, seed=5, epochs=8))
+    for env in ({"TL_LK_NO_SPLIT": "1"}, {"TL_LK_MULTI_MIN_N": "1000000"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for seed in (1, 2):
+            assert_same(gpu_lk(ctx, xy, seed=seed), O.lin_kernighan(xy, seed=seed))
+        assert_same(gpu_lk(ctx, lat, seed=11, epochs=40), O.lin_kernighan(lat, seed=11, epochs=40))
+        assert_same(gpu_lk(ctx, sq, init=[0, 1, 2, 3], max_depth=1, epochs=0), O.lin_kernighan(sq, init=[0, 1, 2, 3], epochs=0, max_depth=1))
+        assert gpu_lk(ctx, tri, init=[2, 0, 1])[0].tolist() == [2, 0, 1]
+        for depth, k in ((1, 5), (2, 3), (6, 5)):
+            assert_same(gpu_lk(ctx, xy2, seed=1, epochs=20, max_depth=depth, n_nearest=k),
+                        O.lin_kernighan(xy2, seed=1, epochs=20, max_depth=depth, n_nearest=k))
+        for k in env:
+            monkeypatch.delenv(k)
+    big = O.synth_xy(2000, seed=6)
+    assert_same(gpu_lk(ctx, big, seed=5, epochs=8), O.lin_kernighan(big, seed=5, epochs=8))
