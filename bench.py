@@ -131,6 +131,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if dist is not None:  # RCCL communicator set-up (lazy on the first collective) is not part of any timed step
+        dist.all_reduce(torch.zeros(1, dtype=torch.int64, device=dev), op=dist.ReduceOp.MIN)
     for _ in range(a.warmup):
         step()
     sync()

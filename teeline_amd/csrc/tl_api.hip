@@ -264,7 +264,7 @@ static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uin
     HIPCHK(c, hipEventRecord(c->ev0, s));
     if (d_dm) {
         if (init_mode == TL_INIT_SEEDED) return fail(c, TL_ERR_UNSUPPORTED, "seeded restarts need coordinates (dm_packed must be NULL)");
-        if (two_opt_ref_dm_lds_bytes(n) > (size_t)c->lds_bytes)
+        if (two_opt_ref_dm_lds_bytes(n) > (size_t)c->lds_bytes || n > 65535)
             return fail(c, TL_ERR_UNSUPPORTED, "two_opt (matrix form): n=%u exceeds the LDS tour capacity", n);
         HIPCHK(c, launch_two_opt_ref_dm(A, count, s));
     } else {

@@ -3,9 +3,9 @@
 //
 // Used when the caller supplies `dm_packed` (EXPLICIT / GEO problems, and north-star config 2:
 // "fp32 distance matrix in HBM").  One persistent workgroup per descent; the tour (u32 positions)
-// lives in LDS.  A step evaluates the rest of row i from the resume column j0 with lanes along j,
-// reduces the first improving j (ballot/ffs per wave, one ds_min_u32 per wave), applies the
-// reversal cooperatively and resumes at (i, j+1) — exactly the reference's loop order.
+// lives in LDS.  A step speculatively decides 16 rows (one per wave, lanes along j) under "no move yet",
+// reduces the lexicographically first improving (i,j) (ballot/ffs per wave, ds_min_u32 on i<<16|j), applies
+// the reversal cooperatively and resumes at (i, j+1) — exactly the reference's loop order.
 // Algorithmic bytes per candidate: perm[j+1] 4 B + D[a][c] 4 B + D[b][e] 4 B + D[c][e] 4 B = 16 B
 // (SURVEY.md §8(d)); the row terms a, b, D[a][b] are amortised over the row.
 #include "tl_kernels.h"
@@ -44,37 +44,77 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
     uint32_t i0 = 0, j0 = 2, step = 0, sweeps = 1, status = 0;
     bool improved = false;
     uint64_t moves = 0, reversed = 0;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    constexpr uint32_t NWv = kDmNT / 64;
+    uint32_t since_rows = 0;  // rows scanned since the last move
 
     while (n >= 4) {
         const uint32_t slot = step % 3u;
         if (tid == 0) keys[(step + 1u) % 3u] = kNoKey;
         ++step;
-        const uint32_t a = perm[i0], b = perm[i0 + 1u];
-        const float dab = dm_lookup(dm, a, b);
-        // lanes along j; a thread's columns are j0 + tid + m*NT, ascending, so its first hit is its best
-        for (uint32_t jb = j0 - (j0 & 63u); jb <= n - 2u; jb += kDmNT) {
-            const uint32_t j = jb + tid;
-            bool imp = false;
-            if (j >= j0 && j <= n - 2u) {
-                const uint32_t c = perm[j], e = perm[j + 1u];
-                const float cur = dab + dm_lookup(dm, c, e);                       // two_opt.rs:35-40
-                const float neu = dm_lookup(dm, a, c) + dm_lookup(dm, b, e);       // two_opt.rs:42-47
-                imp = neu < cur;                                                   // :49
+        // Two block shapes, chosen from the observed gap between moves (like the coordinate kernel):
+        //  wide  — moves are rare: 16 rows per step, one per wave, lanes along j;
+        //  dense — moves every few rows: one row per step, its columns dealt to the 16 waves.
+        // Either way the lexicographically first improving (i, j) wins (ds_min_u32 on i << 16 | j) and the scan
+        // resumes at (i, j+1) like the reference.
+        const bool wide = since_rows >= 4u;
+        const uint32_t R = wide ? NWv : 1u;
+        if (wide) {
+            const uint32_t i = i0 + wave;
+            if (i < nrows) {
+                const uint32_t a = perm[i], b = perm[i + 1u];
+                const float dab = dm_lookup(dm, a, b);
+                const uint32_t jmin = wave == 0u ? j0 : i + 2u;
+                for (uint32_t jb = jmin - (jmin & 63u); jb <= n - 2u; jb += 64u) {
+                    const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)keys[slot]);
+                    if (kb != kNoKey && ((kb >> 16) < i || ((kb >> 16) == i && (kb & 0xFFFFu) < jb))) break;  // an earlier hit exists
+                    const uint32_t j = jb + lane;
+                    bool imp = false;
+                    if (j >= jmin && j <= n - 2u) {
+                        const uint32_t c = perm[j], e = perm[j + 1u];
+                        const float cur = dab + dm_lookup(dm, c, e);                       // two_opt.rs:35-40
+                        const float neu = dm_lookup(dm, a, c) + dm_lookup(dm, b, e);       // two_opt.rs:42-47
+                        imp = neu < cur;                                                   // :49
+                    }
+                    const uint64_t m = __builtin_amdgcn_ballot_w64(imp);
+                    if (m) {
+                        if (lane == 0) atomicMin(&keys[slot], (i << 16) | (jb + (uint32_t)(__builtin_ffsll((long long)m) - 1)));
+                        break;
+                    }
+                }
             }
-            const uint64_t m = __builtin_amdgcn_ballot_w64(imp);
-            if (m) {
-                if (lane == 0) atomicMin(&keys[slot], j + (uint32_t)(__builtin_ffsll((long long)m) - 1));
-                break;  // wave-uniform: later columns of this wave are lexicographically later
+        } else {
+            const uint32_t i = i0;
+            const uint32_t a = perm[i], b = perm[i + 1u];
+            const float dab = dm_lookup(dm, a, b);
+            for (uint32_t jb = j0 - (j0 & 63u) + (wave << 6); jb <= n - 2u; jb += kDmNT) {
+                const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)keys[slot]);
+                if (kb != kNoKey && (kb & 0xFFFFu) < jb) break;
+                const uint32_t j = jb + lane;
+                bool imp = false;
+                if (j >= j0 && j <= n - 2u) {
+                    const uint32_t c = perm[j], e = perm[j + 1u];
+                    const float cur = dab + dm_lookup(dm, c, e);
+                    const float neu = dm_lookup(dm, a, c) + dm_lookup(dm, b, e);
+                    imp = neu < cur;
+                }
+                const uint64_t m = __builtin_amdgcn_ballot_w64(imp);
+                if (m) {
+                    if (lane == 0) atomicMin(&keys[slot], (i << 16) | (jb + (uint32_t)(__builtin_ffsll((long long)m) - 1)));
+                    break;
+                }
             }
-            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)keys[slot]) < jb) break;  // someone already holds an earlier hit
         }
         __syncthreads();
-        const uint32_t js = (uint32_t)__builtin_amdgcn_readfirstlane((int)keys[slot]);
-        if (js == kNoKey) {
-            ++i0;
+        const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)keys[slot]);
+        if (key == kNoKey) {
+            i0 += R;
             j0 = i0 + 2u;
+            since_rows += R;
         } else {
-            const uint32_t lo = i0 + 1u, hi = js;  // swap_2opt(path, i+1, j), two_opt.rs:69-79
+            since_rows = 0;
+            const uint32_t is = key >> 16, js = key & 0xFFFFu;
+            const uint32_t lo = is + 1u, hi = js;  // swap_2opt(path, i+1, j), two_opt.rs:69-79
             const uint32_t half = (hi - lo + 1u) >> 1;
             for (uint32_t t = tid; t < half; t += kDmNT) {
                 const uint32_t u = perm[lo + t], v = perm[hi - t];
@@ -84,7 +124,8 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
             __syncthreads();
             improved = true;
             ++moves;
-            reversed += (uint64_t)(js - i0);
+            reversed += (uint64_t)(js - is);
+            i0 = is;
             j0 = js + 1u;
             if (j0 > n - 2u) {
                 ++i0;

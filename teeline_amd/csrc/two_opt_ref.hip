@@ -285,7 +285,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 bool row_hit = false;
 #pragma unroll
                 for (int gI = 0; gI < kMaxGroups; ++gI) {
-                    if (gI < G) {
+                    if (gI < G && (((uint32_t)gI + 1u) << 6) > tmin) {  // groups wholly before the row's first column: nothing to test
                         const uint32_t tl = ((uint32_t)gI << 6) + (uint32_t)lane;
                         const bool live = (tl >= tmin) && ((box_lb(ax, ay, box[gI]) < sqab) || (box_lb(bx, by, box[gI]) < msq[gI]));
                         uint64_t m = __builtin_amdgcn_ballot_w64(live);
