@@ -108,7 +108,8 @@ void tl_destroy(tl_ctx *ctx);
 const char *tl_last_error(const tl_ctx *ctx); /* ctx may be NULL: last tl_create failure */
 /* CU count, LDS bytes per workgroup and arch name of the context's device. */
 int tl_device_info(const tl_ctx *ctx, int *cus, int *lds_bytes, char *arch, size_t arch_len);
-/* Largest n the LDS-resident REF_ORDER 2-opt kernel takes (tour + coordinates live in one CU's LDS). */
+/* Largest n the LDS-resident REF_ORDER 2-opt kernel takes (tour + coordinates live in one CU's LDS).  tl_two_opt
+ * handles larger n (<= 65535) with the HBM-resident variant; the batch / multi-start entries are LDS-only. */
 uint32_t tl_two_opt_lds_max_n(const tl_ctx *ctx);
 
 /* ---- distance matrix: replaces DistanceMatrix::build (distance_matrix.rs:122-153) ----------- */

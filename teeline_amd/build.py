@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libteeline_gpu.so")
 
-SOURCES = ["tl_api.hip", "two_opt_ref.hip", "two_opt_dm.hip", "dm_build.hip", "three_opt.hip", "lk.hip", "two_opt_best.hip", "or_opt.hip"]
+SOURCES = ["tl_api.hip", "two_opt_ref.hip", "two_opt_dm.hip", "dm_build.hip", "three_opt.hip", "lk.hip", "two_opt_best.hip", "or_opt.hip", "two_opt_large.hip"]
 HEADERS = ["tl_device.h", "tl_kernels.h", "two_opt_common.h", os.path.join(ROOT, "include", "teeline_gpu.h")]
 
 # -ffp-contract=off: the reference never fuses mul+add (src/tsp/kdtree.rs:291-295); bit-exact parity

@@ -307,6 +307,72 @@ static void fill_stats(tl_stats *st, uint32_t n, const uint64_t *raw, uint32_t c
 static int two_opt_best_sweep(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
                               uint32_t *out_pos, float *out_cost, tl_stats *stats);
 
+// REF_ORDER for n beyond the LDS-resident kernel: tour state in HBM, scan spread over the chip (two_opt_large.hip)
+static int two_opt_ref_large(tl_ctx *c, const float *xy, uint32_t n, const uint32_t *init_pos, uint32_t *out_pos, float *out_cost,
+                             tl_stats *stats)
+{
+    if (n > 65535) return fail(c, TL_ERR_UNSUPPORTED, "two_opt: n=%u > 65535 (packed (i,j) key)", n);
+    const auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const uint32_t n_pad = ((n + 64u + 63u) / 64u) * 64u, ntile_cap = (((n_pad >> 6) + 63u) / 64u) * 64u;
+    const size_t o_perm = 0, o_P = up((size_t)n * 4), o_box = up(o_P + (size_t)(n_pad + 1) * 8), o_msq = up(o_box + (size_t)ntile_cap * 16),
+                 o_st = up(o_msq + (size_t)ntile_cap * 4), total = o_st + 256;
+    if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->work, total)) || (rc = ensure(c, c->out_cost, 4))) return rc;
+    unsigned char *w = (unsigned char *)c->work.p;
+    std::vector<uint32_t> ident;
+    if (!init_pos) {
+        ident.resize(n);
+        for (uint32_t i = 0; i < n; ++i) ident[i] = i;
+        init_pos = ident.data();
+    }
+    HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(w + o_perm, init_pos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    LargeTwoOptArgs A{};
+    A.xy = (const float2 *)c->xy.p;
+    A.perm = (uint32_t *)(w + o_perm);
+    A.P = (float2 *)(w + o_P);
+    A.tbox = (float4 *)(w + o_box);
+    A.tmsq = (float *)(w + o_msq);
+    A.state = (LargeTwoOptState *)(w + o_st);
+    A.n = n;
+    A.n_pad = n_pad;
+    A.ntile_cap = ntile_cap;
+    A.max_sweeps = 1u << 20;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    HIPCHK(c, launch_large_two_opt_init(A, c->stream));
+    LargeTwoOptState hs{};
+    for (;;) {
+        for (int r = 0; r < 64; ++r) HIPCHK(c, launch_large_two_opt_round(A, c->stream));  // kernels no-op once done
+        HIPCHK(c, hipMemcpyAsync(&hs, A.state, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (hs.done) break;
+    }
+    if (hs.status) return fail(c, TL_ERR_NO_CONVERGE, "two_opt: sweep cap reached");
+    HIPCHK(c, launch_tour_length(A.xy, nullptr, n, A.perm, (float *)c->out_cost.p, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    c->ev_valid = true;
+    float cost = 0.f;
+    HIPCHK(c, hipMemcpyAsync(out_pos, A.perm, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&cost, c->out_cost.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (out_cost) *out_cost = cost;
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->sweeps = hs.sweeps;
+        stats->moves = hs.moves;
+        stats->reversed = hs.reversed;
+        stats->candidates = (uint64_t)hs.sweeps * ((uint64_t)(n - 3) * (n - 2) / 2);
+        double kms = 0;
+        tl_last_kernel_ms(c, &kms);
+        stats->kernel_ms = kms;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return TL_OK;
+}
+
 extern "C" int tl_two_opt(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos, int mode,
                           uint32_t *out_pos, float *out_cost, tl_stats *stats)
 {
@@ -315,6 +381,14 @@ extern "C" int tl_two_opt(tl_ctx *c, const float *xy, uint32_t n, const float *d
     if (n < 3) return fail(c, TL_ERR_REF_PANICS, "two_opt: n=%u < 3 — the reference underflows `n_indices - 2` (two_opt.rs:17,29)", n);
     if (init_pos && !is_permutation(init_pos, n)) return fail(c, TL_ERR_BADARG, "tl_two_opt: init tour is not a permutation of 0..n-1");
     if (mode == TL_MODE_BEST_SWEEP) return two_opt_best_sweep(c, xy, n, dm_packed, init_pos, out_pos, out_cost, stats);
+    if (!dm_packed && (n > lds_max_n(c->lds_bytes) || getenv("TL_FORCE_LARGE_2OPT"))) {
+        if (n < 4) {  // n == 3: the reference's loops are empty
+            for (uint32_t i = 0; i < n; ++i) out_pos[i] = init_pos ? init_pos[i] : i;
+            if (stats) { memset(stats, 0, sizeof(*stats)); stats->sweeps = 1; }
+            return out_cost ? tl_tour_length(c, xy, nullptr, n, out_pos, out_cost) : TL_OK;
+        }
+        return two_opt_ref_large(c, xy, n, init_pos, out_pos, out_cost, stats);
+    }
     const auto t0 = std::chrono::steady_clock::now();
     HIPCHK(c, hipSetDevice(c->device));
     int rc;

@@ -52,6 +52,23 @@ hipError_t launch_best_sweep_init(const BestSweepArgs &A, hipStream_t s);
 hipError_t launch_best_sweep_round(const BestSweepArgs &A, hipStream_t s);
 uint32_t best_sweep_scan_blocks(uint32_t n);
 
+// two_opt_large.hip — REF_ORDER for tours beyond one CU's LDS
+struct LargeTwoOptState {
+    uint32_t key, i0, j0, rows, improved, sweeps, done, status;
+    uint64_t moves, reversed;
+};
+struct LargeTwoOptArgs {
+    const float2 *xy;
+    uint32_t *perm;     // [n] in/out
+    float2 *P;          // [n_pad + 1]
+    float4 *tbox;       // [ntile_cap]
+    float *tmsq;        // [ntile_cap]
+    LargeTwoOptState *state;
+    uint32_t n, n_pad, ntile_cap, max_sweeps;
+};
+hipError_t launch_large_two_opt_init(const LargeTwoOptArgs &A, hipStream_t s);
+hipError_t launch_large_two_opt_round(const LargeTwoOptArgs &A, hipStream_t s);
+
 // three_opt.hip
 struct ThreeOptBest {
     float sav;

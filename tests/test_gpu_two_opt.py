@@ -240,16 +240,40 @@ def test_config5_size_and_lds_limit(ctx):
     assert_same(gpu_two_opt(ctx, xy, None, n, nn), O.two_opt(xy, None, n, init=nn), n)
     nmax = ctx.two_opt_lds_max_n()
     assert 13509 <= nmax < 16384
+    # the largest LDS-resident size (last tile / group logic) and the first size beyond it (HBM-resident tour,
+    # scan spread over the chip: two_opt_large.hip) — both must be fixed points of the reference's sweep
     big = O.synth_xy(nmax + 1, seed=2)
+    for m in (nmax, nmax + 1):
+        xym = big[:m]
+        rc, nnm, _ = O.nearest_neighbor(xym, None, m, 3)
+        route, cost, st = gpu_two_opt(ctx, xym, None, m, nnm)
+        rc, again, c2, st2 = O.two_opt(xym, None, m, init=route, max_candidates=1)
+        assert st2["moves"] == 0 and c2 == cost and O.validate_tour(route)
+    # the batch entry stays LDS-only and says so loudly
     with pytest.raises(TA.TeelineGpuError) as e:
-        gpu_two_opt(ctx, big, None, nmax + 1)
-    assert e.value.code == -6  # TL_ERR_UNSUPPORTED, loudly — never a CPU fallback
-    # the largest supported size still works (one sweep is enough to exercise the last tile / group logic)
-    xym = big[:nmax]
-    rc, nnm, _ = O.nearest_neighbor(xym, None, nmax, 3)
-    route, cost, st = gpu_two_opt(ctx, xym, None, nmax, nnm)
-    rc, again, c2, st2 = O.two_opt(xym, None, nmax, init=route, max_candidates=1)
-    assert st2["moves"] == 0 and c2 == cost and O.validate_tour(route)
+        TA.two_opt.multistart(TA.TspProblem(np.arange(nmax + 1), big), 2, ctx=ctx)
+    assert e.value.code == -6  # TL_ERR_UNSUPPORTED — never a CPU fallback
+
+
+def test_large_n_path_matches_oracle(ctx, monkeypatch):
+    # HBM-resident REF_ORDER path, forced on sizes the oracle finishes quickly: identical tours / costs / counters
+    monkeypatch.setenv("TL_FORCE_LARGE_2OPT", "1")
+    for n, seed in ((3, 1), (4, 1), (5, 2), (64, 3), (65, 4), (700, 5), (3000, 6)):
+        xy = O.synth_xy(n, seed=seed)
+        assert_same(gpu_two_opt(ctx, xy, None, n), O.two_opt(xy, None, n), n)
+        if n >= 64:
+            rp = O.restart_perm(n, 8, seed)
+            assert_same(gpu_two_opt(ctx, xy, None, n, rp), O.two_opt(xy, None, n, init=rp), n)
+    monkeypatch.delenv("TL_FORCE_LARGE_2OPT")
+    # n = 20 000 from the NN seed (oracle: ~2.4e9 candidates, too slow for the suite): size-independent checks
+    n = 20000
+    xy = O.synth_xy(n)
+    rc, nn, cnn = O.nearest_neighbor(xy, None, n, 3)
+    route, cost, st = gpu_two_opt(ctx, xy, None, n, nn)
+    assert O.validate_tour(route) and route[0] == nn[0] and route[-1] == nn[-1] and cost < cnn
+    assert st["candidates"] == st["sweeps"] * ((n - 3) * (n - 2) // 2)
+    rc, again, c2, st2 = O.two_opt(xy, None, n, init=route, max_candidates=1)
+    assert st2["moves"] == 0 and c2 == cost
 
 
 def test_device_resident_batch_entry_with_explicit_starts(ctx):
