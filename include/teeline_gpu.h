@@ -112,6 +112,12 @@ int tl_device_info(const tl_ctx *ctx, int *cus, int *lds_bytes, char *arch, size
  * handles larger n (<= 65535) with the HBM-resident variant; the batch / multi-start entries are LDS-only. */
 uint32_t tl_two_opt_lds_max_n(const tl_ctx *ctx);
 
+/* ---- numerics self-test -------------------------------------------------------------------------- */
+/* Every kernel's correctly rounded sqrt (the reference's f32::sqrt, kdtree.rs:294) is a short v_sqrt_f32 + FMA
+ * fix-up; this compares it on the device with the compiler's full expansion for the `count` f32 bit patterns
+ * starting at `first_bits`.  *mismatches must come back 0. */
+int tl_selftest_sqrt(tl_ctx *ctx, uint32_t first_bits, uint64_t count, uint64_t *mismatches, uint32_t *first_bad_bits);
+
 /* ---- distance matrix: replaces DistanceMatrix::build (distance_matrix.rs:122-153) ----------- */
 /* out_host may be NULL (matrix stays on the device for later calls on this context). */
 int tl_dm_build(tl_ctx *ctx, const float *xy, uint32_t n, int dist, int layout, float *out_host,

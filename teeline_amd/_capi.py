@@ -25,7 +25,7 @@ SYMBOLS = [
     "tl_two_opt_lds_max_n", "tl_dm_build", "tl_tour_length", "tl_two_opt", "tl_three_opt",
     "tl_three_opt_find_best_move", "tl_lk", "tl_two_opt_multistart", "tl_pack_cost_key",
     "tl_two_opt_batch_dev", "tl_last_kernel_ms", "tl_dm_build_dev", "tl_build_candidates", "tl_nearest_neighbor",
-    "tl_or_opt", "tl_or_opt_find_best_move",
+    "tl_or_opt", "tl_or_opt_find_best_move", "tl_selftest_sqrt",
 ]
 
 
@@ -92,6 +92,7 @@ def load():
     L.tl_dm_build_dev.argtypes = [vp, vp, u32, i32, i32, vp, vp]
     L.tl_build_candidates.argtypes = [vp, vp, u32, u32, vp]
     L.tl_nearest_neighbor.argtypes = [vp, vp, u32, u32, vp, f32p]
+    L.tl_selftest_sqrt.argtypes = [vp, u32, u64, C.POINTER(u64), C.POINTER(u32)]
     L.tl_or_opt.argtypes = [vp, vp, u32, vp, vp, vp, f32p, C.POINTER(TlStats)]
     L.tl_or_opt_find_best_move.argtypes = [vp, vp, u32, vp, vp, C.POINTER(i32), f32p, C.POINTER(u32), C.POINTER(u32),
                                            C.POINTER(u32), C.POINTER(i32)]

@@ -30,7 +30,6 @@ __global__ __launch_bounds__(kDmThreads) void k_dm_build_packed(const float2 *__
     while (i * (i + 1) / 2 <= t) ++i;
     uint64_t j = t - i * (i - 1) / 2;
     float2 a = xy[i];
-#pragma unroll 4
     for (int k = 0; k < kDmPerThread; ++k) {
         const float2 c = xy[j];
         out[t] = GEO ? geo_dist(a, c) : dist(a, c);  // cities[i].distance(cities[j]), j < i
@@ -56,7 +55,6 @@ __global__ __launch_bounds__(kDmThreads) void k_dm_build_full(const float2 *__re
     const float2 a = xy[i];
     uint32_t j = blockIdx.y * (kDmThreads * kDmPerThread) + threadIdx.x;
     float *__restrict__ row = out + (size_t)i * n;
-#pragma unroll 4
     for (int k = 0; k < kDmPerThread; ++k, j += kDmThreads) {
         if (j >= n) return;
         const float2 c = xy[j];
@@ -128,4 +126,30 @@ hipError_t launch_tour_length(const float2 *xy, const float *dm, uint32_t n, con
     return hipGetLastError();
 }
 
+}  // namespace tl
+
+// ---- self-test of the numerics contract: sqrt_rn (fast path) vs the compiler's correctly rounded expansion ----
+namespace tl {
+__global__ __launch_bounds__(256) void k_selftest_sqrt(uint32_t first_bits, uint64_t count, unsigned long long *mismatches, uint32_t *first_bad)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    unsigned long long bad = 0;
+    for (uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x; k < count; k += stride) {
+        const uint32_t bits = first_bits + (uint32_t)k;
+        const float x = __builtin_bit_cast(float, bits);
+        const float a = sqrt_rn(x), b = sqrt_rn_ref(x);
+        const uint32_t ab = __builtin_bit_cast(uint32_t, a), bb = __builtin_bit_cast(uint32_t, b);
+        if (ab != bb && !(a != a && b != b)) {  // NaN payloads aside
+            ++bad;
+            atomicMin(first_bad, bits);
+        }
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+hipError_t launch_selftest_sqrt(uint32_t first_bits, uint64_t count, unsigned long long *mismatches, uint32_t *first_bad, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_selftest_sqrt, dim3(4096), dim3(256), 0, s, first_bits, count, mismatches, first_bad);
+    return hipGetLastError();
+}
 }  // namespace tl

@@ -190,6 +190,22 @@ extern "C" int tl_dm_build_dev(tl_ctx *c, const float *d_xy, uint32_t n, int dis
     return TL_OK;
 }
 
+extern "C" int tl_selftest_sqrt(tl_ctx *c, uint32_t first_bits, uint64_t count, uint64_t *mismatches, uint32_t *first_bad_bits)
+{
+    if (!c || !mismatches) return fail(c, TL_ERR_BADARG, "tl_selftest_sqrt: NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->misc, 16))) return rc;
+    unsigned long long h[2] = {0ull, 0xFFFFFFFFull};
+    HIPCHK(c, hipMemcpyAsync(c->misc.p, h, 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_selftest_sqrt(first_bits, count, (unsigned long long *)c->misc.p, (uint32_t *)((char *)c->misc.p + 8), c->stream));
+    HIPCHK(c, hipMemcpyAsync(h, c->misc.p, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *mismatches = h[0];
+    if (first_bad_bits) *first_bad_bits = (uint32_t)h[1];
+    return TL_OK;
+}
+
 extern "C" int tl_dm_build(tl_ctx *c, const float *xy, uint32_t n, int dist, int layout, float *out_host, double *kernel_ms)
 {
     if (!c || !xy) return fail(c, TL_ERR_BADARG, "tl_dm_build: NULL argument");

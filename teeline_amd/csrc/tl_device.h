@@ -21,10 +21,27 @@ __device__ __forceinline__ float sqdist(float2 p, float2 q)
     return dx * dx + dy * dy;
 }
 
-// Correctly rounded f32 sqrt.  hipcc (-fhip-fp32-correctly-rounded-divide-sqrt, default on) expands
-// this to v_sqrt_f32 plus a +-1ulp FMA fix-up; tests/test_gpu_numerics.py checks it bit-for-bit
-// against the host's sqrtf over a dense sample of all binades.
-__device__ __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }
+// Correctly rounded f32 sqrt, the compiler's way: hipcc (-fhip-fp32-correctly-rounded-divide-sqrt, default on)
+// expands this to a 2^32 pre-scale for tiny inputs, v_sqrt_f32, a +-1 ulp FMA fix-up, the un-scale and a zero/inf
+// select (~17 VALU).
+__device__ __forceinline__ float sqrt_rn_ref(float x) { return __builtin_sqrtf(x); }
+
+// The same algorithm without the scaling: v_sqrt_f32 (<= 1 ulp), then pick among y-1ulp, y, y+1ulp with two exact FMA
+// residuals (r = x - y'*y).  Valid for x = 0, +inf and every x >= 2^-96 (where v_sqrt_f32 needs no denormal help);
+// smaller non-zero inputs take the compiler's full expansion under a wave-uniform branch.  ~9 VALU.
+// tl_selftest_sqrt compares it with sqrt_rn_ref over whole bit-pattern ranges on the device (tests/test_gpu_numerics.py
+// sweeps all 2^31 non-negative floats).
+__device__ __forceinline__ float sqrt_rn(float x)
+{
+    if (__builtin_amdgcn_ballot_w64((x < 1.2621774e-29f) & (x != 0.0f))) return sqrt_rn_ref(x);  // 2^-96
+    const float y = __builtin_amdgcn_sqrtf(x);
+    const int yi = __builtin_bit_cast(int, y);
+    const float yd = __builtin_bit_cast(float, yi - 1), yu = __builtin_bit_cast(float, yi + 1);
+    const float rd = __builtin_fmaf(-yd, y, x), ru = __builtin_fmaf(-yu, y, x);
+    float r = (rd <= 0.0f) ? yd : y;
+    r = (ru > 0.0f) ? yu : r;
+    return r;
+}
 
 __device__ __forceinline__ float dist(float2 p, float2 q) { return sqrt_rn(sqdist(p, q)); }
 
