@@ -74,9 +74,10 @@ static constexpr uint32_t kMaxChainHits = 16;  // hits one wave may chain inside
 // to the key slot.  Only the list of the wave that owns the globally first hit is used afterwards.
 template <bool PRUNE, bool CHAIN>
 __device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint32_t i, uint32_t tb, uint32_t jmin,
-                                               float ax, float ay, float bx, float by, uint32_t *hl,
-                                               uint32_t *keyslot, int lane)
+                                               float ax, float ay, float bx, float by, float sqab, float dab_a,
+                                               uint32_t *hl, uint32_t *keyslot, int lane)
 {
+    // sqab = sq(a, b) and (CHAIN only) dab_a = v_sqrt_f32(sqab) are row constants the caller already holds
     const uint32_t j = tb + (uint32_t)lane;
     const float2 c = P[j], e = P[j + 1u];
     const float sqce = sqdist(c, e);
@@ -94,9 +95,6 @@ __device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint
     uint32_t from = jmin, nh = 0, hitv = 0;  // lane h of hitv holds the h-th hit column
     for (;;) {
         // one straight-line pass per value of b: L1, L2 and the rare L3 for the lanes at or after `from`
-        dx = ax - bx;
-        dy = ay - by;
-        const float sqab = dx * dx + dy * dy;
         dx = bx - e.x;
         dy = by - e.y;
         const float s2 = dx * dx + dy * dy;
@@ -110,7 +108,8 @@ __device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint
                 dce_a = __builtin_amdgcn_sqrtf(sqce);
             }
             const float neu_a = dac_a + __builtin_amdgcn_sqrtf(s2);          // L2
-            const float cur_a = __builtin_amdgcn_sqrtf(sqab) + dce_a;
+            if (!CHAIN) dab_a = __builtin_amdgcn_sqrtf(sqab);
+            const float cur_a = dab_a + dce_a;
             const float margin = cur_a * 1.9073486e-6f;                      // 2^-19
             imp = test & (neu_a < cur_a - margin);
             const bool tie = test & !imp & ((neu_a <= cur_a + margin) | (fminf(smin0, fminf(s2, sqab)) < 1e-30f) | !(cur_a < 3.0e38f));
@@ -138,6 +137,10 @@ __device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint
         if (!CHAIN) return nh;  // pruned mode: the first improving column of this (row, tile) is all that is needed
         bx = readlane_f(c.x, l);  // new p[i+1] = old p[j]
         by = readlane_f(c.y, l);
+        dx = ax - bx;
+        dy = ay - by;
+        sqab = dx * dx + dy * dy;
+        dab_a = __builtin_amdgcn_sqrtf(sqab);
         from = jh + 1u;
         if (nh >= kMaxChainHits || l == 63) break;
     }

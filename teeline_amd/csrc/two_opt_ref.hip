@@ -204,7 +204,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #ifdef TL_PROFILE
                             ++livetiles;
 #endif
-                            if (dense_tile<PRUNE, false>(P, n, i, t << 6, jmin, ax, ay, bx, by, nullptr, keyslot, lane)) {
+                            if (dense_tile<PRUNE, false>(P, n, i, t << 6, jmin, ax, ay, bx, by, sqab, 0.0f, nullptr, keyslot, lane)) {
                                 m = 0;  // later tiles of this row are later columns
                                 row_hit = true;
                             }
@@ -223,12 +223,13 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             const uint32_t i = i0, t0 = j0 >> 6;
             const float ax = readlane_f(rp.x, 0), ay = readlane_f(rp.y, 0);
             const float bx = readlane_f(rp.x, 1), by = readlane_f(rp.y, 1);
+            const float sqab = readlane_f(rowsq, 0), dab_a = __builtin_amdgcn_sqrtf(sqab);
             if ((uint32_t)wave < kDenseLead && t0 + (uint32_t)wave <= last_tile) {
                 const uint32_t t = t0 + (uint32_t)wave;
 #ifdef TL_PROFILE
                 ++livetiles;
 #endif
-                dense_tile<PRUNE, true>(P, n, i, t << 6, j0, ax, ay, bx, by, queues + (t & 15u) * kQCap, keyslot, lane);
+                dense_tile<PRUNE, true>(P, n, i, t << 6, j0, ax, ay, bx, by, sqab, dab_a, queues + (t & 15u) * kQCap, keyslot, lane);
             }
             __syncthreads();
             if ((uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot) == kNoKey) {
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #ifdef TL_PROFILE
                     ++livetiles;
 #endif
-                    if (dense_tile<PRUNE, true>(P, n, i, t << 6, j0, ax, ay, bx, by, queues + (t & 15u) * kQCap, keyslot, lane)) break;
+                    if (dense_tile<PRUNE, true>(P, n, i, t << 6, j0, ax, ay, bx, by, sqab, dab_a, queues + (t & 15u) * kQCap, keyslot, lane)) break;
                 }
             }
         }
@@ -275,24 +276,32 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                     const uint32_t t2 = t + NT;
                     const bool two = t2 < half;
                     const float2 x = P[lo + t], y = P[hi - t];
+#ifndef TL_X_NOPERM
                     const uint16_t u = perm[lo + t], v = perm[hi - t];
-                    float2 x2 = x, y2 = y;
                     uint16_t u2 = u, v2 = v;
+#endif
+                    float2 x2 = x, y2 = y;
                     if (two) {
                         x2 = P[lo + t2];
                         y2 = P[hi - t2];
+#ifndef TL_X_NOPERM
                         u2 = perm[lo + t2];
                         v2 = perm[hi - t2];
+#endif
                     }
                     P[lo + t] = y;
                     P[hi - t] = x;
+#ifndef TL_X_NOPERM
                     perm[lo + t] = v;
                     perm[hi - t] = u;
+#endif
                     if (two) {
                         P[lo + t2] = y2;
                         P[hi - t2] = x2;
+#ifndef TL_X_NOPERM
                         perm[lo + t2] = v2;
                         perm[hi - t2] = u2;
+#endif
                     }
                 }
                 __syncthreads();
