@@ -114,12 +114,12 @@ __device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint
             imp = test & (neu_a < cur_a - margin);
             const bool tie = test & !imp & ((neu_a <= cur_a + margin) | (fminf(smin0, fminf(s2, sqab)) < 1e-30f) | !(cur_a < 3.0e38f));
             if (__builtin_amdgcn_ballot_w64(tie)) {                          // L3
-                // the opaque copies keep the compiler from hoisting the loop-invariant exact sqrt of s1 / sqce into
-                // the tile prologue, where every tile would pay ~40 VALU for a path that almost never runs
-                float s1v = s1, scev = sqce;
-                asm volatile("" : "+v"(s1v), "+v"(scev));
+                // the opaque copies keep the compiler from hoisting the loop-invariant exact sqrt of s1 / sqce / sq(a,b)
+                // into the tile or row prologue, where every tile (row) would pay ~40 VALU for a path that almost never runs
+                float s1v = s1, scev = sqce, sabv = sqab;
+                asm volatile("" : "+v"(s1v), "+v"(scev), "+v"(sabv));
                 const float neu = sqrt_rn(s1v) + sqrt_rn(s2);
-                const float cur = sqrt_rn(sqab) + sqrt_rn(scev);
+                const float cur = sqrt_rn(sabv) + sqrt_rn(scev);
                 imp = tie ? (neu < cur) : imp;
             }
         } else {
