@@ -155,4 +155,54 @@ __device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint
 }
 
 
+// The single-shot form of dense_tile for pruned mode (and the chip-wide scans): the improving columns of row (a, b)
+// inside one 64-wide j tile as a lane mask.  Straight-line code, every branch wave-uniform, the result in SGPRs.
+template <bool PRUNE>
+__device__ __forceinline__ uint64_t tile_improving_mask(const float2 *P, uint32_t n, uint32_t tb, uint32_t jmin,
+                                                        float ax, float ay, float bx, float by, float sqab, int lane)
+{
+    const uint32_t j = tb + (uint32_t)lane;
+    const float2 c = P[j], e = P[j + 1u];
+    const float sqce = sqdist(c, e);
+    float dx = ax - c.x, dy = ay - c.y;
+    const float s1 = dx * dx + dy * dy;
+    dx = bx - e.x;
+    dy = by - e.y;
+    const float s2 = dx * dx + dy * dy;
+    bool test = (j + 2u <= n) & (j >= jmin);
+    bool imp;
+    if (PRUNE) {
+        test = test & ((s1 < sqab) | (s2 < sqce));                       // L1
+        if (!__builtin_amdgcn_ballot_w64(test)) return 0;                // the common case
+        const float neu_a = __builtin_amdgcn_sqrtf(s1) + __builtin_amdgcn_sqrtf(s2);  // L2
+        const float cur_a = __builtin_amdgcn_sqrtf(sqab) + __builtin_amdgcn_sqrtf(sqce);
+        const float margin = cur_a * 1.9073486e-6f;                      // 2^-19
+        imp = test & (neu_a < cur_a - margin);
+        const bool tie = test & !imp & ((neu_a <= cur_a + margin) | (fminf(fminf(s1, sqce), fminf(s2, sqab)) < 1e-30f) | !(cur_a < 3.0e38f));
+        if (__builtin_amdgcn_ballot_w64(tie)) {                          // L3
+            float s1v = s1, scev = sqce, sabv = sqab;
+            asm volatile("" : "+v"(s1v), "+v"(scev), "+v"(sabv));      // keep the exact roots inside this branch
+            const float neu = sqrt_rn(s1v) + sqrt_rn(s2);
+            const float cur = sqrt_rn(sabv) + sqrt_rn(scev);
+            imp = tie ? (neu < cur) : imp;
+        }
+    } else {
+        const float neu = sqrt_rn(s1) + sqrt_rn(s2);
+        const float cur = sqrt_rn(sqab) + sqrt_rn(sqce);
+        imp = test & (neu < cur);  // two_opt.rs:35-49
+    }
+    return __builtin_amdgcn_ballot_w64(imp);
+}
+
+template <bool PRUNE>
+__device__ __forceinline__ bool tile_first_hit(const float2 *P, uint32_t n, uint32_t i, uint32_t tb, uint32_t jmin,
+                                               float ax, float ay, float bx, float by, float sqab,
+                                               uint32_t *keyslot, int lane)
+{
+    const uint64_t m = tile_improving_mask<PRUNE>(P, n, tb, jmin, ax, ay, bx, by, sqab, lane);
+    if (m == 0) return false;
+    if (lane == 0) atomicMin(keyslot, (i << 16) | (tb + (uint32_t)(__builtin_ffsll((long long)m) - 1)));
+    return true;
+}
+
 }  // namespace tl

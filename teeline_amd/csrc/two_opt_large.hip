@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kRlWaves * 64) void k_rl_scan(LargeTwoOptArgs A)
         while (m) {
             const uint32_t t = (g << 6) + (uint32_t)(__builtin_ffsll((long long)m) - 1);
             m &= m - 1;
-            if (dense_tile<true, false>(P, n, i, t << 6, jmin, a.x, a.y, b.x, b.y, sqab, 0.0f, nullptr, &S->key, lane)) return;
+            if (tile_first_hit<true>(P, n, i, t << 6, jmin, a.x, a.y, b.x, b.y, sqab, &S->key, lane)) return;
         }
     }
 }

@@ -196,18 +196,22 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 for (int gI = 0; gI < kMaxGroups; ++gI) {
                     if (gI < G && (((uint32_t)gI + 1u) << 6) > tmin) {  // groups wholly before the row's first column: nothing to test
                         const uint32_t tl = ((uint32_t)gI << 6) + (uint32_t)lane;
-                        const bool live = (tl >= tmin) && ((box_lb(ax, ay, box[gI]) < sqab) || (box_lb(bx, by, box[gI]) < msq[gI]));
+                        const bool near_a = box_lb(ax, ay, box[gI]) < sqab, near_b = box_lb(bx, by, box[gI]) < msq[gI];
+                        const bool live = (tl >= tmin) & (near_a | near_b);  // no short-circuit: both bounds are cheaper than a branch
                         uint64_t m = __builtin_amdgcn_ballot_w64(live);
-                        while (m) {
-                            const uint32_t t = ((uint32_t)gI << 6) + (uint32_t)(__builtin_ffsll((long long)m) - 1);
+                        uint64_t hm = 0;
+                        uint32_t t = 0;
+                        while (m != 0 && hm == 0) {  // later tiles of this row are later columns
+                            t = ((uint32_t)gI << 6) + (uint32_t)(__builtin_ffsll((long long)m) - 1);
                             m &= m - 1;
 #ifdef TL_PROFILE
                             ++livetiles;
 #endif
-                            if (dense_tile<PRUNE, false>(P, n, i, t << 6, jmin, ax, ay, bx, by, sqab, 0.0f, nullptr, keyslot, lane)) {
-                                m = 0;  // later tiles of this row are later columns
-                                row_hit = true;
-                            }
+                            hm = tile_improving_mask<PRUNE>(P, n, t << 6, jmin, ax, ay, bx, by, sqab, lane);
+                        }
+                        if (hm) {
+                            if (lane == 0) atomicMin(keyslot, (i << 16) | ((t << 6) + (uint32_t)(__builtin_ffsll((long long)hm) - 1)));
+                            row_hit = true;
                         }
                     }
                     if (row_hit) break;
