@@ -178,6 +178,14 @@ int tl_two_opt_multistart(tl_ctx *ctx, const float *xy, uint32_t n, uint64_t see
                           uint32_t *out_best_restart, float *out_costs, tl_stats *stats);
 /* (float_bits(cost) << 32) | restart: order-preserving for cost >= 0, ties -> lowest restart. */
 uint64_t tl_pack_cost_key(float cost, uint32_t restart);
+/* A population of `count` explicit tours (init_pos: count x n positions), each refined by its own
+ * REF_ORDER descent, one workgroup per tour, all concurrently; tour r of out_pos / out_costs equals what
+ * tl_two_opt returns for it alone (two_opt.rs:7-67 with init_tour = Some(tour r)).  The reference has no
+ * batch form: its callers loop over two_opt::solve (the north-star's GA refinement would, too).
+ * dm_packed as in tl_two_opt.  n is limited to tl_two_opt_lds_max_n (TL_ERR_UNSUPPORTED beyond). */
+int tl_two_opt_population(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed,
+                          const uint32_t *init_pos, uint32_t count, uint32_t *out_pos, float *out_costs,
+                          tl_stats *stats);
 
 /* ---- device-resident batch entry (bench / pipelines that keep data in HBM) ------------------- */
 /* All d_* are DEVICE pointers on the context's device.  d_init: count x n u32 (NULL: seeded restarts

@@ -499,6 +499,51 @@ extern "C" int tl_two_opt_multistart(tl_ctx *c, const float *xy, uint32_t n, uin
     return TL_OK;
 }
 
+// A population of explicit tours, each refined by its own REF_ORDER descent (one workgroup per individual): what a
+// memetic GA or any caller holding several seeds needs; every individual's result equals tl_two_opt on it alone.
+extern "C" int tl_two_opt_population(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
+                                     uint32_t count, uint32_t *out_pos, float *out_costs, tl_stats *stats)
+{
+    if (!c || (!xy && !dm_packed) || !init_pos || !out_pos) return fail(c, TL_ERR_BADARG, "tl_two_opt_population: NULL argument");
+    if (count == 0) return fail(c, TL_ERR_BADARG, "tl_two_opt_population: count == 0");
+    if (n < 3) return fail(c, TL_ERR_REF_PANICS, "two_opt: n=%u < 3", n);
+    for (uint32_t r = 0; r < count; ++r)
+        if (!is_permutation(init_pos + (size_t)r * n, n))
+            return fail(c, TL_ERR_BADARG, "tl_two_opt_population: tour %u is not a permutation of 0..n-1", r);
+    const auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    const size_t dm_bytes = dm_packed ? (size_t)n * (n - 1) / 2 * 4 : 0;
+    if ((rc = ensure(c, c->init, (size_t)count * n * 4)) || (rc = ensure(c, c->out_pos, (size_t)count * n * 4)) ||
+        (rc = ensure(c, c->out_cost, (size_t)count * 4)) || (rc = ensure(c, c->out_stats, (size_t)count * TL_STATS_STRIDE * 8)))
+        return rc;
+    if (dm_packed) {
+        if ((rc = ensure(c, c->dm, dm_bytes))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->dm.p, dm_packed, dm_bytes, hipMemcpyHostToDevice, c->stream));
+    } else {
+        if ((rc = ensure(c, c->xy, (size_t)n * 8))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->init.p, init_pos, (size_t)count * n * 4, hipMemcpyHostToDevice, c->stream));
+    if ((rc = two_opt_enqueue(c, dm_packed ? nullptr : (const float2 *)c->xy.p, dm_packed ? (const float *)c->dm.p : nullptr, n,
+                              (const uint32_t *)c->init.p, TL_INIT_ARRAY, 0, 0, count, TL_MODE_REF_ORDER, (uint32_t *)c->out_pos.p,
+                              (float *)c->out_cost.p, (uint64_t *)c->out_stats.p, c->stream)))
+        return rc;
+    std::vector<uint64_t> raw((size_t)count * TL_STATS_STRIDE);
+    HIPCHK(c, hipMemcpyAsync(out_pos, c->out_pos.p, (size_t)count * n * 4, hipMemcpyDeviceToHost, c->stream));
+    std::vector<float> costs(count);
+    HIPCHK(c, hipMemcpyAsync(costs.data(), c->out_cost.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(raw.data(), c->out_stats.p, (size_t)count * TL_STATS_STRIDE * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint32_t r = 0; r < count; ++r)
+        if (raw[TL_STATS_STRIDE * r + 3] != 0) return fail(c, TL_ERR_NO_CONVERGE, "two_opt: sweep cap reached in tour %u", r);
+    if (out_costs) memcpy(out_costs, costs.data(), (size_t)count * 4);
+    double kms = 0;
+    tl_last_kernel_ms(c, &kms);
+    fill_stats(stats, n, raw.data(), count, kms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    return TL_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // 2-opt, TL_MODE_BEST_SWEEP (this build's own mode; specification: oracle tlo_two_opt_best)
 // ------------------------------------------------------------------------------------------------

@@ -54,3 +54,28 @@ def multistart(problem, restarts, seed=0, first=0, *, ctx=None, mode=_capi.TL_MO
     stats["best_restart"] = best.value
     sol = Solution(cost.value, problem.ids[out], problem, stats)
     return (sol, costs) if return_costs else sol
+
+
+def solve_population(problem, init_tours, *, ctx=None):
+    """Refine a population of tours (lists of city ids), each by its own two_opt::solve descent, all concurrently
+    (tl_two_opt_population).  Returns one Solution per tour; Solution k equals solve(problem, None, None, init_tours[k])."""
+    from . import Solution, default_context
+    ctx = ctx or default_context()
+    n = len(problem)
+    count = len(init_tours)
+    init = np.empty((count, n), dtype=np.uint32)
+    for k, tour in enumerate(init_tours):
+        pos = problem.positions_of(tour)
+        if len(pos) != n:
+            raise _capi.TeelineGpuError(_capi.TL_ERR_BADARG, f"tour {k}: length differs from the number of cities")
+        init[k] = pos
+    packed = problem.explicit_packed()
+    out = np.empty((count, n), dtype=np.uint32)
+    costs = np.empty(count, dtype=np.float32)
+    st = _capi.TlStats()
+    ctx.check(ctx.lib.tl_two_opt_population(ctx.handle, problem.xy.ctypes.data_as(C.c_void_p), n,
+                                            None if packed is None else packed.ctypes.data_as(C.c_void_p),
+                                            init.ctypes.data_as(C.c_void_p), count, out.ctypes.data_as(C.c_void_p),
+                                            costs.ctypes.data_as(C.c_void_p), C.byref(st)))
+    stats = st.as_dict()
+    return [Solution(float(costs[k]), problem.ids[out[k]], problem, stats) for k in range(count)]

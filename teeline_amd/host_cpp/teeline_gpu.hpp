@@ -202,6 +202,29 @@ inline Solution solve(Context &ctx, const TspProblem &problem, const HeuristicOp
     ctx.check(tl_two_opt(ctx.get(), xy.data(), n, problem.explicit_packed(), init_tour ? init.data() : nullptr, mode, out.data(), &cost, &st));
     return detail::finish(problem, out, cost, st, progress_tx);
 }
+
+// A population of tours, each refined by its own descent, all concurrently (tl_two_opt_population);
+// element k equals solve(ctx, problem, {}, nullptr, &init_tours[k]).
+inline std::vector<Solution> solve_population(Context &ctx, const TspProblem &problem, const std::vector<std::vector<size_t>> &init_tours)
+{
+    const auto xy = problem.xy();
+    const uint32_t n = (uint32_t)problem.cities.size(), count = (uint32_t)init_tours.size();
+    std::vector<uint32_t> init((size_t)count * n), out((size_t)count * n);
+    for (uint32_t k = 0; k < count; ++k) {
+        const auto pos = problem.positions_of(init_tours[k]);
+        if (pos.size() != n) throw std::runtime_error("solve_population: tour length differs from the number of cities");
+        std::copy(pos.begin(), pos.end(), init.begin() + (size_t)k * n);
+    }
+    std::vector<float> costs(count);
+    tl_stats st{};
+    ctx.check(tl_two_opt_population(ctx.get(), xy.data(), n, problem.explicit_packed(), init.data(), count, out.data(), costs.data(), &st));
+    std::vector<Solution> res;
+    for (uint32_t k = 0; k < count; ++k) {
+        std::vector<uint32_t> one(out.begin() + (size_t)k * n, out.begin() + (size_t)(k + 1) * n);
+        res.push_back(detail::finish(problem, one, costs[k], st, nullptr));
+    }
+    return res;
+}
 }  // namespace two_opt
 
 namespace three_opt {  // three_opt.rs:16-51

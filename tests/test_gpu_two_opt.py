@@ -299,3 +299,34 @@ def test_device_resident_batch_entry_with_explicit_starts(ctx):
         assert d_pos[r].cpu().numpy().astype(np.uint32).tolist() == p.tolist()
         assert np.float32(d_cost[r].item()).tobytes() == np.float32(c).tobytes()
         assert (int(d_stats[r, 0]), int(d_stats[r, 1]), int(d_stats[r, 2]), int(d_stats[r, 3])) == (st["sweeps"], st["moves"], st["reversed"], 0)
+
+
+def test_population_equals_individual_descents(ctx):
+    """tl_two_opt_population: every tour of a batch gets exactly the descent tl_two_opt / the oracle gives it alone."""
+    import teeline_amd as TA
+    n, count = 700, 9
+    xy = O.synth_xy(n, seed=4242)
+    prob = TA.TspProblem(np.arange(10, 10 + n), xy)  # ids != positions
+    inits = [O.restart_perm(n, 99, r) for r in range(count - 1)] + [np.arange(n, dtype=np.uint32)]
+    sols = TA.two_opt.solve_population(prob, [(p + 10).tolist() for p in inits], ctx=ctx)
+    assert len(sols) == count
+    for p, sol in zip(inits, sols):
+        rc, route, cost, st = O.two_opt(xy, None, n, init=p)
+        assert rc == 0
+        assert [int(v) - 10 for v in sol.route()] == route.tolist()
+        assert np.float32(sol.total).tobytes() == np.float32(cost).tobytes()
+    assert sols[0].stats["moves"] == sum(O.two_opt(xy, None, n, init=p)[3]["moves"] for p in inits)
+
+
+def test_population_explicit_matrix_and_bad_input(ctx, tsplib_dir):
+    import teeline_amd as TA
+    prob = TA.tsplib.read_from_file(os.path.join(tsplib_dir, "gr17.tsp")).problem()
+    n = len(prob)
+    ids = [int(v) for v in prob.ids]
+    tours = [ids, ids[::-1], ids[5:] + ids[:5]]
+    sols = TA.two_opt.solve_population(prob, tours, ctx=ctx)
+    for t, sol in zip(tours, sols):
+        one = TA.two_opt.solve(prob, None, None, t, ctx=ctx)
+        assert list(sol.route()) == list(one.route()) and float(sol.total) == float(one.total)
+    with pytest.raises(TA.TeelineGpuError):
+        TA.two_opt.solve_population(prob, [ids, ids[:-1] + [ids[0]]], ctx=ctx)  # second tour repeats a city
