@@ -182,10 +182,32 @@ def main():
             "traffic": None,
             "kernel": "k_two_opt_ref_lds", "kernel_ms_avg": k_ms, "launches": a.steps,
             "algorithmic_bytes_per_candidate": ALG_BYTES_PER_CANDIDATE,
-            "note": "algorithmic bytes = 8 B per candidate (SURVEY.md §8(d)); the tour lives in LDS for the whole descent, so real "
-                    "HBM traffic is ~n*(8+4) B per restart and the kernel is VALU/LDS/latency-bound, not HBM-bound (DESIGN.md §5)",
+            "note": "algorithmic bytes = 8 B per candidate (SURVEY.md §8(d)) as the contract defines `achieved`; the tour lives in LDS "
+                    "for the whole descent and the L0/L1 bounds discard most candidates without touching them, so `frac` can "
+                    "exceed 1 and says nothing about HBM: real HBM traffic is `traffic` (~13 MB per launch). What binds the kernel "
+                    "is per-SIMD instruction issue, LDS bandwidth of the segment reversals and workgroup barriers (`binding`, "
+                    "DESIGN.md §4.2)",
         },
     }
+    spath = os.path.join(ROOT, "profiles", "r01_pmc_sq_two_opt.csv")
+    if os.path.exists(spath) and n == 10000 and R == 256:
+        try:
+            sq = {}
+            for line in open(spath).read().strip().splitlines()[1:]:
+                name, val, _ = line.split(",")
+                sq[name] = float(val)
+            wc = sq["SQ_WAVE_CYCLES"]
+            out["roofline"]["binding"] = {
+                "source": "profiles/r01_pmc_sq_two_opt.csv (rocprofv3 --pmc SQ_*, one launch)",
+                "waves_per_simd": 4,
+                "valu_active_frac_per_wave": sq.get("SQ_ACTIVE_INST_VALU", 0.0) / wc,
+                "valu_busy_frac_per_simd_est": 4 * sq.get("SQ_ACTIVE_INST_VALU", 0.0) / wc,
+                "wave_parked_frac": sq.get("SQ_WAIT_ANY", 0.0) / wc,
+                "issue_stall_frac": sq.get("SQ_WAIT_INST_ANY", 0.0) / wc,
+                "lds_active_frac_per_wave": sq.get("SQ_ACTIVE_INST_LDS", 0.0) / wc,
+            }
+        except Exception:
+            pass
     # traffic from a committed PMC pass, if one exists for this round
     tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
     if os.path.exists(tpath) and n == 10000 and R == 256:
