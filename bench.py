@@ -116,14 +116,25 @@ def main():
     d_stats = torch.zeros((R, _capi.TL_DEV_STATS_STRIDE), dtype=torch.int64, device=dev)
     first, _ = TA.multistart.shard(rank, R)
     per_sweep = (n - 3) * (n - 2) // 2
-    stream = torch.cuda.current_stream()
+    # Everything of a step is enqueued on ONE explicit stream: the descent kernel (through the C ABI), the key packing
+    # and the collective.  (A NULL stream would mean the context's own non-blocking stream, unordered with torch's.)
+    stream = torch.cuda.Stream(device=dev)
+    sweeps_dev = torch.zeros((), dtype=torch.int64, device=dev)
+    stream.wait_stream(torch.cuda.current_stream())
 
-    def step():
-        ctx.check(lib.tl_two_opt_batch_dev(h, d_xy.data_ptr(), n, None, a.seed, first, R, _capi.TL_MODE_REF_ORDER,
-                                           d_pos.data_ptr(), d_cost.data_ptr(), d_stats.data_ptr(),
-                                           C.c_void_p(stream.cuda_stream)))
-        # RCCL over xGMI: one 8-byte min-all-reduce per round
-        return TA.multistart.allreduce_best(TA.multistart.pack_keys(d_cost, first), dist)
+    def step(count_it=False, events=None):
+        with torch.cuda.stream(stream):
+            if events is not None:
+                events[0].record(stream)
+            ctx.check(lib.tl_two_opt_batch_dev(h, d_xy.data_ptr(), n, None, a.seed, first, R, _capi.TL_MODE_REF_ORDER,
+                                               d_pos.data_ptr(), d_cost.data_ptr(), d_stats.data_ptr(),
+                                               C.c_void_p(stream.cuda_stream)))
+            if events is not None:
+                events[1].record(stream)
+            if count_it:
+                sweeps_dev.add_(d_stats[:, 0].sum())
+            # RCCL over xGMI: one 8-byte min-all-reduce per round
+            return TA.multistart.allreduce_best(TA.multistart.pack_keys(d_cost, first), dist)
 
     def sync():
         torch.cuda.synchronize()
@@ -132,18 +143,22 @@ def main():
             torch.cuda.synchronize()
 
     if dist is not None:  # RCCL communicator set-up (lazy on the first collective) is not part of any timed step
-        dist.all_reduce(torch.zeros(1, dtype=torch.int64, device=dev), op=dist.ReduceOp.MIN)
-    for _ in range(a.warmup):
-        step()
+        with torch.cuda.stream(stream):
+            dist.all_reduce(torch.zeros(1, dtype=torch.int64, device=dev), op=dist.ReduceOp.MIN)
+    for _ in range(max(a.warmup, 0)):
+        step(count_it=True)
     sync()
-    kernel_ms, cands = [], 0
+    sweeps_dev.zero_()
+    sync()
+    # HIP events around every launch, on the stream the kernel is launched on
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        key = step()
-        kernel_ms.append(ctx.last_kernel_ms())       # HIP events on the launch stream (syncs on the end event)
-        cands += int(d_stats[:, 0].sum().item()) * per_sweep
+    for k in range(a.steps):
+        key = step(count_it=True, events=evs[k])
     sync()
     dt = time.perf_counter() - t0
+    kernel_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
+    cands = int(sweeps_dev.item()) * per_sweep
 
     total, dt_max = TA.multistart.aggregate_throughput(cands, dt, dev, dist)
     best_cost, best_restart = TA.multistart.unpack_key(key.item())

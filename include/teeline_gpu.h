@@ -190,8 +190,10 @@ int tl_two_opt_population(tl_ctx *ctx, const float *xy, uint32_t n, const float 
 /* ---- device-resident batch entry (bench / pipelines that keep data in HBM) ------------------- */
 /* All d_* are DEVICE pointers on the context's device.  d_init: count x n u32 (NULL: seeded restarts
  * first..first+count as above; seed ignored otherwise).  d_out_pos: count x n u32, d_out_cost: count f32,
- * d_out_stats: count x TL_DEV_STATS_STRIDE u64 {sweeps, moves, reversed, status, steps, reserved...}.  stream: hipStream_t or NULL for the
- * context's stream.  Asynchronous: returns after enqueueing. */
+ * d_out_stats: count x TL_DEV_STATS_STRIDE u64 {sweeps, moves, reversed, status, steps, reserved...}.  stream: the hipStream_t to enqueue on,
+ * or NULL for the context's own stream — which is NON-BLOCKING, i.e. not ordered with the legacy default stream: a
+ * caller that passes NULL must wait on tl_last_kernel_ms() (or a device synchronise) before touching the outputs.
+ * Asynchronous: returns after enqueueing. */
 int tl_two_opt_batch_dev(tl_ctx *ctx, const float *d_xy, uint32_t n, const uint32_t *d_init,
                          uint64_t seed, uint32_t first, uint32_t count, int mode, uint32_t *d_out_pos,
                          float *d_out_cost, uint64_t *d_out_stats, void *stream);
