@@ -66,103 +66,13 @@ __device__ __forceinline__ float box_lb(float px, float py, float4 box)
 static constexpr uint32_t kDenseLead = TL_DENSE_LEAD;  // waves active in round 1 of a dense step
 static constexpr uint32_t kMaxChainHits = 16;  // hits one wave may chain inside its tile before handing back
 
-// One row (a, b) against one 64-wide j tile held in registers, decided inline by the L1 -> L2 -> L3 cascade.
-// All improving moves of the reference's scan INSIDE this tile are chained here without leaving the wave:
-// after a hit at lane l the row's b becomes the old P[j] (two_opt.rs:50 reverses p[i+1..=j], so p[i+1] := p[j]),
-// positions > j are untouched, hence lanes > l are simply re-decided against the new b.  Hits are recorded in
-// `hl` (hl[0] = count, hl[1] = column at which the scan resumes, hl[2..] = hit columns); the first one is posted
-// to the key slot.  Only the list of the wave that owns the globally first hit is used afterwards.
-template <bool PRUNE, bool CHAIN>
-__device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint32_t i, uint32_t tb, uint32_t jmin,
-                                               float ax, float ay, float bx, float by, float sqab, float dab_a,
-                                               uint32_t *hl, uint32_t *keyslot, int lane)
-{
-    // sqab = sq(a, b) and (CHAIN only) dab_a = v_sqrt_f32(sqab) are row constants the caller already holds
-    const uint32_t j = tb + (uint32_t)lane;
-    const float2 c = P[j], e = P[j + 1u];
-    const float sqce = sqdist(c, e);
-    float dx = ax - c.x, dy = ay - c.y;
-    const float s1 = dx * dx + dy * dy;
-    const bool inrange = j + 2u <= n;
-    // chain mode re-enters the loop body per hit, so the b-independent L2 terms are taken once up front; the
-    // single-shot (pruned) mode rarely gets past L1 and computes them only then
-    float dac_a = 0.f, dce_a = 0.f;
-    if (CHAIN) {
-        dac_a = __builtin_amdgcn_sqrtf(s1);
-        dce_a = __builtin_amdgcn_sqrtf(sqce);
-    }
-    const float smin0 = fminf(s1, sqce);
-    uint32_t from = jmin, nh = 0, hitv = 0;  // lane h of hitv holds the h-th hit column
-    for (;;) {
-        // one straight-line pass per value of b: L1, L2 and the rare L3 for the lanes at or after `from`
-        dx = bx - e.x;
-        dy = by - e.y;
-        const float s2 = dx * dx + dy * dy;
-        bool test = inrange & (j >= from);
-        bool imp;
-        if (PRUNE) {
-            test = test & ((s1 < sqab) | (s2 < sqce));                       // L1
-            if (!__builtin_amdgcn_ballot_w64(test)) break;                   // the common case late in a sweep
-            if (!CHAIN) {
-                dac_a = __builtin_amdgcn_sqrtf(s1);
-                dce_a = __builtin_amdgcn_sqrtf(sqce);
-            }
-            const float neu_a = dac_a + __builtin_amdgcn_sqrtf(s2);          // L2
-            if (!CHAIN) dab_a = __builtin_amdgcn_sqrtf(sqab);
-            const float cur_a = dab_a + dce_a;
-            const float margin = cur_a * 1.9073486e-6f;                      // 2^-19
-            imp = test & (neu_a < cur_a - margin);
-            const bool tie = test & !imp & ((neu_a <= cur_a + margin) | (fminf(smin0, fminf(s2, sqab)) < 1e-30f) | !(cur_a < 3.0e38f));
-            if (__builtin_amdgcn_ballot_w64(tie)) {                          // L3
-                // the opaque copies keep the compiler from hoisting the loop-invariant exact sqrt of s1 / sqce / sq(a,b)
-                // into the tile or row prologue, where every tile (row) would pay ~40 VALU for a path that almost never runs
-                float s1v = s1, scev = sqce, sabv = sqab;
-                asm volatile("" : "+v"(s1v), "+v"(scev), "+v"(sabv));
-                const float neu = sqrt_rn(s1v) + sqrt_rn(s2);
-                const float cur = sqrt_rn(sabv) + sqrt_rn(scev);
-                imp = tie ? (neu < cur) : imp;
-            }
-        } else {
-            const float neu = sqrt_rn(s1) + sqrt_rn(s2);
-            const float cur = sqrt_rn(sqab) + sqrt_rn(sqce);
-            imp = test & (neu < cur);  // two_opt.rs:35-49
-        }
-        const uint64_t m = __builtin_amdgcn_ballot_w64(imp);
-        if (m == 0) break;
-        const int l = __builtin_ffsll((long long)m) - 1;
-        const uint32_t jh = tb + (uint32_t)l;
-        hitv = ((uint32_t)lane == nh) ? jh : hitv;
-        if (nh == 0 && lane == 0) atomicMin(keyslot, (i << 16) | jh);  // post at once: it stops the other waves' scans
-        ++nh;
-        if (!CHAIN) return nh;  // pruned mode: the first improving column of this (row, tile) is all that is needed
-        bx = readlane_f(c.x, l);  // new p[i+1] = old p[j]
-        by = readlane_f(c.y, l);
-        dx = ax - bx;
-        dy = ay - by;
-        sqab = dx * dx + dy * dy;
-        dab_a = __builtin_amdgcn_sqrtf(sqab);
-        from = jh + 1u;
-        if (nh >= kMaxChainHits || l == 63) break;
-    }
-    if (nh) {
-        if ((uint32_t)lane < nh) hl[2u + (uint32_t)lane] = hitv;
-        if (lane == 0) {
-            hl[0] = nh;
-            hl[1] = (nh >= kMaxChainHits) ? from : (tb + 64u);  // tile exhausted unless the chain was cut short
-        }
-    }
-    return nh;
-}
-
-
-// The single-shot form of dense_tile for pruned mode (and the chip-wide scans): the improving columns of row (a, b)
-// inside one 64-wide j tile as a lane mask.  Straight-line code, every branch wave-uniform, the result in SGPRs.
+// The improving columns of row (a, b) inside one 64-wide j tile (lane l holds c = P[tb+l], e = P[tb+l+1]) as a lane mask,
+// decided by the L1 -> L2 -> L3 cascade.  Straight-line code, every branch wave-uniform, the result in SGPRs.
+// sqab = sq(a, b) is a row constant the caller already holds.
 template <bool PRUNE>
-__device__ __forceinline__ uint64_t tile_improving_mask(const float2 *P, uint32_t n, uint32_t tb, uint32_t jmin,
-                                                        float ax, float ay, float bx, float by, float sqab, int lane)
+__device__ __forceinline__ uint64_t tile_mask_core(float2 c, float2 e, uint32_t j, uint32_t n, uint32_t jmin,
+                                                   float ax, float ay, float bx, float by, float sqab)
 {
-    const uint32_t j = tb + (uint32_t)lane;
-    const float2 c = P[j], e = P[j + 1u];
     const float sqce = sqdist(c, e);
     float dx = ax - c.x, dy = ay - c.y;
     const float s1 = dx * dx + dy * dy;
@@ -173,15 +83,17 @@ __device__ __forceinline__ uint64_t tile_improving_mask(const float2 *P, uint32_
     bool imp;
     if (PRUNE) {
         test = test & ((s1 < sqab) | (s2 < sqce));                       // L1
-        if (!__builtin_amdgcn_ballot_w64(test)) return 0;                // the common case
+        if (!__builtin_amdgcn_ballot_w64(test)) return 0;                // the common case late in a sweep
         const float neu_a = __builtin_amdgcn_sqrtf(s1) + __builtin_amdgcn_sqrtf(s2);  // L2
         const float cur_a = __builtin_amdgcn_sqrtf(sqab) + __builtin_amdgcn_sqrtf(sqce);
         const float margin = cur_a * 1.9073486e-6f;                      // 2^-19
         imp = test & (neu_a < cur_a - margin);
         const bool tie = test & !imp & ((neu_a <= cur_a + margin) | (fminf(fminf(s1, sqce), fminf(s2, sqab)) < 1e-30f) | !(cur_a < 3.0e38f));
         if (__builtin_amdgcn_ballot_w64(tie)) {                          // L3
+            // the opaque copies keep the compiler from hoisting the loop-invariant exact roots into a tile or row
+            // prologue, where every tile (row) would pay ~40 VALU for a path that almost never runs
             float s1v = s1, scev = sqce, sabv = sqab;
-            asm volatile("" : "+v"(s1v), "+v"(scev), "+v"(sabv));      // keep the exact roots inside this branch
+            asm volatile("" : "+v"(s1v), "+v"(scev), "+v"(sabv));
             const float neu = sqrt_rn(s1v) + sqrt_rn(s2);
             const float cur = sqrt_rn(sabv) + sqrt_rn(scev);
             imp = tie ? (neu < cur) : imp;
@@ -195,6 +107,14 @@ __device__ __forceinline__ uint64_t tile_improving_mask(const float2 *P, uint32_
 }
 
 template <bool PRUNE>
+__device__ __forceinline__ uint64_t tile_improving_mask(const float2 *P, uint32_t n, uint32_t tb, uint32_t jmin,
+                                                        float ax, float ay, float bx, float by, float sqab, int lane)
+{
+    const uint32_t j = tb + (uint32_t)lane;
+    return tile_mask_core<PRUNE>(P[j], P[j + 1u], j, n, jmin, ax, ay, bx, by, sqab);
+}
+
+template <bool PRUNE>
 __device__ __forceinline__ bool tile_first_hit(const float2 *P, uint32_t n, uint32_t i, uint32_t tb, uint32_t jmin,
                                                float ax, float ay, float bx, float by, float sqab,
                                                uint32_t *keyslot, int lane)
@@ -203,6 +123,44 @@ __device__ __forceinline__ bool tile_first_hit(const float2 *P, uint32_t n, uint
     if (m == 0) return false;
     if (lane == 0) atomicMin(keyslot, (i << 16) | (tb + (uint32_t)(__builtin_ffsll((long long)m) - 1)));
     return true;
+}
+
+// Dense mode: ALL improving moves of the reference's scan inside this tile, chained without leaving the wave.  After a hit
+// at lane l the row's b becomes the old P[j] (two_opt.rs:50 reverses p[i+1..=j], so p[i+1] := p[j]) and positions > j
+// are untouched, hence the lanes > l are simply decided again against the new b.  Hits are recorded in `hl`
+// (hl[0] = count, hl[1] = column at which the scan resumes, hl[2..] = hit columns); the first one is posted to the key
+// slot.  Only the list of the wave that owns the globally first hit is used afterwards.  Returns the number of hits.
+template <bool PRUNE>
+__device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint32_t i, uint32_t tb, uint32_t jmin,
+                                               float ax, float ay, float bx, float by, float sqab,
+                                               uint32_t *hl, uint32_t *keyslot, int lane)
+{
+    const uint32_t j = tb + (uint32_t)lane;
+    const float2 c = P[j], e = P[j + 1u];
+    uint64_t m = tile_mask_core<PRUNE>(c, e, j, n, jmin, ax, ay, bx, by, sqab);
+    if (m == 0) return 0;  // the common case: no chain state was ever set up
+    uint32_t from = jmin, nh = 0, hitv = 0;  // lane h of hitv holds the h-th hit column
+    for (;;) {
+        const int l = __builtin_ffsll((long long)m) - 1;
+        const uint32_t jh = tb + (uint32_t)l;
+        hitv = ((uint32_t)lane == nh) ? jh : hitv;
+        if (nh == 0 && lane == 0) atomicMin(keyslot, (i << 16) | jh);  // post at once: it stops the other waves' scans
+        ++nh;
+        from = jh + 1u;
+        if (nh >= kMaxChainHits || l == 63) break;
+        bx = readlane_f(c.x, l);  // new p[i+1] = old p[j]
+        by = readlane_f(c.y, l);
+        const float dx = ax - bx, dy = ay - by;
+        sqab = dx * dx + dy * dy;
+        m = tile_mask_core<PRUNE>(c, e, j, n, from, ax, ay, bx, by, sqab);
+        if (m == 0) break;
+    }
+    if ((uint32_t)lane < nh) hl[2u + (uint32_t)lane] = hitv;
+    if (lane == 0) {
+        hl[0] = nh;
+        hl[1] = (nh >= kMaxChainHits) ? from : (tb + 64u);  // tile exhausted unless the chain was cut short
+    }
+    return nh;
 }
 
 }  // namespace tl

@@ -35,10 +35,10 @@ namespace {
 
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 #ifndef TL_RMAX
-#define TL_RMAX 32
+#define TL_RMAX 63
 #endif
 #ifndef TL_DENSE_ROWS
-#define TL_DENSE_ROWS 12.0f
+#define TL_DENSE_ROWS 8.0f
 #endif
 constexpr int kRMax = TL_RMAX;        // rows per speculative block in pruned mode (<= 63: lane-resident row table)
 constexpr uint32_t kQCap = 128;       // u32 words per tile slot of the chained-hit lists (also the cost-sum scratch)
@@ -135,9 +135,10 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     uint64_t rows_total = 0, livetiles = 0;
 #endif
 
+    uint32_t slot = 0;  // step % 3
     while (n >= 4) {
-        const uint32_t slot = step % 3u;
-        if (tid == 0) ctl->keys[(step + 1u) % 3u] = kNoKey;  // slot of the next step
+        const uint32_t slot_next = slot == 2u ? 0u : slot + 1u;
+        if (tid == 0) ctl->keys[slot_next] = kNoKey;  // slot of the next step
         ++step;
         uint32_t *keyslot = &ctl->keys[slot];
 
@@ -227,13 +228,13 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             const uint32_t i = i0, t0 = j0 >> 6;
             const float ax = readlane_f(rp.x, 0), ay = readlane_f(rp.y, 0);
             const float bx = readlane_f(rp.x, 1), by = readlane_f(rp.y, 1);
-            const float sqab = readlane_f(rowsq, 0), dab_a = __builtin_amdgcn_sqrtf(sqab);
+            const float sqab = readlane_f(rowsq, 0);
             if ((uint32_t)wave < kDenseLead && t0 + (uint32_t)wave <= last_tile) {
                 const uint32_t t = t0 + (uint32_t)wave;
 #ifdef TL_PROFILE
                 ++livetiles;
 #endif
-                dense_tile<PRUNE, true>(P, n, i, t << 6, j0, ax, ay, bx, by, sqab, dab_a, queues + (t & 15u) * kQCap, keyslot, lane);
+                dense_tile<PRUNE>(P, n, i, t << 6, j0, ax, ay, bx, by, sqab, queues + (t & 15u) * kQCap, keyslot, lane);
             }
             __syncthreads();
             if ((uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot) == kNoKey) {
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #ifdef TL_PROFILE
                     ++livetiles;
 #endif
-                    if (dense_tile<PRUNE, true>(P, n, i, t << 6, j0, ax, ay, bx, by, sqab, dab_a, queues + (t & 15u) * kQCap, keyslot, lane)) break;
+                    if (dense_tile<PRUNE>(P, n, i, t << 6, j0, ax, ay, bx, by, sqab, queues + (t & 15u) * kQCap, keyslot, lane)) break;
                 }
             }
         }
@@ -346,6 +347,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             i0 = 0;
             j0 = 2;
         }
+        slot = slot_next;
     }
 
     // ---------------------------------------------------------------- results
