@@ -79,7 +79,7 @@ __device__ __forceinline__ uint64_t tile_mask_core(float2 c, float2 e, uint32_t 
     dx = bx - e.x;
     dy = by - e.y;
     const float s2 = dx * dx + dy * dy;
-    bool test = (j + 2u <= n) & (j >= jmin);
+    bool test = (j - jmin) <= (n - 2u - jmin);  // jmin <= j <= n-2 in one unsigned compare (callers keep jmin <= n-2)
     bool imp;
     if (PRUNE) {
         test = test & ((s1 < sqab) | (s2 < sqce));                       // L1
@@ -88,7 +88,12 @@ __device__ __forceinline__ uint64_t tile_mask_core(float2 c, float2 e, uint32_t 
         const float cur_a = __builtin_amdgcn_sqrtf(sqab) + __builtin_amdgcn_sqrtf(sqce);
         const float margin = cur_a * 1.9073486e-6f;                      // 2^-19
         imp = test & (neu_a < cur_a - margin);
-        const bool tie = test & !imp & ((neu_a <= cur_a + margin) | (fminf(fminf(s1, sqce), fminf(s2, sqab)) < 1e-30f) | !(cur_a < 3.0e38f));
+        // near-ties, tiny squares (v_sqrt_f32 loses accuracy on denormals) and non-finite sums go to L3.  Squares are
+        // >= +0, so their bit patterns order like unsigned ints (a NaN compares high and is caught through cur_a, or
+        // makes neu_a NaN, which L2 and the reference both read as "not improving").
+        const uint32_t smin = min(min(__builtin_bit_cast(uint32_t, s1), __builtin_bit_cast(uint32_t, sqce)),
+                                  min(__builtin_bit_cast(uint32_t, s2), __builtin_bit_cast(uint32_t, sqab)));
+        const bool tie = test & !imp & ((neu_a <= cur_a + margin) | (smin < 0x0DA24260u /* 1e-30f */) | !(cur_a < 3.0e38f));
         if (__builtin_amdgcn_ballot_w64(tie)) {                          // L3
             // the opaque copies keep the compiler from hoisting the loop-invariant exact roots into a tile or row
             // prologue, where every tile (row) would pay ~40 VALU for a path that almost never runs
@@ -147,7 +152,7 @@ __device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint
         if (nh == 0 && lane == 0) atomicMin(keyslot, (i << 16) | jh);  // post at once: it stops the other waves' scans
         ++nh;
         from = jh + 1u;
-        if (nh >= kMaxChainHits || l == 63) break;
+        if (nh >= kMaxChainHits || l == 63 || from > n - 2u) break;
         bx = readlane_f(c.x, l);  // new p[i+1] = old p[j]
         by = readlane_f(c.y, l);
         const float dx = ax - bx, dy = ay - by;
