@@ -7,12 +7,14 @@
 //
 // This one IS best-improvement in the reference, so the whole chip works on one pass:
 //   k_three_opt_prepare   Pt[k] = xy[perm[k]] (tour order, Pt[n] = Pt[0]) and E[k] = d(path[k], path[(k+1)%n])
+//   k_three_opt_build_dt  the n x n matrix of distances between tour POSITIONS (coordinates: one correctly rounded
+//                         distance each; explicit matrices: one gather each), rebuilt every pass — O(n^2) next to
+//                         the pass's O(n^3).
 //   k_three_opt_scan      one workgroup per (i, chunk of JC consecutive j).  Distance ROWS are staged in LDS:
 //                         Da[k] = d(a, path[k]), Db[k] (per i), and a rolling pair Dc / Dn with Dn(j) = Dc(j+1)
 //                         because D = path[j+1] is the next j's C — so each (i,j) costs ONE new row of n-j
-//                         correctly rounded distances, i.e. one sqrt per triple instead of seven.  Lanes run
-//                         along k: 7 stride-1 LDS reads + ~35 VALU per triple; every f32 sum is associated
-//                         exactly as the reference writes it, (x + y) + z.
+//                         coalesced loads from Dt.  Lanes run along k: 7 stride-1 LDS reads + ~25 VALU per triple;
+//                         every f32 sum is associated exactly as the reference writes it, (x + y) + z.
 //   k_three_opt_pick      reduces the per-workgroup bests (max savings, lowest (i,j,k) on ties == the reference's
 //                         strict `>` in loop order) and applies the move (apply_3opt) in place.
 // Roofline: VALU (one correctly rounded sqrt + 7 three-term sums per triple); algorithmic bytes in matrix form
@@ -59,21 +61,23 @@ __global__ __launch_bounds__(256) void k_three_opt_prepare(ThreeOptArgs A)
 }
 
 template <bool DM>
+__global__ __launch_bounds__(256) void k_three_opt_build_dt(ThreeOptArgs A)
+{
+    const uint32_t n = A.n, p = blockIdx.x, q = blockIdx.y * 256u + threadIdx.x;
+    if (q > n) return;
+    A.Dt[(size_t)p * (n + 1u) + q] = Dpos<DM>(A.Pt, A.dm, A.perm, p, q, n);
+}
+
 __global__ __launch_bounds__(kT3) void k_three_opt_scan(ThreeOptArgs A)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t n = A.n, stride = n + 2u;
-    float *Da = reinterpret_cast<float *>(smem);
-    float *Db = Da + stride;
-    float *Dr0 = Db + stride;
-    float *Dr1 = Dr0 + stride;
-    float *El = Dr1 + stride;
+    const uint32_t n = A.n;
     __shared__ uint32_t s_i;
     __shared__ float r_s[kT3 / 64];
     __shared__ uint32_t r_ij[kT3 / 64], r_kc[kT3 / 64];
     const uint32_t tid = threadIdx.x;
-    const float2 *__restrict__ Pt = A.Pt;
-    const uint32_t *__restrict__ perm = A.perm;
+    const float *__restrict__ Dt = A.Dt;
+    const float *__restrict__ E = A.E;
+    const size_t rs = (size_t)n + 1u;  // row stride of Dt; column n == column 0 (F = path[(k+1) % n], :85)
 
     // block -> (i, chunk): prefix[i] = number of chunks of rows < i
     if (tid == 0) {
@@ -91,55 +95,57 @@ __global__ __launch_bounds__(kT3) void k_three_opt_scan(ThreeOptArgs A)
     const uint32_t jlo = i + 1u + (blockIdx.x - A.chunk_prefix[i]) * A.jc;
     uint32_t jhi = jlo + A.jc;
     if (jhi > n - 1u) jhi = n - 1u;  // j in [i+1, n-1)
-
-    // rows for k in [jlo, n]  (index n == wrap to position 0)
-    for (uint32_t k = jlo + tid; k <= n; k += kT3) {
-        Da[k] = Dpos<DM>(Pt, A.dm, perm, i, k, n);
-        Db[k] = Dpos<DM>(Pt, A.dm, perm, i + 1u, k, n);
-        Dr0[k] = Dpos<DM>(Pt, A.dm, perm, jlo, k, n);
-        if (k < n) El[k] = A.E[k];
-    }
-    __syncthreads();
-    const float d_ab = A.E[i];
+    const float *__restrict__ Ra = Dt + i * rs, *__restrict__ Rb = Ra + rs;  // rows of a = path[i], b = path[i+1]
+    const float d_ab = E[i];
 
     float bs = 0.0f;  // three_opt.rs:61 best_savings = 0.0
     uint32_t bij = 0xFFFFFFFFu, bkc = 0xFFFFFFFFu;
-    float *Dc = Dr0, *Dn = Dr1;
-    for (uint32_t j = jlo; j < jhi; ++j) {
-        // Dn = distances from D = path[j+1] (the next j's C row)
-        for (uint32_t k = j + 1u + tid; k <= n; k += kT3) Dn[k] = Dpos<DM>(Pt, A.dm, perm, j + 1u, k, n);
-        __syncthreads();
-        const float d_c_dt = El[j], d_ac = Da[j], d_b_dt = Db[j + 1u], d_a_dt = Da[j + 1u];
-        const float s_orig = d_ab + d_c_dt;   // (d_ab + d_c_dt) + d_ef
-        const float s_c0 = d_ac + d_b_dt;     // (d_ac + d_b_dt) + d_ef
-        for (uint32_t k = j + 1u + tid; k < n; k += kT3) {
-            if (i == 0u && k == n - 1u) continue;  // :81-83
-            const float d_ef = El[k], d_ae = Da[k], d_be = Db[k], d_bf = Db[k + 1u];
-            const float d_ce = Dc[k], d_cf = Dc[k + 1u], d_dt_f = Dn[k + 1u];
-            const float orig = s_orig + d_ef;
-            float cmin = orig;
-            int ci = -1;
-            float c;
-            c = s_c0 + d_ef;              if (c < cmin) { cmin = c; ci = 0; }   // case 1
-            c = (d_ab + d_ce) + d_dt_f;   if (c < cmin) { cmin = c; ci = 1; }   // case 2
-            c = (d_ac + d_be) + d_dt_f;   if (c < cmin) { cmin = c; ci = 2; }   // case 3
-            c = (d_a_dt + d_be) + d_cf;   if (c < cmin) { cmin = c; ci = 3; }   // case 4
-            c = (d_a_dt + d_ce) + d_bf;   if (c < cmin) { cmin = c; ci = 4; }   // case 5
-            c = (d_ae + d_b_dt) + d_cf;   if (c < cmin) { cmin = c; ci = 5; }   // case 6
-            c = (d_ae + d_c_dt) + d_bf;   if (c < cmin) { cmin = c; ci = 6; }   // case 7
-            if (ci >= 0) {
-                const float sav = orig - cmin;  // :120
-                if (sav > bs) {                  // :121 strict; a thread visits (j,k) in ascending order
-                    bs = sav;
+    // A lane owns a column k and walks the chunk's j in registers: everything that depends on (i, k) only is loaded
+    // once, the row of C = path[j] rolls into the row of the next j (D = path[j+1] is the next j's C), so a triple
+    // costs two coalesced loads and the seven sums.  No LDS, no barrier.
+    for (uint32_t k = jlo + 1u + tid; k < n; k += kT3) {
+        if (i == 0u && k == n - 1u) continue;  // :81-83
+        const float d_ef = E[k], d_ae = Ra[k], d_be = Rb[k], d_bf = Rb[k + 1u];
+        const uint32_t jend = jhi < k ? jhi : k;  // j < k
+        const float *__restrict__ Rc = Dt + jlo * rs;
+        float d_ce = Rc[k], d_cf = Rc[k + 1u];
+        for (uint32_t j = jlo; j < jend; ++j) {
+            const float *__restrict__ Rd = Dt + (j + 1u) * rs;  // row of D = path[j+1]
+            const float d_de = Rd[k], d_dt_f = Rd[k + 1u];
+            const float d_c_dt = E[j], d_ac = Ra[j], d_b_dt = Rb[j + 1u], d_a_dt = Ra[j + 1u];  // wave-uniform
+            const float orig = (d_ab + d_c_dt) + d_ef;
+            const float c0 = (d_ac + d_b_dt) + d_ef;   // case 1
+            const float c1 = (d_ab + d_ce) + d_dt_f;   // case 2
+            const float c2 = (d_ac + d_be) + d_dt_f;   // case 3
+            const float c3 = (d_a_dt + d_be) + d_cf;   // case 4
+            const float c4 = (d_a_dt + d_ce) + d_bf;   // case 5
+            const float c5 = (d_ae + d_b_dt) + d_cf;   // case 6
+            const float c6 = (d_ae + d_c_dt) + d_bf;   // case 7
+            // :113-117 leaves cmin = min(orig, c0..c6) (NaN costs never pass `c < cmin`; fminf drops them the same way),
+            // and a triple matters only if it beats this thread's best so far — rare, so the case index is worked out
+            // under a wave-uniform branch
+            const float cm = fminf(fminf(fminf(orig, c0), fminf(c1, c2)), fminf(fminf(c3, c4), fminf(c5, c6)));
+            const float sav = orig - cm;  // :120
+            if (__builtin_amdgcn_ballot_w64(sav > 0.0f && better(sav, (i << 16) | j, k << 3, bs, bij, bkc))) {
+                float cmin = orig;
+                int ci = -1;
+                if (c0 < cmin) { cmin = c0; ci = 0; }
+                if (c1 < cmin) { cmin = c1; ci = 1; }
+                if (c2 < cmin) { cmin = c2; ci = 2; }
+                if (c3 < cmin) { cmin = c3; ci = 3; }
+                if (c4 < cmin) { cmin = c4; ci = 4; }
+                if (c5 < cmin) { cmin = c5; ci = 5; }
+                if (c6 < cmin) { cmin = c6; ci = 6; }
+                // :119-125 strict `>` in (i, j, k) loop order; this thread meets its triples k-major, so order by key
+                if (ci >= 0 && better(orig - cmin, (i << 16) | j, (k << 3) | (uint32_t)(ci + 1), bs, bij, bkc)) {
+                    bs = orig - cmin;
                     bij = (i << 16) | j;
                     bkc = (k << 3) | (uint32_t)(ci + 1);
                 }
             }
+            d_ce = d_de;
+            d_cf = d_dt_f;
         }
-        __syncthreads();
-        float *t = Dc;
-        Dc = Dn;
-        Dn = t;
     }
 
     // workgroup reduction: wave (shuffles) then LDS
@@ -216,24 +222,24 @@ __global__ __launch_bounds__(1024) void k_three_opt_pick(ThreeOptArgs A, uint32_
     }
 }
 
-size_t three_opt_scan_lds_bytes(uint32_t n) { return (size_t)5 * (n + 2u) * 4; }
+size_t three_opt_scan_lds_bytes(uint32_t) { return 0; }  // the scan keeps its rows in registers
 
 hipError_t launch_three_opt_pass(const ThreeOptArgs &A, uint32_t nblocks, bool dm, int apply, hipStream_t s)
 {
     const uint32_t pg = (A.n + 256u) / 256u;
     const size_t lds = three_opt_scan_lds_bytes(A.n);
     hipError_t e;
+    const dim3 dg(A.n, (A.n + 1u + 255u) / 256u);
     if (dm) {
         hipLaunchKernelGGL(k_three_opt_prepare<true>, dim3(pg), dim3(256), 0, s, A);
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_three_opt_scan<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_three_opt_scan<true>, dim3(nblocks), dim3(kT3), lds, s, A);
+        hipLaunchKernelGGL(k_three_opt_build_dt<true>, dg, dim3(256), 0, s, A);
     } else {
         hipLaunchKernelGGL(k_three_opt_prepare<false>, dim3(pg), dim3(256), 0, s, A);
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_three_opt_scan<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_three_opt_scan<false>, dim3(nblocks), dim3(kT3), lds, s, A);
+        hipLaunchKernelGGL(k_three_opt_build_dt<false>, dg, dim3(256), 0, s, A);
     }
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_three_opt_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_three_opt_scan, dim3(nblocks), dim3(kT3), lds, s, A);
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_three_opt_pick), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)A.n * 4));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_three_opt_pick, dim3(1), dim3(1024), (size_t)A.n * 4, s, A, nblocks, apply);

@@ -627,18 +627,16 @@ struct ThreeOptSetup {
     bool dm = false;
 };
 
-static uint32_t three_opt_max_n(const tl_ctx *c)
+static uint32_t three_opt_max_n(const tl_ctx *)
 {
-    long n = ((long)c->lds_bytes - 1024) / 20 - 2;
-    if (n > 65535) n = 65535;
-    return n < 0 ? 0u : (uint32_t)n;
+    return 65535u;  // (i, j) and (k, case) travel as packed 16-bit fields; the workspace holds an n x (n+1) f32 matrix
 }
 
 // uploads inputs, lays out the workspace in c->work and fills the kernel argument block
 static int three_opt_setup(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *path, ThreeOptSetup &S)
 {
     if (n > three_opt_max_n(c))
-        return fail(c, TL_ERR_UNSUPPORTED, "three_opt: n=%u exceeds the LDS row-cache limit %u of this build", n, three_opt_max_n(c));
+        return fail(c, TL_ERR_UNSUPPORTED, "three_opt: n=%u exceeds the limit %u of this build (packed 16-bit indices)", n, three_opt_max_n(c));
     int rc;
     S.dm = dm_packed != nullptr;
     const uint32_t jc = n <= 256 ? 4u : 16u;
@@ -662,9 +660,10 @@ static int three_opt_setup(tl_ctx *c, const float *xy, uint32_t n, const float *
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_perm = 0, o_pt = up(o_perm + (size_t)n * 4), o_e = up(o_pt + (size_t)(n + 1) * 8), o_pre = up(o_e + (size_t)n * 4),
                  o_par = up(o_pre + (size_t)(n - 1) * 4), o_best = up(o_par + (size_t)S.nblocks * sizeof(ThreeOptBest)),
-                 o_cnt = up(o_best + sizeof(ThreeOptBest)), total = up(o_cnt + 16);
+                 o_cnt = up(o_best + sizeof(ThreeOptBest)), o_dt = up(o_cnt + 16), total = up(o_dt + (size_t)n * (n + 1) * 4);
     if ((rc = ensure(c, c->work, total))) return rc;
     unsigned char *w = (unsigned char *)c->work.p;
+    S.A.Dt = (float *)(w + o_dt);
     std::vector<uint32_t> ident;
     if (!path) {
         ident.resize(n);

@@ -82,6 +82,7 @@ struct ThreeOptArgs {
     uint32_t *perm;              // [n] tour positions, updated in place by k_three_opt_pick
     float2 *Pt;                  // [n+1] tour-ordered coordinates (coordinate form)
     float *E;                    // [n] tour-edge lengths, E[n-1] = closing edge
+    float *Dt;                   // [n][n+1] distances between tour POSITIONS, column n == column 0 (rebuilt every pass)
     const uint32_t *chunk_prefix;  // [n-1]: chunks of rows < i
     ThreeOptBest *partials;      // one per scan workgroup
     ThreeOptBest *best;          // result of the pass
