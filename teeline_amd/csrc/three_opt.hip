@@ -91,8 +91,8 @@ __global__ __launch_bounds__(kT3) void k_three_opt_scan(ThreeOptArgs A)
         s_i = lo;
     }
     __syncthreads();
-    const uint32_t i = s_i;
-    const uint32_t jlo = i + 1u + (blockIdx.x - A.chunk_prefix[i]) * A.jc;
+    const uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_i);  // provably wave-uniform: scalar loads for the (i, j) terms
+    const uint32_t jlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(i + 1u + (blockIdx.x - A.chunk_prefix[i]) * A.jc));
     uint32_t jhi = jlo + A.jc;
     if (jhi > n - 1u) jhi = n - 1u;  // j in [i+1, n-1)
     const float *__restrict__ Ra = Dt + i * rs, *__restrict__ Rb = Ra + rs;  // rows of a = path[i], b = path[i+1]
@@ -106,13 +106,24 @@ __global__ __launch_bounds__(kT3) void k_three_opt_scan(ThreeOptArgs A)
     for (uint32_t k = jlo + 1u + tid; k < n; k += kT3) {
         if (i == 0u && k == n - 1u) continue;  // :81-83
         const float d_ef = E[k], d_ae = Ra[k], d_be = Rb[k], d_bf = Rb[k + 1u];
-        const uint32_t jend = jhi < k ? jhi : k;  // j < k
         const float *__restrict__ Rc = Dt + jlo * rs;
         float d_ce = Rc[k], d_cf = Rc[k + 1u];
-        for (uint32_t j = jlo; j < jend; ++j) {
-            const float *__restrict__ Rd = Dt + (j + 1u) * rs;  // row of D = path[j+1]
-            const float d_de = Rd[k], d_dt_f = Rd[k + 1u];
-            const float d_c_dt = E[j], d_ac = Ra[j], d_b_dt = Rb[j + 1u], d_a_dt = Ra[j + 1u];  // wave-uniform
+        // software pipeline: the row of D = path[j+1] and the j terms of the NEXT iteration are in flight during this one
+        float n_de = Rc[rs + k], n_dtf = Rc[rs + k + 1u];
+        float n_c_dt = E[jlo], n_ac = Ra[jlo], n_a_dt = Ra[jlo + 1u], n_b_dt = Rb[jlo + 1u];
+        for (uint32_t j = jlo; j < jhi; ++j) {  // wave-uniform trip count (scalar loads for the j terms); j >= k is masked below
+            const float d_de = n_de, d_dt_f = n_dtf;
+            const float d_c_dt = n_c_dt, d_ac = n_ac, d_a_dt = n_a_dt, d_b_dt = n_b_dt;
+            {   // rows up to jhi+1 <= n exist (row n-1 is the last; jhi <= n-1, so j+2 <= n needs a clamp at the very end)
+                const uint32_t jn = j + 1u < jhi ? j + 1u : j;  // last iteration: reload the same (unused) values
+                const float *__restrict__ Rn = Dt + (jn + 1u) * rs;
+                n_de = Rn[k];
+                n_dtf = Rn[k + 1u];
+                n_c_dt = E[jn];
+                n_ac = Ra[jn];
+                n_a_dt = Ra[jn + 1u];
+                n_b_dt = Rb[jn + 1u];
+            }
             const float orig = (d_ab + d_c_dt) + d_ef;
             const float c0 = (d_ac + d_b_dt) + d_ef;   // case 1
             const float c1 = (d_ab + d_ce) + d_dt_f;   // case 2
@@ -126,7 +137,7 @@ __global__ __launch_bounds__(kT3) void k_three_opt_scan(ThreeOptArgs A)
             // under a wave-uniform branch
             const float cm = fminf(fminf(fminf(orig, c0), fminf(c1, c2)), fminf(fminf(c3, c4), fminf(c5, c6)));
             const float sav = orig - cm;  // :120
-            if (__builtin_amdgcn_ballot_w64(sav > 0.0f && better(sav, (i << 16) | j, k << 3, bs, bij, bkc))) {
+            if (__builtin_amdgcn_ballot_w64((sav >= bs) & (sav > 0.0f) & (j < k))) {
                 float cmin = orig;
                 int ci = -1;
                 if (c0 < cmin) { cmin = c0; ci = 0; }
@@ -137,7 +148,7 @@ __global__ __launch_bounds__(kT3) void k_three_opt_scan(ThreeOptArgs A)
                 if (c5 < cmin) { cmin = c5; ci = 5; }
                 if (c6 < cmin) { cmin = c6; ci = 6; }
                 // :119-125 strict `>` in (i, j, k) loop order; this thread meets its triples k-major, so order by key
-                if (ci >= 0 && better(orig - cmin, (i << 16) | j, (k << 3) | (uint32_t)(ci + 1), bs, bij, bkc)) {
+                if (ci >= 0 && j < k && better(orig - cmin, (i << 16) | j, (k << 3) | (uint32_t)(ci + 1), bs, bij, bkc)) {
                     bs = orig - cmin;
                     bij = (i << 16) | j;
                     bkc = (k << 3) | (uint32_t)(ci + 1);
