@@ -14,11 +14,16 @@ namespace tl {
 
 constexpr int kWave = 64;  // CDNA wavefront width
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// fl(fl(dx*dx) + fl(dy*dy)): written on 2-vectors so that it becomes v_pk_add_f32, v_pk_mul_f32, v_add_f32 — the same
+// three roundings per component as the scalar form, no operand shuffling.
 __device__ __forceinline__ float sqdist(float2 p, float2 q)
 {
-    float dx = p.x - q.x;
-    float dy = p.y - q.y;
-    return dx * dx + dy * dy;
+    const v2f a = {p.x, p.y}, b = {q.x, q.y};
+    v2f d = a - b;
+    d = d * d;
+    return d.x + d.y;
 }
 
 // Correctly rounded f32 sqrt, the compiler's way: hipcc (-fhip-fp32-correctly-rounded-divide-sqrt, default on)

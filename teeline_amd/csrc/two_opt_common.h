@@ -74,11 +74,8 @@ __device__ __forceinline__ uint64_t tile_mask_core(float2 c, float2 e, uint32_t 
                                                    float ax, float ay, float bx, float by, float sqab)
 {
     const float sqce = sqdist(c, e);
-    float dx = ax - c.x, dy = ay - c.y;
-    const float s1 = dx * dx + dy * dy;
-    dx = bx - e.x;
-    dy = by - e.y;
-    const float s2 = dx * dx + dy * dy;
+    const float s1 = sqdist(make_float2(ax, ay), c);
+    const float s2 = sqdist(make_float2(bx, by), e);
     bool test = (j - jmin) <= (n - 2u - jmin);  // jmin <= j <= n-2 in one unsigned compare (callers keep jmin <= n-2)
     bool imp;
     if (PRUNE) {

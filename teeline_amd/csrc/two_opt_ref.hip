@@ -240,7 +240,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             if ((uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot) == kNoKey) {
                 for (uint32_t t = t0 + kDenseLead + (uint32_t)wave; t <= last_tile; t += NW) {
                     const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot);
-                    if (kb != kNoKey && (kb & 0xFFFFu) < (t << 6)) break;  // an earlier column already improves
+                    if ((kb & 0xFFFFu) < (t << 6)) break;  // an earlier column already improves (kNoKey reads as column 65535)
 #ifdef TL_PROFILE
                     ++livetiles;
 #endif
