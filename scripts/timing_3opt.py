@@ -1,4 +1,4 @@
-"""Developer probe: 3-opt scan / solve kernel times (no oracle runs)."""
+"""Developer probe: 3-opt scan / solve kernel times (kernel times only)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

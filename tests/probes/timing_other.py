@@ -1,6 +1,6 @@
 """Developer probe: 3-opt / LK / NN / k-NN timings (kernel ms) vs the oracle on the same host."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import _oracle as O, _tsplib as T

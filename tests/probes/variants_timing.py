@@ -1,6 +1,6 @@
 """Developer probe: time build variants (build_variants/*.so) on the n=10^4 descents; each in a subprocess."""
 import os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 probe = r'''
 import os, sys
 sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
