@@ -41,7 +41,11 @@ constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 #define TL_DENSE_ROWS 8.0f
 #endif
 constexpr int kRMax = TL_RMAX;        // rows per speculative block in pruned mode (<= 63: lane-resident row table)
-constexpr uint32_t kQCap = 128;       // u32 words per tile slot of the chained-hit lists (also the cost-sum scratch)
+constexpr uint32_t kQCap = 32;        // u32 words per chained-hit list: 2 + kMaxChainHits used.  32 lists = (tile index mod 16) x
+                                      // (step parity): a list is read after its step's barrier with no barrier behind the read,
+                                      // so the next step writes the other parity.  The 4 KB are also the cost-sum scratch.
+constexpr uint32_t kPendMax = 64;     // deferred reversals of one row: lane m of every wave keeps hit m (= the flush's segment table)
+constexpr int kFlushSlots = 15;       // elements per thread a flush can hold: 15 x 1024 covers every n that fits the LDS
 constexpr int kMaxGroups = 4;         // 64-tile groups: n_pad <= 4 * 64 * 64 = 16384
 
 #ifdef TL_PROFILE
@@ -53,6 +57,100 @@ constexpr int kMaxGroups = 4;         // 64-tile groups: n_pad <= 4 * 64 * 64 = 
 struct Ctl {
     uint32_t keys[4];
 };
+
+// Deferred reversals (dense mode).  The hits (i, g_0 < g_1 < ... < g_{k-1}) of ONE row all reverse a prefix that starts at
+// lo = i+1 (two_opt.rs:50 swap_2opt(path, i+1, j)), and the rest of that row's scan reads only positions > g and
+// b = p[i+1] = the old p[g_last] — so nothing inside [lo..g_last] is looked at before the row ends and the k reversals
+// can be applied at once.  With S_0 = [lo..g_0], S_m = [g_{m-1}+1..g_m] their composition is
+//     rev(S_{k-1}) rev(S_{k-3}) ... | ... S_{k-4} S_{k-2}
+// (segments of the parity of k-1 reversed, in descending order, then the others as they are, ascending): every element
+// moves once instead of once per hit.  Lane m of every wave holds segment m's table entry; a thread takes source
+// positions lo + q*NT + tid, whose segment index is the number of hits below the position (ballot + popcount for the
+// wave's 64-wide window, then a wave-uniform walk over the few segments the window overlaps), keeps value and target
+// in registers across one barrier and stores.  Returns (per lane m < k) g_m - i, the reference's reversal length.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_shr0(uint32_t v)
+{
+    // row_shr within rows of 16 lanes; lanes without a source read 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint32_t readlane_u(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+
+// `g`: lane m < k holds hit column g_m (the row's deferred-hit register of every wave), lanes >= k hold 0xFFFFFFFF.
+template <int NT>
+__device__ __forceinline__ uint32_t flush_deferred(float2 *P, uint16_t *perm, uint32_t g, uint32_t lo, uint32_t k, int lane, int wave)
+{
+    const bool have = (uint32_t)lane < k;
+    const uint32_t ghi = readlane_u(g, k - 1u);
+    const uint32_t wfirst = lo + ((uint32_t)wave << 6);  // this wave's first window (wave-uniform)
+    float2 val[kFlushSlots];
+    uint32_t pk[kFlushSlots];  // perm id | target << 16
+    if (wfirst <= ghi) {  // waves without a window go straight to the barriers
+        // g of the lane below (row_shr stays inside its row of 16: lanes 16, 32, 48 are patched)
+        uint32_t gprev = dpp_shr0<0x111>(g);
+        gprev = lane == 16 ? readlane_u(g, 15) : gprev;
+        gprev = lane == 32 ? readlane_u(g, 31) : gprev;
+        gprev = lane == 48 ? readlane_u(g, 47) : gprev;
+        gprev = lane == 0 ? lo - 1u : gprev;
+        const uint32_t start = gprev + 1u;
+        const uint32_t len = have ? g - gprev : 0u;
+        // inclusive prefix sum over the lanes of the same parity: stride-2 scan inside each row of 16, then the rows below
+        uint32_t pre = len;
+        pre += dpp_shr0<0x112>(pre);
+        pre += dpp_shr0<0x114>(pre);
+        pre += dpp_shr0<0x118>(pre);
+        if (k > 16u) {
+            const uint32_t e0 = readlane_u(pre, 14), o0 = readlane_u(pre, 15);
+            const uint32_t e1 = e0 + readlane_u(pre, 30), o1 = o0 + readlane_u(pre, 31);
+            const uint32_t e2 = e1 + readlane_u(pre, 46), o2 = o1 + readlane_u(pre, 47);
+            const bool odd = (lane & 1) != 0;
+            uint32_t off = 0u;
+            off = lane >= 16 ? (odd ? o0 : e0) : off;
+            off = lane >= 32 ? (odd ? o1 : e1) : off;
+            off = lane >= 48 ? (odd ? o2 : e2) : off;
+            pre += off;
+        }
+        const uint32_t t_rev = readlane_u(pre, k - 1u);  // total length of the reversed group
+        const bool isrev = ((k - 1u - (uint32_t)lane) & 1u) == 0u;
+        const uint32_t base = lo + (isrev ? t_rev - pre : t_rev + pre - len);
+        const uint32_t cst = isrev ? base + g : base - start;  // target = cst - p (reversed) or cst + p (kept)
+#pragma unroll
+        for (int q = 0; q < kFlushSlots; ++q) {
+            const uint32_t w0 = wfirst + (uint32_t)(q * NT);
+            if (w0 > ghi) break;
+            const uint32_t p = w0 + (uint32_t)lane;
+            const uint32_t w1 = (w0 + 63u < ghi) ? w0 + 63u : ghi;
+            uint32_t m = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(g < w0));
+            const uint32_t mhi = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(g < w1));
+            const uint32_t c0 = readlane_u(cst, m);
+            uint32_t dst = ((k - 1u - m) & 1u) == 0u ? c0 - p : c0 + p;  // the window's first segment (usually its only one)
+            for (++m; m <= mhi; ++m) {
+                const uint32_t sm = readlane_u(start, m), cm = readlane_u(cst, m);
+                const bool rv = ((k - 1u - m) & 1u) == 0u;
+                dst = p >= sm ? (rv ? cm - p : cm + p) : dst;
+            }
+            if (p <= ghi) {
+                val[q] = P[p];
+                pk[q] = (uint32_t)perm[p] | (dst << 16);
+            }
+        }
+    }
+    __syncthreads();
+    if (wfirst <= ghi) {
+#pragma unroll
+        for (int q = 0; q < kFlushSlots; ++q) {
+            const uint32_t w0 = wfirst + (uint32_t)(q * NT);
+            if (w0 > ghi) break;
+            if (w0 + (uint32_t)lane <= ghi) {
+                const uint32_t dst = pk[q] >> 16;
+                P[dst] = val[q];
+                perm[dst] = (uint16_t)pk[q];
+            }
+        }
+    }
+    __syncthreads();
+    return have ? g - (lo - 1u) : 0u;
+}
 
 }  // namespace
 
@@ -71,7 +169,8 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     float4 *tbox = reinterpret_cast<float4 *>(tailp);                        // kMaxGroups*64 entries
     float *tmsq = reinterpret_cast<float *>(tailp + kMaxGroups * 64 * 16);     // kMaxGroups*64
     Ctl *ctl = reinterpret_cast<Ctl *>(tailp + kMaxGroups * 64 * 20);
-    // chained-hit lists (one kQCap-word slot per tile index mod 16) during the descent; reused as NT floats for the cost sum
+    // chained-hit lists (kQCap words per (tile index mod 16, step parity)) during the descent; reused as NT floats for the
+    // cost sum
     uint32_t *queues = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(ctl) + 64);
     float *scratch = reinterpret_cast<float *>(queues);
 
@@ -125,6 +224,10 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     bool improved = false;
     uint32_t sweeps = 1, step = 0, status = 0;
     uint64_t moves = 0, reversed = 0;
+    uint32_t np = 0, hlast = 0, prow = 0;  // dense mode: np hits of row `prow` whose reversals are deferred; the last one
+    uint32_t pendv = 0xFFFFFFFFu;          // ... lane m < np of every wave holds hit column g_m
+    bool flush_due = false;                // row `prow` is finished (or the hit register is nearly full)
+    uint64_t rev_lane = 0;        // per-lane share of `reversed` from the flushes (summed over lanes at the end)
     float gap_est = 0.0f, since = 0.0f;
     uint32_t dirty_lo = 0xFFFFFFFFu, dirty_hi = 0;               // tiles whose L0 metadata is stale
 #ifdef TL_PROFILE
@@ -132,11 +235,38 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     bool pmode = false;
     uint64_t nsteps_pruned = 0, nmoves_pruned = 0;
     uint64_t tlast = __builtin_amdgcn_s_memtime();
-    uint64_t rows_total = 0, livetiles = 0;
+    uint64_t rows_total = 0, livetiles = 0, nflush = 0;
 #endif
 
     uint32_t slot = 0;  // step % 3
     while (n >= 4) {
+        // deferred reversals are applied (one call site) when their row is finished, when the hit register runs full, or when the
+        // next block is a pruned one, which reads every row of the block
+        if (np && (flush_due || (PRUNE && i0 < nrows && fmaxf(gap_est, since) > TL_DENSE_ROWS * (float)(n - 2u - i0)))) {
+            TL_STAMP(7);
+#ifdef TL_PROFILE
+            ++nflush;
+#endif
+            rev_lane += flush_deferred<NT>(P, perm, pendv, prow + 1u, np, lane, wave);
+            pendv = 0xFFFFFFFFu;
+            const uint32_t t0 = prow >> 6, t1 = hlast >> 6;  // L0 metadata of tiles with a changed position or tour-edge
+            dirty_lo = t0 < dirty_lo ? t0 : dirty_lo;
+            dirty_hi = t1 > dirty_hi ? t1 : dirty_hi;
+            np = 0;
+            flush_due = false;
+            TL_STAMP(5);
+        }
+        if (i0 >= nrows) {  // sweep finished (two_opt.rs:26-28)
+            if (!improved) break;
+            if (sweeps >= A.max_sweeps) {
+                status = 1;
+                break;
+            }
+            improved = false;
+            ++sweeps;
+            i0 = 0;
+            j0 = 2;
+        }
         const uint32_t slot_next = slot == 2u ? 0u : slot + 1u;
         if (tid == 0) ctl->keys[slot_next] = kNoKey;  // slot of the next step
         ++step;
@@ -151,6 +281,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             if ((uint32_t)R > nrows - i0) R = (int)(nrows - i0);
         }
         const bool pruned = PRUNE && R > 1;
+        const uint32_t hpar = (step & 1u) << 4;
 #ifdef TL_PROFILE
         pmode = pruned;
         nsteps_pruned += pruned ? 1 : 0;
@@ -227,14 +358,20 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             // its SIMD's issue slots with three busy neighbours.  Round 2 (no hit yet): all waves take the rest of the row.
             const uint32_t i = i0, t0 = j0 >> 6;
             const float ax = readlane_f(rp.x, 0), ay = readlane_f(rp.y, 0);
-            const float bx = readlane_f(rp.x, 1), by = readlane_f(rp.y, 1);
-            const float sqab = readlane_f(rowsq, 0);
+            float bx = readlane_f(rp.x, 1), by = readlane_f(rp.y, 1);
+            float sqab = readlane_f(rowsq, 0);
+            if (np) {  // p[i+1] after the deferred reversals = the old p[g_last], still in place (two_opt.rs:50)
+                const float2 bq = P[hlast];
+                bx = readlane_f(bq.x, 0);
+                by = readlane_f(bq.y, 0);
+                sqab = sqdist(make_float2(ax, ay), make_float2(bx, by));
+            }
             if ((uint32_t)wave < kDenseLead && t0 + (uint32_t)wave <= last_tile) {
                 const uint32_t t = t0 + (uint32_t)wave;
 #ifdef TL_PROFILE
                 ++livetiles;
 #endif
-                dense_tile<PRUNE>(P, n, i, t << 6, j0, ax, ay, bx, by, sqab, queues + (t & 15u) * kQCap, keyslot, lane);
+                dense_tile<PRUNE>(P, n, i, t << 6, j0, ax, ay, bx, by, sqab, queues + ((t & 15u) | hpar) * kQCap, keyslot, lane);
             }
             __syncthreads();
             if ((uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot) == kNoKey) {
@@ -244,7 +381,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #ifdef TL_PROFILE
                     ++livetiles;
 #endif
-                    if (dense_tile<PRUNE>(P, n, i, t << 6, j0, ax, ay, bx, by, sqab, queues + (t & 15u) * kQCap, keyslot, lane)) break;
+                    if (dense_tile<PRUNE>(P, n, i, t << 6, j0, ax, ay, bx, by, sqab, queues + ((t & 15u) | hpar) * kQCap, keyslot, lane)) break;
                 }
             }
         }
@@ -257,24 +394,51 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #endif
 
         if (key == kNoKey) {
+            flush_due = np != 0;  // row i0 is finished: its reversals are due, composed
             since += (float)R * rowlen;
             i0 += (uint32_t)R;
             j0 = i0 + 2u;
-        } else {
-            const uint32_t is = key >> 16, js = key & 0xFFFFu;
-            // hits to apply: pruned mode found one; in dense mode the wave owning the first hit chained every
-            // improving move inside its tile (dense_tile) and left the list in the tile's slot
-            uint32_t nh = 1, resume = js + 1u;
-            const uint32_t *hl = queues + (((js >> 6) & 15u) * kQCap);
-            if (!pruned) {
-                nh = (uint32_t)__builtin_amdgcn_readfirstlane((int)hl[0]);
-                resume = (uint32_t)__builtin_amdgcn_readfirstlane((int)hl[1]);
+        } else if (!pruned) {
+            // dense mode: the wave owning the first hit chained every improving move inside its tile (dense_tile) and left
+            // the list in the tile's slot.  Nothing of the row's remaining scan reads [i+1..hit], so the reversals wait
+            // in `pendv` until the row ends (flush_deferred); the scan goes on at `resume` with b = the old p[hit].
+            const uint32_t js = key & 0xFFFFu;
+            const uint32_t *hl = queues + ((((js >> 6) & 15u) | hpar) * kQCap);
+            static_assert(kMaxChainHits == 16, "hl[2 + (hsel & 15)]");
+            const uint32_t hsel = (uint32_t)lane - np;  // lanes np .. np+nh-1 take the new hits (hl[] has kQCap words: any read is in range)
+            const uint32_t hval = hl[2u + (hsel & 15u)];
+            const uint32_t nh = (uint32_t)__builtin_amdgcn_readfirstlane((int)hl[0]);
+            const uint32_t resume = (uint32_t)__builtin_amdgcn_readfirstlane((int)hl[1]);
+            pendv = hsel < nh ? hval : pendv;
+            np += nh;
+            hlast = readlane_u(pendv, np - 1u);
+            prow = i0;
+            moves += nh;
+            // gap estimate (block-shape heuristic only): the first hit exactly, chained hits as evenly spaced
+            since += (float)(js - j0);
+            gap_est = 0.5f * (gap_est + since);
+            since = 0.0f;
+            if (nh > 1u) {
+                const float w = __builtin_ldexpf(1.0f, -(int)(nh - 1u));
+                gap_est = gap_est * w + (float)(hlast - js) / (float)(nh - 1u) * (1.0f - w);
             }
+            improved = true;
+            j0 = resume;
+            const bool row_end = j0 > n - 2u;
+            flush_due = row_end || np + kMaxChainHits > kPendMax;
+            if (row_end) {
+                ++i0;
+                j0 = i0 + 2u;
+            }
+            TL_STAMP(4);
+        } else {
+            // pruned mode: one hit, applied at once (moves are rare here)
+            const uint32_t is = key >> 16, js = key & 0xFFFFu;
+            const uint32_t resume = js + 1u;
             const uint32_t lo = is + 1u;
-            uint32_t hi = js, prev_hit = j0;
+            const uint32_t hi = js;
             since += (float)(is - i0) * rowlen;
-            for (uint32_t h = 0; h < nh; ++h) {
-                if (h > 0) hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hl[2u + h]);
+            {
                 // two_opt.rs:50,69-79  swap_2opt(path, i+1, j); two pairs per thread in flight
                 const uint32_t half = (hi - lo + 1u) >> 1;
                 for (uint32_t t = tid; t < half; t += 2 * NT) {
@@ -312,10 +476,13 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 __syncthreads();
                 ++moves;
                 reversed += (uint64_t)(hi - is);
-                since += (float)(hi - prev_hit);
+#ifdef TL_X_GAPFIX
+                since += (float)(hi - (is == i0 ? j0 : is + 2u));
+#else
+                since += (float)(hi - j0);
+#endif
                 gap_est = 0.5f * (gap_est + since);
                 since = 0.0f;
-                prev_hit = hi;
             }
             TL_STAMP(4);
             // L0 metadata of every tile that saw a changed position or tour-edge (j = lo-1 .. hi) is now stale
@@ -327,7 +494,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             TL_STAMP(6);
             improved = true;
 #ifdef TL_PROFILE
-            nmoves_pruned += pruned ? nh : 0;
+            nmoves_pruned += 1;
 #endif
             i0 = is;
             j0 = resume;
@@ -335,17 +502,6 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 ++i0;
                 j0 = i0 + 2u;
             }
-        }
-        if (i0 >= nrows) {  // sweep finished (two_opt.rs:26-28)
-            if (!improved) break;
-            if (sweeps >= A.max_sweeps) {
-                status = 1;
-                break;
-            }
-            improved = false;
-            ++sweeps;
-            i0 = 0;
-            j0 = 2;
         }
         slot = slot_next;
     }
@@ -378,6 +534,15 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         }
         __syncthreads();
     }
+    // `reversed` of the deferred (dense-mode) reversals: per-lane shares of wave 0, summed
+    if (wave == 0) {
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            const uint32_t lo32 = (uint32_t)__shfl_xor((int)(uint32_t)rev_lane, sft), hi32 = (uint32_t)__shfl_xor((int)(uint32_t)(rev_lane >> 32), sft);
+            rev_lane += ((uint64_t)hi32 << 32) | lo32;
+        }
+        reversed += rev_lane;
+    }
     if (tid == 0) {
         A.out_cost[d] = total;
         uint64_t *st = A.out_stats + (size_t)d * TL_STATS_STRIDE;
@@ -391,10 +556,10 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         st[5] = prof[0] + prof[1] + prof[2];
         st[6] = prof[3];
         st[7] = prof[4];
-        st[8] = prof[6];
-        st[9] = prof[8];
-        st[10] = prof[9];
-        st[11] = prof[10];
+        st[8] = prof[6] + prof[7] + prof[15];
+        st[9] = prof[8] + prof[10];
+        st[10] = prof[5] + prof[13];  // flush_deferred
+        st[11] = nflush;
         st[12] = prof[11];
         st[13] = prof[12] + prof[14];
         st[14] = nsteps_pruned;
@@ -414,8 +579,10 @@ size_t two_opt_ref_lds_bytes(uint32_t n, uint32_t *n_pad_out, int nt)
     if (n_pad_out) *n_pad_out = n_pad;
     if (n_pad > (uint32_t)kMaxGroups * 64u * 64u) return ~(size_t)0;  // beyond the tile-table capacity
     const size_t meta = (size_t)kMaxGroups * 64 * 20 + 64;
-    const size_t tail = (size_t)(nt / 64) * kQCap * 4;  // hit-list slots, >= nt floats of scratch
-    return (size_t)n_pad * 10 + meta + (tail > (size_t)nt * 4 ? tail : (size_t)nt * 4);
+    const size_t lists = (size_t)32 * kQCap * 4;  // chained-hit lists, also the nt floats of cost-sum scratch
+    static_assert(32 * kQCap * 4 >= TL_TWO_OPT_NT * 4, "the hit lists double as the cost-sum scratch");
+    (void)nt;
+    return (size_t)n_pad * 10 + meta + lists;
 }
 
 template <int NT, bool PRUNE>
