@@ -282,6 +282,12 @@ static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uin
         if (init_mode == TL_INIT_SEEDED) return fail(c, TL_ERR_UNSUPPORTED, "seeded restarts need coordinates (dm_packed must be NULL)");
         if (two_opt_ref_dm_lds_bytes(n) > (size_t)c->lds_bytes || n > 65535)
             return fail(c, TL_ERR_UNSUPPORTED, "two_opt (matrix form): n=%u exceeds the LDS tour capacity", n);
+        // the packed triangle (reference layout) is expanded to a full row-major matrix once per call: a row scan then
+        // gathers inside one 4n-byte row instead of one cache line per column (two_opt_dm.hip)
+        int rc2;
+        if ((rc2 = ensure(c, c->dmfull, (size_t)n * n * 4))) return rc2;
+        HIPCHK(c, launch_dm_expand_full(d_dm, n, (float *)c->dmfull.p, s));
+        A.dm_full = (const float *)c->dmfull.p;
         HIPCHK(c, launch_two_opt_ref_dm(A, count, s));
     } else {
         const uint32_t nmax = lds_max_n(c->lds_bytes);

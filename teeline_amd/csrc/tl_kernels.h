@@ -16,6 +16,7 @@ enum : uint32_t { TL_INIT_IDENTITY = 0, TL_INIT_ARRAY = 1, TL_INIT_SEEDED = 2 };
 struct TwoOptBatchArgs {
     const float2 *xy;        // n cities, city order
     const float *dm;         // packed lower triangle (matrix kernels) or nullptr
+    const float *dm_full;    // the same matrix expanded to row-major n x n (k_dm_expand_full), matrix kernels only
     const uint32_t *init;    // [count][n] when init_mode == TL_INIT_ARRAY
     uint32_t *out_pos;       // [count][n]
     float *out_cost;         // [count]
@@ -36,6 +37,7 @@ hipError_t launch_two_opt_ref_lds(const TwoOptBatchArgs &A, uint32_t count, bool
 // two_opt_dm.hip — same algorithm, distances gathered from the packed matrix in HBM/L2
 size_t two_opt_ref_dm_lds_bytes(uint32_t n);
 hipError_t launch_two_opt_ref_dm(const TwoOptBatchArgs &A, uint32_t count, hipStream_t s);
+hipError_t launch_dm_expand_full(const float *packed, uint32_t n, float *full, hipStream_t s);
 
 // two_opt_best.hip — BEST_SWEEP mode (whole chip per sweep)
 struct BestSweepArgs {

@@ -1,11 +1,17 @@
-// two_opt_dm.hip — REF_ORDER 2-opt (src/tsp/two_opt.rs:26-61) with distances gathered from the
-// reference's packed lower-triangle matrix (distance_matrix.rs:177-191) resident in HBM/L2.
+// two_opt_dm.hip — REF_ORDER 2-opt (src/tsp/two_opt.rs:26-61) with every distance taken from the caller's matrix
+// (the reference's packed lower triangle, distance_matrix.rs:177-191) resident in HBM/L2.
 //
 // Used when the caller supplies `dm_packed` (EXPLICIT / GEO problems, and north-star config 2:
-// "fp32 distance matrix in HBM").  One persistent workgroup per descent; the tour (u32 positions)
-// lives in LDS.  A step speculatively decides 16 rows (one per wave, lanes along j) under "no move yet",
-// reduces the lexicographically first improving (i,j) (ballot/ffs per wave, ds_min_u32 on i<<16|j), applies
-// the reversal cooperatively and resumes at (i, j+1) — exactly the reference's loop order.
+// "fp32 distance matrix in HBM").  MI355X layout: the packed triangle is expanded once per call into a full
+// row-major n x n matrix in the context's workspace (k_dm_expand_full; 4 MB at n = 1002, sized for 288 GB of HBM),
+// because a row scan gathers D[a][perm[j]] for one a and all j: in the full matrix those 64 gathers of a wave fall
+// into the 4n bytes of row a (L1/L2-resident after the first touch), in the packed triangle every column > a sits in
+// a different cache line.  One persistent workgroup per descent; in LDS: the tour (u32 positions) and the lengths of
+// its edges, edge[j] = D[perm[j]][perm[j+1]] (the D[c][e] term of every candidate; a reversal reverses that array
+// too and its two new boundary edges are the D[a][c], D[b][e] the winning lane already holds).
+// A step speculatively decides 16 rows (one per wave, lanes along j, four 64-column tiles of gathers in flight) under
+// "no move yet", reduces the lexicographically first improving (i,j) (ballot/ffs per wave, ds_min_u32 on i<<16|j),
+// applies the reversal cooperatively and resumes at (i, j+1) — exactly the reference's loop order.
 // Algorithmic bytes per candidate: perm[j+1] 4 B + D[a][c] 4 B + D[b][e] 4 B + D[c][e] 4 B = 16 B
 // (SURVEY.md §8(d)); the row terms a, b, D[a][b] are amortised over the row.
 #include "tl_kernels.h"
@@ -17,16 +23,43 @@ namespace tl {
 namespace {
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 constexpr int kDmNT = 1024;
+constexpr int kDmTiles = 4;  // 64-column tiles whose gathers are in flight together (wide mode)
+}
+
+// packed strict lower triangle (idx(r > c) = r(r-1)/2 + c) -> full symmetric row-major n x n, zero diagonal
+// (distance_by_pos returns 0.0 for equal positions, distance_matrix.rs:181-183).  One workgroup per 64 x 64 tile of the
+// lower triangle: coalesced reads along a packed row, the mirrored tile through an LDS transpose.
+__global__ __launch_bounds__(256) void k_dm_expand_full(const float *__restrict__ packed, uint32_t n, float *__restrict__ full)
+{
+    __shared__ float tile[64][65];
+    const uint32_t tr = blockIdx.y, tc = blockIdx.x;
+    if (tc > tr) return;
+    const uint32_t lx = threadIdx.x & 63u, ly = threadIdx.x >> 6;  // 64 x 4
+    for (uint32_t rr = ly; rr < 64u; rr += 4u) {
+        const uint32_t r = tr * 64u + rr, c = tc * 64u + lx;
+        float v = 0.0f;
+        if (r < n && c < r) v = packed[(size_t)r * (r - 1u) / 2u + c];
+        tile[rr][lx] = v;
+        if (r < n && c < n && c <= r) full[(size_t)r * n + c] = v;
+    }
+    __syncthreads();
+    for (uint32_t rr = ly; rr < 64u; rr += 4u) {
+        // mirrored element: full[c'][r'] with c' = tc*64 + rr (row of the upper part), r' = tr*64 + lx
+        const uint32_t cu = tc * 64u + rr, ru = tr * 64u + lx;
+        if (cu < n && ru < n && cu < ru) full[(size_t)cu * n + ru] = tile[lx][rr];
+    }
 }
 
 __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t n = A.n;
+    const uint32_t nq = (n + 1u + 3u) & ~3u;
     uint32_t *perm = reinterpret_cast<uint32_t *>(smem);            // n + 1 (pad)
-    uint32_t *keys = perm + ((n + 1u + 3u) & ~3u);                  // 4 slots
-    float *scratch = reinterpret_cast<float *>(keys + 4);           // kDmNT floats
-    const float *__restrict__ dm = A.dm;
+    float *edge = reinterpret_cast<float *>(perm + nq);             // edge[j] = D[perm[j]][perm[j+1]], j < n-1
+    uint32_t *keys = reinterpret_cast<uint32_t *>(edge + nq);       // 4 slots
+    float *hv = reinterpret_cast<float *>(keys + 4);                // per wave: D[a][c], D[b][e] of its first improving lane
+    const float *__restrict__ dm = A.dm_full;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t d = blockIdx.x;
 
@@ -38,6 +71,8 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
     }
     if (tid == 0) perm[n] = 0;
     if (tid < 4) keys[tid] = kNoKey;
+    __syncthreads();
+    for (uint32_t k = tid; k + 1u < n; k += kDmNT) edge[k] = dm[(size_t)perm[k] * n + perm[k + 1u]];
     __syncthreads();
 
     const uint32_t nrows = n - 3;
@@ -59,48 +94,72 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
         // resumes at (i, j+1) like the reference.
         const bool wide = since_rows >= 4u;
         const uint32_t R = wide ? NWv : 1u;
+        const uint32_t jbase = j0 - (j0 & 63u);
         if (wide) {
             const uint32_t i = i0 + wave;
             if (i < nrows) {
                 const uint32_t a = perm[i], b = perm[i + 1u];
-                const float dab = dm_lookup(dm, a, b);
+                const float dab = edge[i];
+                const float *__restrict__ rowa = dm + (size_t)a * n;
+                const float *__restrict__ rowb = dm + (size_t)b * n;
                 const uint32_t jmin = wave == 0u ? j0 : i + 2u;
-                for (uint32_t jb = jmin - (jmin & 63u); jb <= n - 2u; jb += 64u) {
+                bool done = false;
+                for (uint32_t jb = jmin - (jmin & 63u); jb <= n - 2u && !done; jb += 64u * kDmTiles) {
                     const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)keys[slot]);
                     if (kb != kNoKey && ((kb >> 16) < i || ((kb >> 16) == i && (kb & 0xFFFFu) < jb))) break;  // an earlier hit exists
-                    const uint32_t j = jb + lane;
-                    bool imp = false;
-                    if (j >= jmin && j <= n - 2u) {
-                        const uint32_t c = perm[j], e = perm[j + 1u];
-                        const float cur = dab + dm_lookup(dm, c, e);                       // two_opt.rs:35-40
-                        const float neu = dm_lookup(dm, a, c) + dm_lookup(dm, b, e);       // two_opt.rs:42-47
-                        imp = neu < cur;                                                   // :49
+                    float dac[kDmTiles], dbe[kDmTiles], dce[kDmTiles];
+#pragma unroll
+                    for (int u = 0; u < kDmTiles; ++u) {
+                        const uint32_t j = jb + 64u * (uint32_t)u + lane;
+                        const uint32_t jj = j <= n - 2u ? j : n - 2u;  // lanes beyond the row read a valid column and are masked below
+                        const uint32_t c = perm[jj], e = perm[jj + 1u];
+                        dac[u] = rowa[c];
+                        dbe[u] = rowb[e];
+                        dce[u] = edge[jj];
                     }
-                    const uint64_t m = __builtin_amdgcn_ballot_w64(imp);
-                    if (m) {
-                        if (lane == 0) atomicMin(&keys[slot], (i << 16) | (jb + (uint32_t)(__builtin_ffsll((long long)m) - 1)));
-                        break;
+#pragma unroll
+                    for (int u = 0; u < kDmTiles; ++u) {
+                        const uint32_t j = jb + 64u * (uint32_t)u + lane;
+                        const float cur = dab + dce[u];                    // two_opt.rs:35-40
+                        const float neu = dac[u] + dbe[u];                 // two_opt.rs:42-47
+                        const bool imp = (j >= jmin) & (j <= n - 2u) & (neu < cur);  // :49
+                        const uint64_t m = __builtin_amdgcn_ballot_w64(imp);
+                        if (m && !done) {
+                            const uint32_t l = (uint32_t)(__builtin_ffsll((long long)m) - 1);
+                            if (lane == l) {
+                                atomicMin(&keys[slot], (i << 16) | j);
+                                hv[2u * wave] = dac[u];
+                                hv[2u * wave + 1u] = dbe[u];
+                            }
+                            done = true;
+                        }
                     }
                 }
             }
         } else {
             const uint32_t i = i0;
             const uint32_t a = perm[i], b = perm[i + 1u];
-            const float dab = dm_lookup(dm, a, b);
-            for (uint32_t jb = j0 - (j0 & 63u) + (wave << 6); jb <= n - 2u; jb += kDmNT) {
+            const float dab = edge[i];
+            const float *__restrict__ rowa = dm + (size_t)a * n;
+            const float *__restrict__ rowb = dm + (size_t)b * n;
+            for (uint32_t jb = jbase + (wave << 6); jb <= n - 2u; jb += kDmNT) {
                 const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)keys[slot]);
                 if (kb != kNoKey && (kb & 0xFFFFu) < jb) break;
                 const uint32_t j = jb + lane;
-                bool imp = false;
-                if (j >= j0 && j <= n - 2u) {
-                    const uint32_t c = perm[j], e = perm[j + 1u];
-                    const float cur = dab + dm_lookup(dm, c, e);
-                    const float neu = dm_lookup(dm, a, c) + dm_lookup(dm, b, e);
-                    imp = neu < cur;
-                }
+                const uint32_t jj = j <= n - 2u ? j : n - 2u;
+                const uint32_t c = perm[jj], e = perm[jj + 1u];
+                const float dac = rowa[c], dbe = rowb[e];
+                const float cur = dab + edge[jj];
+                const float neu = dac + dbe;
+                const bool imp = (j >= j0) & (j <= n - 2u) & (neu < cur);
                 const uint64_t m = __builtin_amdgcn_ballot_w64(imp);
                 if (m) {
-                    if (lane == 0) atomicMin(&keys[slot], (i << 16) | (jb + (uint32_t)(__builtin_ffsll((long long)m) - 1)));
+                    const uint32_t l = (uint32_t)(__builtin_ffsll((long long)m) - 1);
+                    if (lane == l) {
+                        atomicMin(&keys[slot], (i << 16) | j);
+                        hv[2u * wave] = dac;
+                        hv[2u * wave + 1u] = dbe;
+                    }
                     break;
                 }
             }
@@ -115,11 +174,25 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
             since_rows = 0;
             const uint32_t is = key >> 16, js = key & 0xFFFFu;
             const uint32_t lo = is + 1u, hi = js;  // swap_2opt(path, i+1, j), two_opt.rs:69-79
+            // the wave that posted the winning key: its row in a wide block, its tile of the row in a dense one
+            const uint32_t ww = wide ? is - i0 : ((js - jbase) >> 6) & (NWv - 1u);
             const uint32_t half = (hi - lo + 1u) >> 1;
             for (uint32_t t = tid; t < half; t += kDmNT) {
                 const uint32_t u = perm[lo + t], v = perm[hi - t];
                 perm[lo + t] = v;
                 perm[hi - t] = u;
+            }
+            // edges inside the segment keep their lengths in reversed order (the matrix is symmetric); the two boundary
+            // edges become (a, c) and (b, e)
+            const uint32_t ehalf = (hi - lo) >> 1;
+            for (uint32_t t = tid; t < ehalf; t += kDmNT) {
+                const float x = edge[lo + t], y = edge[hi - 1u - t];
+                edge[lo + t] = y;
+                edge[hi - 1u - t] = x;
+            }
+            if (tid == 0) {
+                edge[lo - 1u] = hv[2u * ww];
+                edge[hi] = hv[2u * ww + 1u];
             }
             __syncthreads();
             improved = true;
@@ -148,20 +221,11 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
     uint32_t *__restrict__ out = A.out_pos + (size_t)d * n;
     for (uint32_t k = tid; k < n; k += kDmNT) out[k] = perm[k];
 
-    // tour_length_by_pos (distance_matrix.rs:235-245), sequential f32 sum in tour order
-    float total = 0.0f;
-    if (n >= 2 && tid == 0) total = dm_lookup(dm, perm[n - 1], perm[0]);
-    for (uint32_t base = 0; base + 1 < n; base += kDmNT) {
-        const uint32_t k = base + tid;
-        scratch[tid] = (k + 1 < n) ? dm_lookup(dm, perm[k], perm[k + 1]) : 0.0f;
-        __syncthreads();
-        if (tid == 0) {
-            const uint32_t cnt = (n - 1 - base) < (uint32_t)kDmNT ? (n - 1 - base) : (uint32_t)kDmNT;
-            for (uint32_t q = 0; q < cnt; ++q) total += scratch[q];
-        }
-        __syncthreads();
-    }
+    // tour_length_by_pos (distance_matrix.rs:235-245): closing edge first, then the windows, sequential f32 sum
     if (tid == 0) {
+        float total = 0.0f;
+        if (n >= 2) total = dm[(size_t)perm[n - 1] * n + perm[0]];
+        for (uint32_t k = 0; k + 1u < n; ++k) total += edge[k];
         A.out_cost[d] = total;
         uint64_t *st = A.out_stats + (size_t)d * TL_STATS_STRIDE;
         st[0] = sweeps;
@@ -174,7 +238,14 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
 
 size_t two_opt_ref_dm_lds_bytes(uint32_t n)
 {
-    return (size_t)((n + 1u + 3u) & ~3u) * 4 + 16 + (size_t)kDmNT * 4;
+    return (size_t)((n + 1u + 3u) & ~3u) * 8 + 16 + (size_t)(kDmNT / 64) * 8;
+}
+
+hipError_t launch_dm_expand_full(const float *packed, uint32_t n, float *full, hipStream_t s)
+{
+    const uint32_t nt = (n + 63u) / 64u;
+    hipLaunchKernelGGL(k_dm_expand_full, dim3(nt, nt), dim3(256), 0, s, packed, n, full);
+    return hipGetLastError();
 }
 
 hipError_t launch_two_opt_ref_dm(const TwoOptBatchArgs &A, uint32_t count, hipStream_t s)

@@ -418,10 +418,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             since += (float)(js - j0);
             gap_est = 0.5f * (gap_est + since);
             since = 0.0f;
-            if (nh > 1u) {
-                const float w = __builtin_ldexpf(1.0f, -(int)(nh - 1u));
-                gap_est = gap_est * w + (float)(hlast - js) / (float)(nh - 1u) * (1.0f - w);
-            }
+            if (nh > 1u) gap_est = fminf(gap_est, 0.5f * gap_est + 16.0f);  // chained hits are < 64 columns apart
             improved = true;
             j0 = resume;
             const bool row_end = j0 > n - 2u;
