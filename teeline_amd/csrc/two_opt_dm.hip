@@ -23,7 +23,10 @@ namespace tl {
 namespace {
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 constexpr int kDmNT = 1024;
-constexpr int kDmTiles = 4;  // 64-column tiles whose gathers are in flight together (wide mode)
+#ifndef TL_DM_TILES
+#define TL_DM_TILES 4
+#endif
+constexpr int kDmTiles = TL_DM_TILES;  // 64-column tiles whose gathers are in flight together (wide mode)
 }
 
 // packed strict lower triangle (idx(r > c) = r(r-1)/2 + c) -> full symmetric row-major n x n, zero diagonal

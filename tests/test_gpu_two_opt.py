@@ -255,6 +255,15 @@ def test_config5_size_and_lds_limit(ctx):
     assert e.value.code == -6  # TL_ERR_UNSUPPORTED — never a CPU fallback
 
 
+def test_lds_limit_random_start_matches_oracle(ctx):
+    # the largest LDS-resident size from a random restart: rows with dozens of deferred reversals, composed flushes that
+    # span every register slot (15 x 1024 positions) and all four tile groups — tours, costs and counters as the oracle's
+    n = ctx.two_opt_lds_max_n()
+    xy = O.synth_xy(n, seed=3)
+    rp = O.restart_perm(n, 4242, 1)
+    assert_same(gpu_two_opt(ctx, xy, None, n, rp), O.two_opt(xy, None, n, init=rp), n)
+
+
 def test_large_n_path_matches_oracle(ctx, monkeypatch):
     # HBM-resident REF_ORDER path, forced on sizes the oracle finishes quickly: identical tours / costs / counters
     monkeypatch.setenv("TL_FORCE_LARGE_2OPT", "1")
