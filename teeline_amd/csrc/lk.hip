@@ -87,61 +87,170 @@ __global__ __launch_bounds__(256) void k_knn(const float2 *__restrict__ xy, uint
     }
 }
 
-// ---------------------------------------------------------------------------------------------- NN seed
-__global__ __launch_bounds__(kLkNT) void k_nn_seed(const float2 *__restrict__ xy, uint32_t n, const uint32_t *__restrict__ cand,
-                                                   uint32_t k, uint32_t *__restrict__ path, unsigned char *__restrict__ visited)
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_shr_keep(uint32_t v)
 {
-    __shared__ uint32_t s_len, s_cur;
-    __shared__ unsigned long long s_best;
-    const uint32_t tid = threadIdx.x;
+    // row_shr within rows of 16 lanes; lanes without a source keep their own value
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)  // the minimum over the wave, in every lane (as SGPR values)
+{
+    uint32_t o;
+    o = dpp_shr_keep<0x111>(v); v = o < v ? o : v;
+    o = dpp_shr_keep<0x112>(v); v = o < v ? o : v;
+    o = dpp_shr_keep<0x114>(v); v = o < v ? o : v;
+    o = dpp_shr_keep<0x118>(v); v = o < v ? o : v;  // lane 15 of each row: min of the row
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 47), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+
+// ---------------------------------------------------------------------------------------------- NN seed
+// nearest_neighbor::solve (nearest_neighbor.rs:8-76) is one sequential walk: n steps, each "first unvisited among the
+// n_nearest closest" (:44-49) or, failing that, the globally nearest unvisited city (:50-63; ties -> lowest position, the
+// oracle's rule where the reference iterates a HashSet).  One workgroup; what the walk touches per step lives in LDS so a
+// step costs LDS latencies, not HBM/L2 round trips: the visited flags (n bytes), the candidate lists as u16 positions
+// (2kn bytes, when n < 65536 and they fit) and, if there is room left, the coordinates for the fallback scans
+// (8n bytes).  Wave 0 walks (lane t checks the t-th nearest); the fallback scan is the whole workgroup in two u32 passes (smallest
+// squared distance, then the lowest position at the rounded minimum), DPP wave reductions, one LDS atomicMin per wave.
+constexpr int kNnRegs = 16;  // cities per thread whose coordinates stay in registers for the fallback scans (n <= 16 384)
+
+template <bool LDS_CAND, bool LDS_XY>
+__global__ __launch_bounds__(kLkNT) void k_nn_seed(const float2 *__restrict__ xy, uint32_t n, const uint32_t *__restrict__ cand,
+                                                   uint32_t k, uint32_t *__restrict__ path)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char nn_smem[];
+    __shared__ uint32_t s_len, s_cur, s_minsq, s_minpos;
+    unsigned char *visited = nn_smem;                                                      // n bytes
+    const size_t o_cand = ((size_t)n + 15u) & ~(size_t)15u;
+    uint16_t *lc = reinterpret_cast<uint16_t *>(nn_smem + o_cand);                         // k*n u16 (LDS_CAND)
+    const size_t o_xy = o_cand + (LDS_CAND ? ((((size_t)n * k * 2u) + 15u) & ~(size_t)15u) : 0u);
+    float2 *lxy = reinterpret_cast<float2 *>(nn_smem + o_xy);                              // n float2 (LDS_XY)
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
     for (uint32_t p = tid; p < n; p += kLkNT) visited[p] = 0;
+    if (LDS_CAND)
+        for (size_t e = tid; e < (size_t)n * k; e += kLkNT) lc[e] = (uint16_t)cand[e];    // 0xFFFFFFFF (no neighbour) -> 0xFFFF
+    if (LDS_XY)
+        for (uint32_t p = tid; p < n; p += kLkNT) lxy[p] = xy[p];
+    const bool regs = n <= (uint32_t)kNnRegs * kLkNT;
+    float2 rxy[kNnRegs];
+#pragma unroll
+    for (int m = 0; m < kNnRegs; ++m) {
+        const uint32_t p = tid + (uint32_t)m * kLkNT;
+        rxy[m] = (regs && p < n) ? xy[p] : make_float2(0.f, 0.f);
+    }
     __syncthreads();
     if (tid == 0) {
         path[0] = 0;  // :28 start = cities[0]
         visited[0] = 1;
         s_len = 1;
         s_cur = 0;
+        s_minsq = 0xFFFFFFFFu;
+        s_minpos = 0xFFFFFFFFu;
     }
     __syncthreads();
     while (true) {
-        if (tid == 0) {
-            uint32_t len = s_len, cur = s_cur;
-            while (len < n) {  // :44-49 first unvisited among the n_nearest closest
-                uint32_t nx = 0xFFFFFFFFu;
-                for (uint32_t t = 0; t < k; ++t) {
-                    const uint32_t q = cand[(size_t)cur * k + t];
-                    if (q != 0xFFFFFFFFu && !visited[q]) { nx = q; break; }
+        if (tid < 64u) {
+            // the walk (:44-49), wave 0: lane t looks at the t-th nearest of the current city, the first lane whose city is
+            // unvisited wins — two LDS latencies per step
+            uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_len), cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cur);
+            const uint32_t fb = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_minpos);
+            if (fb != 0xFFFFFFFFu) {  // the city the last fallback scan found
+                if (lane == 0) {
+                    path[len] = fb;
+                    visited[fb] = 1;
+                    s_minsq = 0xFFFFFFFFu;
+                    s_minpos = 0xFFFFFFFFu;
                 }
-                if (nx == 0xFFFFFFFFu) break;
-                path[len++] = nx;
-                visited[nx] = 1;
+                ++len;
+                cur = fb;
+            }
+            while (len < n) {
+                uint32_t q = 0xFFFFFFFFu;
+                if (lane < k) {
+                    if (LDS_CAND) {
+                        const uint32_t v = lc[(size_t)cur * k + lane];
+                        q = v == 0xFFFFu ? 0xFFFFFFFFu : v;
+                    } else {
+                        q = cand[(size_t)cur * k + lane];
+                    }
+                }
+                const bool open = q != 0xFFFFFFFFu && !visited[q];
+                const uint64_t m = __builtin_amdgcn_ballot_w64(open);
+                if (m == 0) break;
+                const uint32_t nx = (uint32_t)__builtin_amdgcn_readlane((int)q, __builtin_ffsll((long long)m) - 1);
+                if (lane == 0) {
+                    path[len] = nx;
+                    visited[nx] = 1;
+                }
+                ++len;
                 cur = nx;
             }
-            s_len = len;
-            s_cur = cur;
-            s_best = ~0ULL;
+            if (lane == 0) {
+                s_len = len;
+                s_cur = cur;
+            }
         }
         __syncthreads();
         if (s_len >= n) break;
-        // :50-63 fallback: globally nearest unvisited; ties -> lowest position (the reference iterates a HashSet)
+        // :50-63 fallback: globally nearest unvisited; ties -> lowest position (the reference iterates a HashSet).
+        // sqrt is monotone, so the nearest city has the smallest squared distance: pass 1 reduces min sq (u32 bits order
+        // like the floats), pass 2 takes the lowest position among the cities whose ROUNDED distance equals the rounded
+        // minimum (different squares can round to the same f32 distance, and the reference compares distances).
         const uint32_t cur = s_cur;
-        const float2 pc = xy[cur];
-        unsigned long long best = ~0ULL;
-        for (uint32_t p = tid; p < n; p += kLkNT) {
-            if (visited[p]) continue;
-            const float d = dist(pc, xy[p]);
-            const unsigned long long key = ((unsigned long long)__builtin_bit_cast(uint32_t, d) << 32) | p;
-            best = key < best ? key : best;
+        const float2 pc = LDS_XY ? lxy[cur] : xy[cur];
+        uint32_t msq = 0xFFFFFFFFu, mpos = 0xFFFFFFFFu;
+        if (regs) {
+            // this thread's cities (tid + 1024 m) never change: coordinates in registers, squared distances kept for pass 2
+            uint32_t sqb[kNnRegs];
+            unsigned char vis[kNnRegs];
+#pragma unroll
+            for (int m = 0; m < kNnRegs; ++m) {  // all flag reads in flight together (slots beyond n read a valid byte, masked below)
+                const uint32_t p = tid + (uint32_t)m * kLkNT;
+                vis[m] = visited[p < n ? p : 0u];
+            }
+#pragma unroll
+            for (int m = 0; m < kNnRegs; ++m) {
+                const uint32_t p = tid + (uint32_t)m * kLkNT;
+                const uint32_t b = __builtin_bit_cast(uint32_t, sqdist(pc, rxy[m]));
+                sqb[m] = (p < n && !vis[m]) ? b : 0xFFFFFFFFu;
+                msq = sqb[m] < msq ? sqb[m] : msq;
+            }
+            msq = wave_min_u32(msq);
+            if (lane == 0 && msq != 0xFFFFFFFFu) atomicMin(&s_minsq, msq);
+            __syncthreads();
+            const uint32_t gsq = s_minsq;
+            const float dmin = sqrt_rn(__builtin_bit_cast(float, gsq));
+            const uint32_t limb = __builtin_bit_cast(uint32_t, __builtin_bit_cast(float, gsq) * 1.000001f);
+#pragma unroll
+            for (int m = 0; m < kNnRegs; ++m) {
+                if (sqb[m] <= limb) {  // closed cities and slots beyond n carry 0xFFFFFFFF (uniform guards here measured slower)
+                    const uint32_t p = tid + (uint32_t)m * kLkNT;
+                    if (sqrt_rn(__builtin_bit_cast(float, sqb[m])) == dmin) mpos = p < mpos ? p : mpos;
+                }
+            }
+        } else {
+            for (uint32_t p = tid; p < n; p += kLkNT) {
+                if (visited[p]) continue;
+                const uint32_t b = __builtin_bit_cast(uint32_t, sqdist(pc, LDS_XY ? lxy[p] : xy[p]));
+                msq = b < msq ? b : msq;
+            }
+            msq = wave_min_u32(msq);
+            if (lane == 0 && msq != 0xFFFFFFFFu) atomicMin(&s_minsq, msq);
+            __syncthreads();
+            const uint32_t gsq = s_minsq;
+            const float dmin = sqrt_rn(__builtin_bit_cast(float, gsq));
+            // squares that can still round to dmin lie within a few ulps of the minimum; everything else is farther
+            const float lim = __builtin_bit_cast(float, gsq) * 1.000001f;
+            for (uint32_t p = tid; p < n; p += kLkNT) {
+                if (visited[p]) continue;
+                const float sq = sqdist(pc, LDS_XY ? lxy[p] : xy[p]);
+                if (sq <= lim && sqrt_rn(sq) == dmin) mpos = p < mpos ? p : mpos;
+            }
         }
-        if (best != ~0ULL) atomicMin(&s_best, best);
-        __syncthreads();
-        if (tid == 0) {
-            const uint32_t nx = (uint32_t)(s_best & 0xFFFFFFFFu);
-            path[s_len] = nx;
-            visited[nx] = 1;
-            s_len = s_len + 1;
-            s_cur = nx;
-        }
+        mpos = wave_min_u32(mpos);
+        if (lane == 0 && mpos != 0xFFFFFFFFu) atomicMin(&s_minpos, mpos);
         __syncthreads();
     }
 }
@@ -853,10 +962,27 @@ hipError_t launch_knn(const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, 
     return hipGetLastError();
 }
 
-hipError_t launch_nn_seed(const float2 *xy, uint32_t n, const uint32_t *cand, uint32_t k, uint32_t *path, unsigned char *visited, hipStream_t s)
+hipError_t launch_nn_seed(const float2 *xy, uint32_t n, const uint32_t *cand, uint32_t k, uint32_t *path, int lds_bytes, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_nn_seed, dim3(1), dim3(kLkNT), 0, s, xy, n, cand, k, path, visited);
-    return hipGetLastError();
+    // what fits into the CU's LDS next to the visited flags: the candidate lists (u16), then the coordinates
+    const size_t cap = (size_t)lds_bytes > 1024 ? (size_t)lds_bytes - 1024 : 0;  // static shared + slack
+    const size_t b_vis = ((size_t)n + 15u) & ~(size_t)15u;
+    const size_t b_cand = (((size_t)n * k * 2u) + 15u) & ~(size_t)15u;
+    const size_t b_xy = (size_t)n * 8u;
+    if (b_vis > cap) return hipErrorInvalidValue;  // n beyond ~160 K cities: callers check
+    const bool lds_cand = k > 0 && n < 65535u && b_vis + b_cand <= cap;
+    const bool lds_xy = b_vis + (lds_cand ? b_cand : 0) + b_xy <= cap;
+    const size_t lds = b_vis + (lds_cand ? b_cand : 0) + (lds_xy ? b_xy : 0);
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(1), dim3(kLkNT), lds, s, xy, n, cand, k, path);
+        return hipGetLastError();
+    };
+    if (lds_cand && lds_xy) return go(k_nn_seed<true, true>);
+    if (lds_cand) return go(k_nn_seed<true, false>);
+    if (lds_xy) return go(k_nn_seed<false, true>);
+    return go(k_nn_seed<false, false>);
 }
 
 hipError_t launch_lk_solve(const LkArgs &G, hipStream_t s)

@@ -947,12 +947,13 @@ static int nn_seed_dev(tl_ctx *c, const float2 *d_xy, uint32_t n, uint32_t n_nea
     uint32_t k = n_nearest > n - 1 ? n - 1 : n_nearest;
     if (k > 16) return fail(c, TL_ERR_UNSUPPORTED, "nearest_neighbor: n_nearest=%u > 16", n_nearest);
     int rc;
+    if ((size_t)n + 1024 > (size_t)c->lds_bytes)
+        return fail(c, TL_ERR_UNSUPPORTED, "nearest_neighbor: n=%u exceeds the LDS-resident visited flags (%d bytes of LDS)", n, c->lds_bytes);
     const size_t cand_b = ((size_t)n * (k ? k : 1) * 4 + 255) & ~(size_t)255;
-    if ((rc = ensure(c, c->misc, cand_b + n))) return rc;
+    if ((rc = ensure(c, c->misc, cand_b))) return rc;
     uint32_t *d_cand = (uint32_t *)c->misc.p;
-    unsigned char *d_vis = (unsigned char *)c->misc.p + cand_b;
     if (k) HIPCHK(c, launch_knn(d_xy, n, k, d_cand, c->stream));
-    HIPCHK(c, launch_nn_seed(d_xy, n, d_cand, k, d_path, d_vis, c->stream));
+    HIPCHK(c, launch_nn_seed(d_xy, n, d_cand, k, d_path, c->lds_bytes, c->stream));
     return TL_OK;
 }
 

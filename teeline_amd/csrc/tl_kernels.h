@@ -141,7 +141,7 @@ struct LkArgs {
     uint32_t lds_budget;    // LDS bytes a scan workgroup may use for its xy/next copies
 };
 hipError_t launch_knn(const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, hipStream_t s);
-hipError_t launch_nn_seed(const float2 *xy, uint32_t n, const uint32_t *cand, uint32_t k, uint32_t *path, unsigned char *visited, hipStream_t s);
+hipError_t launch_nn_seed(const float2 *xy, uint32_t n, const uint32_t *cand, uint32_t k, uint32_t *path, int lds_bytes, hipStream_t s);
 hipError_t launch_lk_solve(const LkArgs &G, hipStream_t s);
 hipError_t launch_lk_begin(const LkArgs &G, hipStream_t s);
 hipError_t launch_lk_round(const LkArgs &G, hipStream_t s);

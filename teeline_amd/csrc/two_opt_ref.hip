@@ -238,8 +238,14 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     uint64_t rows_total = 0, livetiles = 0, nflush = 0;
 #endif
 
+#ifdef TL_PROFILE2
+    uint64_t q2[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     uint32_t slot = 0;  // step % 3
     while (n >= 4) {
+#ifdef TL_PROFILE2
+        uint64_t t_it = __builtin_amdgcn_s_memtime();
+#endif
         // deferred reversals are applied (one call site) when their row is finished, when the hit register runs full, or when the
         // next block is a pruned one, which reads every row of the block
         if (np && (flush_due || (PRUNE && i0 < nrows && fmaxf(gap_est, since) > TL_DENSE_ROWS * (float)(n - 2u - i0)))) {
@@ -249,6 +255,9 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #endif
             rev_lane += flush_deferred<NT>(P, perm, pendv, prow + 1u, np, lane, wave);
             pendv = 0xFFFFFFFFu;
+#ifdef TL_PROFILE2
+            { const uint64_t t2 = __builtin_amdgcn_s_memtime(); q2[12] += t2 - t_it; t_it = t2; }
+#endif
             const uint32_t t0 = prow >> 6, t1 = hlast >> 6;  // L0 metadata of tiles with a changed position or tour-edge
             dirty_lo = t0 < dirty_lo ? t0 : dirty_lo;
             dirty_hi = t1 > dirty_hi ? t1 : dirty_hi;
@@ -389,6 +398,9 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         __syncthreads();
         TL_STAMP(3);
         const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->keys[slot]);
+#ifdef TL_PROFILE2
+        const uint32_t i0_before = i0;
+#endif
 #ifdef TL_PROFILE
         rows_total += (uint64_t)R;
 #endif
@@ -500,6 +512,15 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 j0 = i0 + 2u;
             }
         }
+#ifdef TL_PROFILE2
+        {
+            const uint64_t dt = __builtin_amdgcn_s_memtime() - t_it;
+            const int b = (pruned ? 0 : 6) + (key == kNoKey ? 3 : 0);
+            q2[b] += 1;
+            q2[b + 1] += dt;
+            q2[b + 2] += (key == kNoKey) ? (uint64_t)R : (uint64_t)((key >> 16) - i0_before);
+        }
+#endif
         slot = slot_next;
     }
 
@@ -548,6 +569,12 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         st[2] = reversed;
         st[3] = status;
         st[4] = step;
+#ifdef TL_PROFILE2
+        // [5..7] pruned hit steps: count, cycles, rows advanced; [8..10] pruned no-hit steps: count, cycles, rows;
+        // [11..12] dense hit steps: count, cycles; [13..14] dense no-hit: count, cycles; [15] flush cycles
+        st[5] = q2[0]; st[6] = q2[1]; st[7] = q2[2]; st[8] = q2[3]; st[9] = q2[4]; st[10] = q2[5];
+        st[11] = q2[6]; st[12] = q2[7]; st[13] = q2[9]; st[14] = q2[10]; st[15] = q2[12];
+#endif
 #ifdef TL_PROFILE
         // dense: [5]=setup+scan [6]=wait [7]=apply [8]=apply-barrier ; pruned: [9]=setup+phaseA [10]=barrier [11]=phaseB [12]=wait [13]=apply+barrier
         st[5] = prof[0] + prof[1] + prof[2];

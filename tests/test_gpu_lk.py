@@ -46,7 +46,10 @@ def test_nearest_neighbor_seed(ctx, tsplib_dir):
         rc, route, c = O.nearest_neighbor(d["xy"], None, d["n"], 3)
         assert f5(sol.total) == cost == f5(c)
         assert list(sol.route()) == d["ids"][route].tolist()
-    for xy, k in ((O.synth_xy(10000), 3), (lattice(12, 4), 3), (O.synth_xy(300, seed=9), 1), (O.synth_xy(300, seed=9), 7)):
+    # sizes chosen to hit every LDS placement of the walk's state: lists + coordinates (10^4), lists only (13 509),
+    # neither (20 000, k = 5), coordinates only (17 000, k = 16)
+    for xy, k in ((O.synth_xy(10000), 3), (lattice(12, 4), 3), (O.synth_xy(300, seed=9), 1), (O.synth_xy(300, seed=9), 7),
+                  (O.synth_xy(13509), 3), (O.synth_xy(20000, seed=2), 5), (O.synth_xy(17000, seed=4), 16)):
         sol = TA.nearest_neighbor.solve(prob(xy), TA.HeuristicOptions(n_nearest=k), ctx=ctx)
         rc, route, c = O.nearest_neighbor(xy, None, len(xy), k)
         assert list(sol.route()) == route.tolist() and np.float32(sol.total).tobytes() == np.float32(c).tobytes()
