@@ -33,6 +33,11 @@ namespace {
 
 constexpr float kLkEps = 1e-6f;  // lin_kernighan.rs:252
 constexpr int kLkNT = 1024;
+#ifndef TL_LK_WINDOW_MARGIN
+#define TL_LK_WINDOW_MARGIN 2048
+#endif
+constexpr uint32_t kLkWindowMargin = TL_LK_WINDOW_MARGIN;  // pairs scanned beyond the previous hit before the whole pass is looked at
+constexpr uint32_t kLkWindowFirst = 4096;                  // prefix of a fresh pass
 
 // ---------------------------------------------------------------------------------------------- k-NN
 template <int KMAX>
@@ -614,7 +619,7 @@ __global__ __launch_bounds__(256) void k_lk_scan(LkArgs G)
         }
         __syncthreads();
     }
-    if (idx >= 2u * n) return;
+    if (idx >= 2u * n || idx >= S->window) return;
     uint32_t chain[kLkMaxChain];
     uint32_t clen = 0;
     const uint32_t t1 = G.city_ids[idx >> 1];
@@ -697,6 +702,7 @@ __global__ __launch_bounds__(256) void k_lk_scan_sub(LkArgs G)
     const uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (g >= (uint64_t)2u * n * subs) return;
     const uint32_t idx = (uint32_t)(g / subs), sub = (uint32_t)(g % subs);
+    if (idx >= G.state->window) return;  // prefix window (k_lk_control)
     const uint32_t t1 = G.city_ids[idx >> 1];
     const uint32_t t2 = (idx & 1u) ? G.prev[t1] : G.next[t1];
     const float2 p1 = G.xy[t1], p2 = G.xy[t2];
@@ -714,7 +720,7 @@ __global__ __launch_bounds__(256) void k_lk_scan_pick(LkArgs G)
     LkState *S = G.state;
     if (S->finished) return;
     const uint32_t n = G.n, idx = blockIdx.x * 256u + threadIdx.x;
-    if (idx >= 2u * n) return;
+    if (idx >= 2u * n || idx >= S->window) return;
     const uint32_t sub = G.pairmin[idx];
     if (sub == 0xFFFFFFFFu) return;
     G.pairmin[idx] = 0xFFFFFFFFu;  // ready for the next scan
@@ -829,7 +835,17 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
             S->moves += 1;
             S->exchanged += clen / 2u;
             S->key = 0xFFFFFFFFu;
+            // find_lk_move restarts at pair 0 after every move (:468-478) and keeps the LOWEST pair with a valid chain, so a
+            // scan of a prefix that contains a hit is a complete scan.  The pairs before this hit had no valid chain a moment
+            // ago; the next hit is most often near or behind this one: look at [0, key + margin) first.
+            const uint32_t w = key + kLkWindowMargin;
+            S->window = w < 2u * n ? w : 2u * n;
         }
+        return;
+    }
+    if (S->window < 2u * n) {  // nothing inside the prefix: the same find_lk_move goes on over all pairs
+        __syncthreads();
+        if (tid == 0) S->window = 2u * n;
         return;
     }
     // ---- the scan found nothing: this lk_pass is over (:472-473)
@@ -897,7 +913,10 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
     __syncthreads();
     for (uint32_t r = tid; r < n; r += kLkNT) G.city_ids[r] = tour[r];
     rebuild();
-    if (tid == 0) S->key = 0xFFFFFFFFu;
+    if (tid == 0) {
+        S->key = 0xFFFFFFFFu;
+        S->window = kLkWindowFirst < 2u * n ? kLkWindowFirst : 2u * n;  // a fresh pass: hits start at the front
+    }
 }
 
 // first lk_pass of solve(): city_ids = tour, next/prev/pos from tour, state reset
@@ -922,6 +941,7 @@ __global__ __launch_bounds__(kLkNT) void k_lk_begin(LkArgs G)
         S->best_dist = 0.0f;
         S->draws = 0;
         S->scans = S->searches = S->moves = S->exchanged = 0;
+        S->window = kLkWindowFirst < 2u * n ? kLkWindowFirst : 2u * n;
     }
 }
 

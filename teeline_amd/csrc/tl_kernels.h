@@ -121,6 +121,8 @@ struct LkState {             // device-side state machine of the multi-CU LK var
     float best_dist;
     uint64_t draws;
     uint64_t scans, searches, moves, exchanged;
+    uint32_t window;         // pairs [0, window) the next scan looks at (a prefix: the lowest pair index wins anyway)
+    uint32_t pad_;
 };
 struct LkArgs {
     const float2 *xy;
