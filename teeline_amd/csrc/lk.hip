@@ -273,6 +273,8 @@ using LkView = LkViewT<uint32_t>;
 
 constexpr int kLkMaxDepth = 6;                       // compile-time recursion bound (default max_depth = 5)
 constexpr int kLkMaxChain = 2 * kLkMaxDepth + 2;
+constexpr uint32_t kLkSubSlot = 16;                 // u32 words per kept sub-search chain (len + kLkMaxChain cities, 64-byte slots)
+static_assert(kLkMaxChain + 1 <= 16, "sub-chain slot");
 
 template <int LEN>
 __device__ __forceinline__ bool in_chain(const uint32_t (&chain)[kLkMaxChain], uint32_t x)
@@ -712,7 +714,15 @@ __global__ __launch_bounds__(256) void k_lk_scan_sub(LkArgs G)
     chain[1] = t2;
     const float g0 = t1 == t2 ? 0.0f : dist(p1, p2);
     LkView V{G.xy, G.cand, G.next, G.k, G.max_depth};
-    if (lk_subsearch<uint32_t>(V, chain, clen, p1, t1, t2, p2, g0, sub / (G.k + 1u), sub % (G.k + 1u))) atomicMin(&G.pairmin[idx], sub);
+    if (lk_subsearch<uint32_t>(V, chain, clen, p1, t1, t2, p2, g0, sub / (G.k + 1u), sub % (G.k + 1u))) {
+        if (G.subchains) {  // keep the chain: the pick step reads the winner's instead of walking it again
+            uint32_t *slot = G.subchains + g * kLkSubSlot;
+            slot[0] = clen;
+#pragma unroll
+            for (int t = 0; t < kLkMaxChain; ++t) slot[1 + t] = chain[t];
+        }
+        atomicMin(&G.pairmin[idx], sub);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_lk_scan_pick(LkArgs G)
@@ -729,12 +739,21 @@ __global__ __launch_bounds__(256) void k_lk_scan_pick(LkArgs G)
     const float2 p1 = G.xy[t1], p2 = G.xy[t2];
     uint32_t chain[kLkMaxChain];
     uint32_t clen = 0;
-    chain[0] = t1;
-    chain[1] = t2;
-    const float g0 = t1 == t2 ? 0.0f : dist(p1, p2);
-    LkView V{G.xy, G.cand, G.next, G.k, G.max_depth};
-    if (lk_subsearch<uint32_t>(V, chain, clen, p1, t1, t2, p2, g0, sub / (G.k + 1u), sub % (G.k + 1u)) &&
-        chain_valid(chain, clen, G.tour, G.pos, n)) {
+    bool have;
+    if (G.subchains) {
+        const uint32_t *src = G.subchains + ((uint64_t)idx * (G.k * (G.k + 1u)) + sub) * kLkSubSlot;
+        clen = src[0];
+#pragma unroll
+        for (int t = 0; t < kLkMaxChain; ++t) chain[t] = src[1 + t];
+        have = true;
+    } else {
+        chain[0] = t1;
+        chain[1] = t2;
+        const float g0 = t1 == t2 ? 0.0f : dist(p1, p2);
+        LkView V{G.xy, G.cand, G.next, G.k, G.max_depth};
+        have = lk_subsearch<uint32_t>(V, chain, clen, p1, t1, t2, p2, g0, sub / (G.k + 1u), sub % (G.k + 1u));
+    }
+    if (have && chain_valid(chain, clen, G.tour, G.pos, n)) {
         uint32_t *slot = G.chains + (size_t)idx * (kLkMaxChain + 2);
         slot[0] = clen;
         for (uint32_t t = 0; t < clen; ++t) slot[1 + t] = chain[t];

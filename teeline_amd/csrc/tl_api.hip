@@ -1004,7 +1004,12 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const uint32_t *ini
     const bool multi_cu = n >= (getenv("TL_LK_MULTI_MIN_N") ? (uint32_t)atoi(getenv("TL_LK_MULTI_MIN_N")) : 0u);
     const size_t o_pairmin = o_chains + (multi_cu ? up((size_t)2 * n * lk_chain_slot_words() * 4) : 0);
     const bool split_scan = multi_cu && max_depth_ge2_split(o.max_depth) && !getenv("TL_LK_NO_SPLIT");
-    const size_t total = o_pairmin + (split_scan ? up((size_t)2 * n * 4) : 0);
+    // every successful sub-search keeps its chain (64 B) so that the pick step does not walk the winner again; sized for
+    // 288 GB of HBM (45 MB at n = 13 509, k = 5), skipped beyond 4 GB
+    const size_t sub_b = split_scan ? (size_t)2 * n * k * (k + 1) * 64 : 0;
+    const bool keep_sub = split_scan && sub_b <= ((size_t)4 << 30) && !getenv("TL_LK_NO_SUBCHAINS");
+    const size_t o_sub = o_pairmin + (split_scan ? up((size_t)2 * n * 4) : 0);
+    const size_t total = o_sub + (keep_sub ? up(sub_b) : 0);
     if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->work, total)) || (rc = ensure(c, c->out_cost, 4))) return rc;
     unsigned char *w = (unsigned char *)c->work.p;
     HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
@@ -1038,6 +1043,7 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const uint32_t *ini
     G.state = (LkState *)(w + o_state);
     G.chains = (uint32_t *)(w + o_chains);
     G.pairmin = split_scan ? (uint32_t *)(w + o_pairmin) : nullptr;
+    G.subchains = keep_sub ? (uint32_t *)(w + o_sub) : nullptr;
     if (split_scan) HIPCHK(c, hipMemsetAsync(G.pairmin, 0xFF, (size_t)2 * n * 4, c->stream));
     uint64_t cnt[4] = {0, 0, 0, 0};
     if (!multi_cu) {

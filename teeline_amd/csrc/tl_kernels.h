@@ -138,6 +138,8 @@ struct LkArgs {
     LkState *state;         // multi-CU variant
     uint32_t *chains;       // multi-CU variant: [2n][kLkMaxChain + 2] chain slots
     uint32_t *pairmin;      // split scan: [2n] minimum sub-search index with a chain (0xFFFFFFFF: none); nullptr = unsplit scan
+    uint32_t *subchains;    // split scan: [2n * k(k+1)][16] the chain each successful sub-search found (len, cities), or nullptr:
+                            // k_lk_scan_pick then reads the winner's chain instead of walking it again
     uint64_t seed;
     uint32_t n, k, max_depth, epochs, platoo_epochs;
     uint32_t lds_budget;    // LDS bytes a scan workgroup may use for its xy/next copies
