@@ -271,6 +271,11 @@ struct LkViewT {
 };
 using LkView = LkViewT<uint32_t>;
 
+__host__ __device__ __forceinline__ uint32_t lk_subs(const LkArgs &G)  // sub-searches per (t1, orientation) pair
+{
+    return G.k * (G.k + 1u) * (G.split_levels == 3u ? G.k + 1u : 1u);
+}
+
 constexpr int kLkMaxDepth = 6;                       // compile-time recursion bound (default max_depth = 5)
 constexpr int kLkMaxChain = 2 * kLkMaxDepth + 2;
 constexpr uint32_t kLkSubSlot = 16;                 // u32 words per kept sub-search chain (len + kLkMaxChain cities, 64-byte slots)
@@ -697,10 +702,86 @@ __device__ bool lk_subsearch(const LkViewT<NextT> &V, uint32_t (&chain)[kLkMaxCh
     return lk_chain<2, NextT>(V, chain, clen, p1, t6, p6, g4);
 }
 
+// One explicit branch of find_lk_chain's loop (:290-337) at depth D: candidate q of t_open.  On success the chain grows by
+// (t_next, t_break) and (t_open, p_open, gain) move on; a rejected branch returns false (for the `break` at g1 <= EPS see
+// the exactness note above: it is implied by the later branches' own tests).
+template <int D, typename NextT>
+__device__ __forceinline__ bool lk_branch(const LkViewT<NextT> &V, uint32_t (&chain)[kLkMaxChain], uint32_t &t_open, float2 &p_open,
+                                          float &gain, const uint32_t q)
+{
+    const uint32_t t_next = V.cand[(size_t)t_open * V.k + q];
+    const float2 p_next = V.xy[t_next];
+    const float g1 = gain - dist(p_open, p_next);
+    if (g1 <= kLkEps) return false;
+    if (in_chain<2 * D + 2>(chain, t_next)) return false;
+    const uint32_t t_break = V.next[t_next];
+    if ((uint32_t)V.next[t_open] == t_next || t_break == t_open) return false;
+    if (in_chain<2 * D + 2>(chain, t_break)) return false;
+    const float2 p_break = V.xy[t_break];
+    chain[2 * D + 2] = t_next;
+    chain[2 * D + 3] = t_break;
+    gain = g1 + dist(p_next, p_break);
+    t_open = t_break;
+    p_open = p_break;
+    return true;
+}
+
+// Three split levels: sub = (q1 (k+1) + s1)(k+1) + s2 — branch q1 at depth 0; at depth 1 the closing test (s1 = 0) or
+// branch s1-1; at depth 2 the closing test (s2 = 0) or branch s2-1, below which the walk is sequential (lk_chain<3>: at most
+// k^2 nodes instead of k^3).  Lexicographic order of (q1, s1, s2) is the reference's DFS order, so the minimum index with a
+// chain is the chain the sequential search returns; (q1, 0, s2 > 0) does not exist.
+template <typename NextT>
+__device__ bool lk_subsearch3(const LkViewT<NextT> &V, uint32_t (&chain)[kLkMaxChain], uint32_t &clen, const float2 p1,
+                              const uint32_t t2, const float2 p2, const float g0, const uint32_t q1, const uint32_t s1, const uint32_t s2)
+{
+    uint32_t t_open = t2;
+    float2 p_open = p2;
+    float gain = g0;
+    if (0u >= V.max_depth) return false;
+    if (!lk_branch<0, NextT>(V, chain, t_open, p_open, gain, q1)) return false;
+    {   // depth 1 (:280-288)
+        const float close_gain = gain - dist(p_open, p1);
+        if (s1 == 0u) {
+            if (s2 == 0u && close_gain > kLkEps) {
+                clen = 4;
+                return true;
+            }
+            return false;
+        }
+        if (close_gain > kLkEps) return false;  // the sequential search returned at s1 = 0
+        if (1u >= V.max_depth) return false;
+    }
+    if (!lk_branch<1, NextT>(V, chain, t_open, p_open, gain, s1 - 1u)) return false;
+    {   // depth 2
+        const float close_gain = gain - dist(p_open, p1);
+        if (s2 == 0u) {
+            if (close_gain > kLkEps) {
+                clen = 6;
+                return true;
+            }
+            return false;
+        }
+        if (close_gain > kLkEps) return false;
+        if (2u >= V.max_depth) return false;
+    }
+    if (!lk_branch<2, NextT>(V, chain, t_open, p_open, gain, s2 - 1u)) return false;
+    return lk_chain<3, NextT>(V, chain, clen, p1, t_open, p_open, gain);
+}
+
+// the sub-search `sub` of pair (t1, t2) under the launch's split depth
+__device__ __forceinline__ bool lk_run_sub(const LkArgs &G, uint32_t (&chain)[kLkMaxChain], uint32_t &clen, const float2 p1, const uint32_t t1,
+                                           const uint32_t t2, const float2 p2, const float g0, const uint32_t sub)
+{
+    LkView V{G.xy, G.cand, G.next, G.k, G.max_depth};
+    const uint32_t k1 = G.k + 1u;
+    if (G.split_levels == 3u) return lk_subsearch3<uint32_t>(V, chain, clen, p1, t2, p2, g0, sub / (k1 * k1), (sub / k1) % k1, sub % k1);
+    return lk_subsearch<uint32_t>(V, chain, clen, p1, t1, t2, p2, g0, sub / k1, sub % k1);
+}
+
 __global__ __launch_bounds__(256) void k_lk_scan_sub(LkArgs G)
 {
     if (G.state->finished) return;
-    const uint32_t n = G.n, subs = G.k * (G.k + 1u);
+    const uint32_t n = G.n, subs = lk_subs(G);
     const uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (g >= (uint64_t)2u * n * subs) return;
     const uint32_t idx = (uint32_t)(g / subs), sub = (uint32_t)(g % subs);
@@ -713,8 +794,7 @@ __global__ __launch_bounds__(256) void k_lk_scan_sub(LkArgs G)
     chain[0] = t1;
     chain[1] = t2;
     const float g0 = t1 == t2 ? 0.0f : dist(p1, p2);
-    LkView V{G.xy, G.cand, G.next, G.k, G.max_depth};
-    if (lk_subsearch<uint32_t>(V, chain, clen, p1, t1, t2, p2, g0, sub / (G.k + 1u), sub % (G.k + 1u))) {
+    if (lk_run_sub(G, chain, clen, p1, t1, t2, p2, g0, sub)) {
         if (G.subchains) {  // keep the chain: the pick step reads the winner's instead of walking it again
             uint32_t *slot = G.subchains + g * kLkSubSlot;
             slot[0] = clen;
@@ -741,7 +821,7 @@ __global__ __launch_bounds__(256) void k_lk_scan_pick(LkArgs G)
     uint32_t clen = 0;
     bool have;
     if (G.subchains) {
-        const uint32_t *src = G.subchains + ((uint64_t)idx * (G.k * (G.k + 1u)) + sub) * kLkSubSlot;
+        const uint32_t *src = G.subchains + ((uint64_t)idx * lk_subs(G) + sub) * kLkSubSlot;
         clen = src[0];
 #pragma unroll
         for (int t = 0; t < kLkMaxChain; ++t) chain[t] = src[1 + t];
@@ -750,8 +830,7 @@ __global__ __launch_bounds__(256) void k_lk_scan_pick(LkArgs G)
         chain[0] = t1;
         chain[1] = t2;
         const float g0 = t1 == t2 ? 0.0f : dist(p1, p2);
-        LkView V{G.xy, G.cand, G.next, G.k, G.max_depth};
-        have = lk_subsearch<uint32_t>(V, chain, clen, p1, t1, t2, p2, g0, sub / (G.k + 1u), sub % (G.k + 1u));
+        have = lk_run_sub(G, chain, clen, p1, t1, t2, p2, g0, sub);
     }
     if (have && chain_valid(chain, clen, G.tour, G.pos, n)) {
         uint32_t *slot = G.chains + (size_t)idx * (kLkMaxChain + 2);
@@ -973,7 +1052,7 @@ hipError_t launch_lk_begin(const LkArgs &G, hipStream_t s)
 hipError_t launch_lk_round(const LkArgs &G, hipStream_t s)
 {
     if (G.pairmin) {  // split scan
-        const uint64_t lanes = (uint64_t)2u * G.n * G.k * (G.k + 1u);
+        const uint64_t lanes = (uint64_t)2u * G.n * G.k * (G.k + 1u) * (G.split_levels == 3u ? G.k + 1u : 1u);
         hipLaunchKernelGGL(k_lk_scan_sub, dim3((uint32_t)((lanes + 255u) / 256u)), dim3(256), 0, s, G);
         hipLaunchKernelGGL(k_lk_scan_pick, dim3((2u * G.n + 255u) / 256u), dim3(256), 0, s, G);
     } else {

@@ -1006,7 +1006,10 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const uint32_t *ini
     const bool split_scan = multi_cu && max_depth_ge2_split(o.max_depth) && !getenv("TL_LK_NO_SPLIT");
     // every successful sub-search keeps its chain (64 B) so that the pick step does not walk the winner again; sized for
     // 288 GB of HBM (45 MB at n = 13 509, k = 5), skipped beyond 4 GB
-    const size_t sub_b = split_scan ? (size_t)2 * n * k * (k + 1) * 64 : 0;
+    // three split levels (k(k+1)^2 sub-searches per pair: the sequential part of a walk shrinks to k^2 nodes) while their
+    // kept chains fit 4 GB, else two
+    const uint32_t levels = (split_scan && !getenv("TL_LK_SPLIT2") && (size_t)2 * n * k * (k + 1) * (k + 1) * 64 <= ((size_t)4 << 30)) ? 3u : 2u;
+    const size_t sub_b = split_scan ? (size_t)2 * n * k * (k + 1) * (levels == 3u ? k + 1 : 1) * 64 : 0;
     const bool keep_sub = split_scan && sub_b <= ((size_t)4 << 30) && !getenv("TL_LK_NO_SUBCHAINS");
     const size_t o_sub = o_pairmin + (split_scan ? up((size_t)2 * n * 4) : 0);
     const size_t total = o_sub + (keep_sub ? up(sub_b) : 0);
@@ -1044,6 +1047,7 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const uint32_t *ini
     G.chains = (uint32_t *)(w + o_chains);
     G.pairmin = split_scan ? (uint32_t *)(w + o_pairmin) : nullptr;
     G.subchains = keep_sub ? (uint32_t *)(w + o_sub) : nullptr;
+    G.split_levels = levels;
     if (split_scan) HIPCHK(c, hipMemsetAsync(G.pairmin, 0xFF, (size_t)2 * n * 4, c->stream));
     uint64_t cnt[4] = {0, 0, 0, 0};
     if (!multi_cu) {

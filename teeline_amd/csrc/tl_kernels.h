@@ -143,6 +143,7 @@ struct LkArgs {
     uint64_t seed;
     uint32_t n, k, max_depth, epochs, platoo_epochs;
     uint32_t lds_budget;    // LDS bytes a scan workgroup may use for its xy/next copies
+    uint32_t split_levels;  // split scan: 2 = k(k+1) sub-searches per pair, 3 = k(k+1)^2
 };
 hipError_t launch_knn(const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, hipStream_t s);
 hipError_t launch_nn_seed(const float2 *xy, uint32_t n, const uint32_t *cand, uint32_t k, uint32_t *path, int lds_bytes, hipStream_t s);

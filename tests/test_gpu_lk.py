@@ -120,7 +120,7 @@ def test_lk_other_instances(ctx, case, tsplib_dir):
 
 
 def test_lk_variants_are_identical(ctx, tsplib_dir, monkeypatch):
-    # default = scans spread over all CUs, each pair's chain search split into k*(k+1) sub-searches, device-side control
+    # default = scans spread over all CUs, each pair's chain search split into k*(k+1)^2 sub-searches (TL_LK_SPLIT2: k*(k+1)), device-side control
     # state machine, kept sub-search chains.  The unsplit scan, the single persistent workgroup and the pick step that walks the
     # winning chain again must reproduce the same results (= the oracle's).
     xy = T.parse_tsplib(os.path.join(tsplib_dir, "berlin52.tsp"))["xy"]
@@ -128,7 +128,7 @@ def test_lk_variants_are_identical(ctx, tsplib_dir, monkeypatch):
     xy2 = O.synth_xy(200, seed=4)
     sq = np.array([[0, 0], [1, 1], [1, 0], [0, 1]], np.float32)
     tri = np.array([[0, 0], [1, 0], [0.5, 1]], np.float32)
-    for env in ({"TL_LK_NO_SPLIT": "1"}, {"TL_LK_MULTI_MIN_N": "1000000"}, {"TL_LK_NO_SUBCHAINS": "1"}):
+    for env in ({"TL_LK_NO_SPLIT": "1"}, {"TL_LK_MULTI_MIN_N": "1000000"}, {"TL_LK_NO_SUBCHAINS": "1"}, {"TL_LK_SPLIT2": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         for seed in (1, 2):
