@@ -122,6 +122,8 @@ def main():
     sweeps_dev = torch.zeros((), dtype=torch.int64, device=dev)
     stream.wait_stream(torch.cuda.current_stream())
 
+    best_tour = [None]
+
     def step(count_it=False, events=None):
         with torch.cuda.stream(stream):
             if events is not None:
@@ -133,8 +135,11 @@ def main():
                 events[1].record(stream)
             if count_it:
                 sweeps_dev.add_(d_stats[:, 0].sum())
-            # RCCL over xGMI: one 8-byte min-all-reduce per round
-            return TA.multistart.allreduce_best(TA.multistart.pack_keys(d_cost, first), dist)
+            # RCCL over xGMI: one 8-byte min-all-reduce per round, then the winner's tour (n x 4 B) to every rank
+            keys = TA.multistart.pack_keys(d_cost, first)
+            best = TA.multistart.allreduce_best(keys, dist)
+            best_tour[0] = TA.multistart.share_best_tour(keys, d_pos, best, dist)
+            return best
 
     def sync():
         torch.cuda.synchronize()
@@ -168,6 +173,8 @@ def main():
             dist.destroy_process_group()
         return
 
+    bt = best_tour[0].cpu().numpy()
+    assert sorted(bt.tolist()) == list(range(n)), "the shared best tour is not a permutation"
     status_bad = int((d_stats[:, 3] != 0).sum().item())
     k_ms = float(np.mean(kernel_ms))
     cand_per_launch = cands / a.steps
@@ -187,7 +194,7 @@ def main():
                                f"REF_ORDER 2-opt to local optimum, {R} seeded random restarts per GPU (one descent per CU), "
                                f"on-the-fly f32 distances, tour resident in LDS",
                    "n": n, "restarts_per_gpu": R, "restarts_total": R * world, "mode": "REF_ORDER",
-                   "restart_seed": a.seed, "collective": "RCCL min-all-reduce of (cost_bits<<32|restart) per step" if world > 1 else "none (1 GPU)"},
+                   "restart_seed": a.seed, "collective": "RCCL min-all-reduce of (cost_bits<<32|restart) per step + SUM-all-reduce of the winner's tour (n x 4 B)" if world > 1 else "none (1 GPU)"},
         "final_tour_cost": best_cost, "best_restart": best_restart,
         "candidates_per_step_per_gpu": cand_per_launch,
         "descents_not_converged": status_bad,

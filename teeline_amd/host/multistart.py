@@ -1,5 +1,6 @@
 """Multi-GPU multi-start plumbing (north-star config 4): one process per GPU, restarts sharded by rank, and
-one RCCL min-all-reduce of an 8-byte key per round.  No counterpart in the reference.
+one RCCL min-all-reduce of an 8-byte key per round, followed by the winning tour (n x 4 B) to every rank.  No counterpart
+in the reference.
 
 key = (f32 cost bits << 32) | restart id — order-preserving for cost >= 0, ties go to the lowest restart id,
 identical to tl_pack_cost_key in the C ABI.  The collective runs on whatever backend the process group was
@@ -30,9 +31,25 @@ def unpack_key(key):
 def allreduce_best(local_keys, dist=None):
     """min over the local keys, then min-all-reduce across ranks; returns a 1-element int64 tensor."""
     best = local_keys.min().reshape(1)
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():  # also with one rank (bench.py's TL_BENCH_FORCE_DIST rehearsal of the RCCL path)
         dist.all_reduce(best, op=dist.ReduceOp.MIN)
     return best
+
+
+def share_best_tour(local_keys, local_tours, best_key, dist=None):
+    """The tour behind `best_key` on every rank, without a host round trip: the rank whose local minimum IS the global key
+    contributes that tour, everybody else zeros, and one SUM-all-reduce of n x 4 B (40 KB at n = 10^4) delivers it —
+    restart ids are unique across ranks, so exactly one rank matches.  (all-reduce the key, then hand the
+    owner's tour round; a broadcast would need the owner's rank on the host first.)
+    local_keys int64 [R], local_tours int32 [R, n], best_key int64 [1] from allreduce_best."""
+    idx = local_keys.argmin()
+    tour = local_tours[idx]
+    if dist is None or not dist.is_initialized():
+        return tour.clone()
+    mine = (local_keys[idx] == best_key[0])
+    buf = torch.where(mine, tour, torch.zeros_like(tour))
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    return buf
 
 
 def aggregate_throughput(candidates_local, seconds_local, device, dist=None):

@@ -39,17 +39,19 @@ def _worker(rank, port, outq):
     try:
         xy = synth.synth_xy(N)
         first, count = ms.shard(rank, R_PER_RANK)
-        costs, cands = [], 0
+        costs, cands, tours = [], 0, []
         for r in range(first, first + count):
             init = synth.restart_perm(N, SEED, r)
             rc, p, c, st = O.two_opt(xy, None, N, init=init)
             costs.append(c)
+            tours.append(np.asarray(p, dtype=np.int32))
             cands += st["candidates"]
         keys = ms.pack_keys(torch.tensor(np.asarray(costs, dtype=np.float32)), first)
         best = ms.allreduce_best(keys, dist)
+        shared = ms.share_best_tour(keys, torch.tensor(np.stack(tours)), best, dist)
         total, tmax = ms.aggregate_throughput(cands, 1.0 + rank, torch.device("cpu"), dist)
         dist.barrier()
-        outq.put((rank, int(best.item()), total, tmax, [float(c) for c in costs], cands))
+        outq.put((rank, int(best.item()), total, tmax, [float(c) for c in costs], cands, shared.tolist(), [t.tolist() for t in tours]))
     finally:
         dist.destroy_process_group()
 
@@ -71,6 +73,9 @@ def test_two_rank_min_allreduce_of_best_tour_key():
     cost, restart = ms.unpack_key(res[0][1])
     want = min(range(len(all_costs)), key=lambda i: (np.float32(all_costs[i]), i))
     assert restart == want and np.float32(cost) == np.float32(all_costs[want])
+    # ... and with the winner's tour (one SUM-all-reduce, only the owner contributes)
+    all_tours = res[0][7] + res[1][7]
+    assert res[0][6] == res[1][6] == all_tours[want]
     # whole-job accounting: candidates are summed, time is the slowest rank's
     assert res[0][2] == res[1][2] == res[0][5] + res[1][5]
     assert res[0][3] == res[1][3] == 2.0
