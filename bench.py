@@ -268,6 +268,20 @@ def main():
         gb = n * (n - 1) / 2 * 4 / 1e9
         extras["dm_build_packed"] = {"kernel_ms": ms, "GBps": gb / (ms * 1e-3), "frac_of_hbm_peak": gb / (ms * 1e-3) / HBM_PEAK_GBPS,
                                      "bytes": n * (n - 1) // 2 * 4}
+        # the HBM-bound kernel of the path (DistanceMatrix::build): a roofline object of its own, traffic from its PMC passes
+        rdm = {"bound": "hbm", "achieved": gb / (ms * 1e-3), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gb / (ms * 1e-3) / HBM_PEAK_GBPS,
+               "traffic": None, "kernel": "k_dm_build_packed_rows", "kernel_ms_avg": ms,
+               "note": "4 B written per distance; a plain fill of the same 200 MB reaches 6.65 TB/s on this part (scripts/hbm_fill_probe.py), "
+                       "the build is at the VALU/HBM crossover (DESIGN.md §4.1)"}
+        dpath = os.path.join(ROOT, "profiles", "r01_dm_build_hbm_traffic.json")
+        if os.path.exists(dpath) and n == 10000:
+            try:
+                dj = json.load(open(dpath))
+                rdm["traffic"] = dj.get("traffic_bytes_per_launch")
+                rdm["traffic_source"] = dj.get("source")
+            except Exception:
+                pass
+        extras["dm_build_packed"]["roofline"] = rdm
         # BASELINE configs[1]: pr1002-sized instance (the file is not in the reference tree -> synthetic n = 1002, labelled),
         # full REF_ORDER sweep to the local optimum with every distance gathered from the fp32 matrix in HBM
         n2 = 1002

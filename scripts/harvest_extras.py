@@ -1,0 +1,49 @@
+"""Copy the judged summaries of a scripts/profile_extras.sh run from gpurun_out/<round>_extras/ into profiles/ (tracked)."""
+import csv, glob, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+G = os.path.join(ROOT, "gpurun_out", rnd + "_extras")
+P = os.path.join(ROOT, "profiles")
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(G, pattern))
+    return f[0] if f else None
+
+
+def own_rows(src, dst):
+    rows = list(csv.reader(open(src)))
+    with open(dst, "w", newline="") as fh:
+        w = csv.writer(fh, quoting=csv.QUOTE_NONNUMERIC)
+        w.writerow(rows[0])
+        for r in rows[1:]:
+            if "tl::" in r[0]:
+                w.writerow(r)
+
+
+for sub, name in (("extras", "bench_extras"), ("lk", "lk"), ("dm_stats", "dm_build")):
+    ks = one(f"{sub}/*/*kernel_stats.csv")
+    if ks:
+        own_rows(ks, os.path.join(P, f"{rnd}_{name}_kernel_stats.csv"))
+vals = {}
+for name in ("write", "fetch"):
+    cc = one(f"dm_{name}/*/*counter_collection.csv")
+    if not cc:
+        continue
+    by = {}
+    for r in csv.DictReader(open(cc)):
+        if "k_dm_build" in r["Kernel_Name"]:
+            by[r["Dispatch_Id"]] = by.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+    if by:
+        vals[name] = by[sorted(by, key=int)[-1]]  # the second (warm) build
+if len(vals) == 2:
+    n = 10000
+    json.dump({
+        "kernel": "k_dm_build_packed_rows", "n": n,
+        "write_size_kb_raw": vals["write"], "fetch_size_kb_raw": vals["fetch"],
+        "traffic_bytes_per_launch": (2 * vals["fetch"] + vals["write"]) * 1024,
+        "algorithmic_bytes_per_launch": n * (n - 1) // 2 * 4,
+        "source": "rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE (separate passes) on scripts/dm_build_once.py, second build; "
+                  "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md §HBM",
+    }, open(os.path.join(P, f"{rnd}_dm_build_hbm_traffic.json"), "w"), indent=1)
+print("harvested", rnd, vals)
