@@ -924,9 +924,13 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
             }
         }
         __syncthreads();
-        for (uint32_t r = tid; r < n; r += kLkNT) tour[r] = alt[r];
-        __syncthreads();
-        rebuild();
+        for (uint32_t r = tid; r < n; r += kLkNT) {  // copy back and rebuild rank / successor / predecessor in the same pass
+            const uint32_t c = alt[r];
+            tour[r] = c;
+            pos[c] = r;
+            next[c] = alt[r + 1u == n ? 0u : r + 1u];
+            prev[c] = alt[r == 0u ? n - 1u : r - 1u];
+        }
         if (tid == 0) {
             S->scans += 1;
             S->searches += (uint64_t)key + 1u;
