@@ -130,7 +130,9 @@ int tl_tour_length(tl_ctx *ctx, const float *xy, const float *dm_packed, uint32_
 
 /* ---- 2-opt: replaces two_opt::solve (two_opt.rs:7-67) ---------------------------------------- */
 /* init_pos NULL = city order (two_opt.rs:18-20).  out_pos: n entries.  out_cost = tour_length(out_pos)
- * as Solution::from_parts computes it (mod.rs:1776-1789). */
+ * as Solution::from_parts computes it (mod.rs:1776-1789).  With dm_packed (EXPLICIT / GEO, "matrix in HBM") every
+ * distance is read from the matrix, which is expanded on the device to a full row-major n x n copy (4 n^2 bytes of
+ * HBM) and the tour plus its edge lengths live in LDS: n <= ~19 900 on 160 KB (TL_ERR_UNSUPPORTED beyond). */
 int tl_two_opt(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed,
                const uint32_t *init_pos, int mode, uint32_t *out_pos, float *out_cost,
                tl_stats *stats);
@@ -163,7 +165,8 @@ int tl_build_candidates(tl_ctx *ctx, const float *xy, uint32_t n, uint32_t k, ui
 
 /* ---- NN seed: replaces nearest_neighbor::solve (nearest_neighbor.rs:8-76), EUC_2D ------------- */
 /* First unvisited among the n_nearest closest (stable ties, mod.rs:1848-1855), else the globally
- * nearest unvisited (tie -> lowest position; the reference iterates a HashSet there). */
+ * nearest unvisited (tie -> lowest position; the reference iterates a HashSet there).  The walk's visited flags
+ * live in one CU's LDS (n bytes): n <= ~160 000 (TL_ERR_UNSUPPORTED beyond); n_nearest <= 16. */
 int tl_nearest_neighbor(tl_ctx *ctx, const float *xy, uint32_t n, uint32_t n_nearest, uint32_t *out_pos,
                         float *out_cost);
 
