@@ -1,0 +1,45 @@
+"""Developer probe: a long randomized parity campaign of REF_ORDER 2-opt (coordinate and matrix form) against the oracle.
+   python tests/probes/fuzz_campaign.py [seconds]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, _oracle as O, teeline_amd as TA
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+t0 = time.time(); runs = fails = 0
+with TA.Context(0) as ctx, TA.Context(0, TA.TL_FLAG_NO_PRUNE) as ctx2:
+    seed = 0
+    while time.time() - t0 < budget:
+        seed += 1
+        rng = np.random.default_rng(seed)
+        n = int(rng.integers(4, 3200)) if seed % 4 else int(rng.integers(4, 200))
+        kind = seed % 6
+        if kind == 0: xy = rng.random((n, 2)) * 1000
+        elif kind == 1: xy = rng.integers(0, int(rng.integers(2, 40)), (n, 2))
+        elif kind == 2:
+            c = rng.random((int(rng.integers(2, 12)), 2)) * 1000; xy = c[rng.integers(0, len(c), n)] + rng.normal(0, 0.5, (n, 2))
+        elif kind == 3:
+            t = np.sort(rng.random(n)) * 1000; xy = np.stack([t, 0.25 * t], 1)          # sorted collinear: long chains per row
+        elif kind == 4:
+            a = np.sort(rng.random(n)) * 2 * np.pi; xy = np.stack([np.cos(a), np.sin(a)], 1) * 300 + 300
+        else: xy = rng.normal(0, 1, (n, 2)) * 10.0 ** rng.integers(-3, 4, (n, 1))
+        xy = np.ascontiguousarray(xy, dtype=np.float32)
+        start = seed % 3
+        init = None if start == 0 else (O.restart_perm(n, seed, 0) if start == 1 else np.arange(n, dtype=np.uint32)[::-1].copy())
+        rc, route, cost, st = O.two_opt(xy, None, n, init=init)
+        prob = TA.TspProblem(np.arange(n), xy)
+        cases = [("coord", prob, ctx)]
+        if seed % 5 == 0: cases.append(("noprune", prob, ctx2))
+        if n <= 1500 and seed % 3 == 0:
+            dm = TA.distance_matrix.build(np.arange(n), xy, ctx=ctx)
+            cases.append(("matrix", TA.TspProblem(np.arange(n), xy, TA.distance_matrix.DistanceMatrix(n, dm.items, np.arange(n), "explicit")), ctx))
+        for name, p, c in cases:
+            sol = TA.two_opt.solve(p, None, None, None if init is None else [int(v) for v in init], ctx=c)
+            a, b = np.float32(sol.total), np.float32(cost)
+            ok = list(sol.route()) == route.tolist() and (a.tobytes() == b.tobytes() or (np.isnan(a) and np.isnan(b))) and \
+                (sol.stats["sweeps"], sol.stats["moves"], sol.stats["reversed"]) == (st["sweeps"], st["moves"], st["reversed"])
+            runs += 1
+            if not ok:
+                fails += 1
+                print(f"MISMATCH seed={seed} n={n} kind={kind} start={start} form={name}: gpu {float(a)!r} {sol.stats['moves']} vs oracle {float(b)!r} {st['moves']}", flush=True)
+print(f"fuzz campaign: {runs} runs, {fails} mismatches, {time.time() - t0:.0f} s")
