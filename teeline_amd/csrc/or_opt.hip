@@ -6,10 +6,11 @@
 //   rev_delta with first/last swapped; the move with the lowest delta below -1e-3 wins, first in loop order
 //   (seg_len, i, j, forward-before-reversed) on ties (strict `<`, :141,153).  apply_relocation (:170-184).
 //
-// Best-improvement, so one pass is a whole-chip scan: one wave per (seg_len, i) row, lanes along j, every f32
-// expression associated exactly as the reference writes it; argmin by a packed 64-bit key
+// Best-improvement, so one pass is a whole-chip scan: a wave takes 8 consecutive segment starts x a slab of insertion
+// points (lanes along j) and shares the distances between the five placement kinds and the 8 starts (k_or_scan), every
+// f32 expression associated exactly as the reference writes it; argmin by a packed 64-bit key
 // (~delta_bits << 32 | loop-order index) reduced per wave, per workgroup, then by k_or_pick, which also applies the
-// relocation in place.  Exact distances (correctly rounded sqrt) — no pruning yet; roofline: VALU.
+// relocation in place.  Exact distances (correctly rounded sqrt); roofline: VALU.
 #include "tl_kernels.h"
 
 #pragma clang fp contract(off)
@@ -19,6 +20,9 @@ namespace tl {
 namespace {
 
 constexpr int kOrWaves = 4;
+constexpr int kOrIR = 8;          // consecutive segment starts served from one set of distance registers
+constexpr uint32_t kOrTargetWaves = 4096;  // waves a scan should at least consist of: small tours take fewer 63-wide chunks of
+                                           // insertion points per wave (or_opt_chunks)
 constexpr unsigned long long kNoKey64 = ~0ULL;
 
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
@@ -29,6 +33,17 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     }
     return __shfl(v, 0);
 }
+
+static uint32_t or_opt_grid_x(uint32_t n) { return ((n + kOrIR - 1) / kOrIR + kOrWaves - 1) / kOrWaves; }
+static uint32_t or_opt_chunks(uint32_t n)  // 63-wide chunks of insertion points per wave
+{
+    const uint32_t total = (n + 62u) / 63u, groups = (n + kOrIR - 1) / kOrIR;
+    uint32_t slabs = (kOrTargetWaves + groups - 1u) / groups;
+    if (slabs > total) slabs = total;
+    if (slabs == 0u) slabs = 1u;
+    return (total + slabs - 1u) / slabs;
+}
+static uint32_t or_opt_grid_y(uint32_t n) { return ((n + 62u) / 63u + or_opt_chunks(n) - 1u) / or_opt_chunks(n); }
 
 template <bool DM>
 struct Dist {
@@ -44,38 +59,88 @@ struct Dist {
 
 }  // namespace
 
+// One wave = kOrIR consecutive segment starts i0..i0+kOrIR-1 x a slab of insertion points (kOrChunks chunks of 63).
+// Every placement of the five kinds (len 1 fwd; len 2, 3 fwd and reversed) of a pair (i, j) is a sum of the row constant,
+// the tour edge (x_j, y_j) and two distances out of { d(x_j, P[i+m]), d(y_j, P[i+m]) : m = 0, 1, 2 } — and y_j = x_{j+1}.
+// So a chunk computes d(x_j, P[i0+m]) once for m = 0..kOrIR+1 (lane = j, lane 63 only supplies x of the next j),
+// gets the y-distances from the neighbouring lane, and serves all kOrIR starts from those registers: 1.25 correctly
+// rounded distances per (i, j) instead of the 10 a row-per-wave scan evaluates.  The f32 expressions keep the
+// reference's association (or_opt.rs:136-139, :148-151); distances are symmetric bit for bit.
 template <bool DM>
-__global__ __launch_bounds__(kOrWaves * 64) void k_or_scan(OrOptArgs A)
+__global__ __launch_bounds__(kOrWaves * 64) void k_or_scan(OrOptArgs A, uint32_t chunks)
 {
     __shared__ unsigned long long s_key[kOrWaves];
     const uint32_t n = A.n;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t row = blockIdx.x * kOrWaves + (uint32_t)wave;  // (seg_len - 1) * n + i
+    const uint32_t i0 = (blockIdx.x * kOrWaves + (uint32_t)wave) * kOrIR;
+    const uint32_t jlo = blockIdx.y * (chunks * 63u);
     unsigned long long best = kNoKey64;
-    const uint32_t seg_len = row / n + 1u, i = row % n;
-    if (row < 3u * n && n > seg_len + 1u && i + seg_len <= n) {  // :90-92, :98-100
+    float bestd = __builtin_inff();
+    if (i0 < n) {
         const Dist<DM> D{A.Pt, A.dm, A.perm};
-        const uint32_t prev = i == 0u ? n - 1u : i - 1u;
-        const uint32_t after = (i + seg_len) % n;
-        const uint32_t pf = i, pl = i + seg_len - 1u;
-        const float remove_gain = D(prev, pf) + D(pl, after) - D(prev, after);  // :114-116
-        const float neg_rg = -remove_gain;
-        for (uint32_t j = (uint32_t)lane; j < n; j += 64u) {
-            if (j == prev || (j >= i && j < i + seg_len)) continue;  // :123-125
-            const uint32_t jy = j + 1u == n ? 0u : j + 1u;
-            const float edge_xy = A.E[j];
-            const float fwd = neg_rg + D(j, pf) + D(pl, jy) - edge_xy;  // :136-139
-            const unsigned long long order = ((unsigned long long)row * n + j) * 2ull;
-            if (fwd < -1e-3f) {
-                const unsigned long long key = ((unsigned long long)(~__builtin_bit_cast(uint32_t, fwd)) << 32) | order;
-                best = key < best ? key : best;
+        // row constants: lane (len-1)*kOrIR + r holds -remove_gain of (seg_len, i0 + r) (:114-116), rowmask its validity (:90-92, :98-100)
+        float nrg = 0.0f;
+        bool rv = false;
+        if (lane < 3 * kOrIR) {
+            const uint32_t len = (uint32_t)lane / kOrIR + 1u, i = i0 + (uint32_t)lane % kOrIR;
+            rv = i < n && n > len + 1u && i + len <= n;
+            if (rv) {
+                const uint32_t prev = i == 0u ? n - 1u : i - 1u, after = (i + len) % n, pl = i + len - 1u;
+                const float remove_gain = D(prev, i) + D(pl, after) - D(prev, after);
+                nrg = -remove_gain;
             }
-            if (seg_len > 1u) {
-                const float rev = neg_rg + D(j, pl) + D(pf, jy) - edge_xy;  // :148-151
-                if (rev < -1e-3f) {
-                    const unsigned long long key = ((unsigned long long)(~__builtin_bit_cast(uint32_t, rev)) << 32) | (order + 1ull);
-                    best = key < best ? key : best;
+        }
+        const uint64_t rowmask = __builtin_amdgcn_ballot_w64(rv);
+        for (uint32_t c = 0; c < chunks; ++c) {
+            const uint32_t jb = jlo + c * 63u;
+            if (jb >= n) break;
+            const uint32_t j = jb + (uint32_t)lane;
+            const bool real = lane < 63 && j < n;
+            const uint32_t jj = j < n ? j : 0u;  // position of x_j; j == n is the wrap (y of j = n-1 is P[0]), lanes beyond are unused
+            const float e = real ? A.E[j] : 0.0f;
+            float dX[kOrIR + 2], dY[kOrIR + 2];
+#pragma unroll
+            for (int m = 0; m < kOrIR + 2; ++m) {
+                const uint32_t pm = i0 + (uint32_t)m < n ? i0 + (uint32_t)m : n - 1u;  // beyond the tour: unused by any valid row
+                dX[m] = D(jj, pm);
+                // d(y_j, P[i0+m]) = d(x_{j+1}, P[i0+m]): the lane above, one DPP wave shift (lane 63, the helper lane, gets 0)
+                dY[m] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dX[m]), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+            }
+#pragma unroll
+            for (int r = 0; r < kOrIR; ++r) {
+                const uint32_t i = i0 + (uint32_t)r;
+                if (i >= n) break;
+                const uint32_t prev = i == 0u ? n - 1u : i - 1u;
+#pragma unroll
+                for (int len = 1; len <= 3; ++len) {
+                    const int rl = (len - 1) * kOrIR + r;
+                    if (!((rowmask >> rl) & 1ull)) continue;  // wave-uniform
+                    const bool ok = real & (j != prev) & !((j - i) < (uint32_t)len);  // :123-125
+                    const float nr = readlane_f(nrg, rl);
+                    const unsigned long long order = ((unsigned long long)((uint32_t)(len - 1) * n + i) * n + j) * 2ull;
+                    {
+                        const float fwd = nr + dX[r] + dY[r + len - 1] - e;  // :136-139  -rg + d(x,first) + d(last,y) - d(x,y)
+                        const bool cnd = ok & (fwd < -1e-3f) & (fwd <= bestd);
+                        if (__builtin_amdgcn_ballot_w64(cnd)) {
+                            const unsigned long long key = ((unsigned long long)(~__builtin_bit_cast(uint32_t, fwd)) << 32) | order;
+                            if (cnd && key < best) {
+                                best = key;
+                                bestd = fwd;
+                            }
+                        }
+                    }
+                    if (len > 1) {
+                        const float rev = nr + dX[r + len - 1] + dY[r] - e;  // :148-151  -rg + d(x,last) + d(first,y) - d(x,y)
+                        const bool cnd = ok & (rev < -1e-3f) & (rev <= bestd);
+                        if (__builtin_amdgcn_ballot_w64(cnd)) {
+                            const unsigned long long key = ((unsigned long long)(~__builtin_bit_cast(uint32_t, rev)) << 32) | (order + 1ull);
+                            if (cnd && key < best) {
+                                best = key;
+                                bestd = rev;
+                            }
+                        }
+                    }
                 }
             }
         }
@@ -86,7 +151,7 @@ __global__ __launch_bounds__(kOrWaves * 64) void k_or_scan(OrOptArgs A)
     if (threadIdx.x == 0) {
         unsigned long long k = s_key[0];
         for (int w = 1; w < kOrWaves; ++w) k = s_key[w] < k ? s_key[w] : k;
-        A.partials[blockIdx.x] = k;
+        A.partials[blockIdx.y * gridDim.x + blockIdx.x] = k;
     }
 }
 
@@ -151,14 +216,14 @@ __global__ __launch_bounds__(1024) void k_or_pick(OrOptArgs A, uint32_t nblocks,
 
 hipError_t launch_or_opt_pass(const OrOptArgs &A, bool dm, int apply, hipStream_t s)
 {
-    const uint32_t rows = 3u * A.n, nblocks = (rows + kOrWaves - 1) / kOrWaves;
+    const uint32_t gx = or_opt_grid_x(A.n), gy = or_opt_grid_y(A.n), nblocks = gx * gy;
     const uint32_t pg = (A.n + 255u) / 256u;
     if (dm) {
         hipLaunchKernelGGL(k_or_prepare<true>, dim3(pg), dim3(256), 0, s, A);
-        hipLaunchKernelGGL(k_or_scan<true>, dim3(nblocks), dim3(kOrWaves * 64), 0, s, A);
+        hipLaunchKernelGGL(k_or_scan<true>, dim3(gx, gy), dim3(kOrWaves * 64), 0, s, A, or_opt_chunks(A.n));
     } else {
         hipLaunchKernelGGL(k_or_prepare<false>, dim3(pg), dim3(256), 0, s, A);
-        hipLaunchKernelGGL(k_or_scan<false>, dim3(nblocks), dim3(kOrWaves * 64), 0, s, A);
+        hipLaunchKernelGGL(k_or_scan<false>, dim3(gx, gy), dim3(kOrWaves * 64), 0, s, A, or_opt_chunks(A.n));
     }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_or_pick), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)A.n * 4));
     if (e != hipSuccess) return e;
@@ -166,6 +231,6 @@ hipError_t launch_or_opt_pass(const OrOptArgs &A, bool dm, int apply, hipStream_
     return hipGetLastError();
 }
 
-uint32_t or_opt_scan_blocks(uint32_t n) { return (3u * n + kOrWaves - 1) / kOrWaves; }
+uint32_t or_opt_scan_blocks(uint32_t n) { return or_opt_grid_x(n) * or_opt_grid_y(n); }
 
 }  // namespace tl
