@@ -329,11 +329,43 @@ struct Arcs {
     uint32_t k;
 };
 
-__device__ __forceinline__ void arcs_build(const uint32_t (&chain)[kLkMaxChain], uint32_t clen, const uint32_t *pos, uint32_t n, Arcs &A)
+// Tour positions of the chain's cities, all loads independent (one L2 latency).  Every arc boundary of the arc model is the
+// position of a chain city, so the validity walk and the application need no further pos[] / tour[] look-ups: the city
+// at a boundary position is found among these (index_at), its added-edge partner by index (partner_index).
+__device__ __forceinline__ void chain_positions(const uint32_t (&chain)[kLkMaxChain], uint32_t clen, const uint32_t *pos,
+                                                uint32_t (&cpos)[kLkMaxChain])
+{
+#pragma unroll
+    for (int t = 0; t < kLkMaxChain; ++t) cpos[t] = (uint32_t)t < clen ? pos[chain[t]] : 0xFFFFFFFFu;
+}
+__device__ __forceinline__ uint32_t sel_at(const uint32_t (&a)[kLkMaxChain], uint32_t idx)
+{
+    uint32_t r = 0xFFFFFFFFu;
+#pragma unroll
+    for (int t = 0; t < kLkMaxChain; ++t) r = ((uint32_t)t == idx) ? a[t] : r;
+    return r;
+}
+__device__ __forceinline__ uint32_t index_at(const uint32_t (&cpos)[kLkMaxChain], uint32_t clen, uint32_t p)
+{
+    uint32_t idx = 0xFFFFFFFFu;
+#pragma unroll
+    for (int t = kLkMaxChain - 1; t >= 0; --t) idx = ((uint32_t)t < clen && cpos[t] == p) ? (uint32_t)t : idx;
+    return idx;
+}
+__device__ __forceinline__ uint32_t partner_index(uint32_t t, uint32_t clen)  // the city joined to chain[t] by an added edge
+{
+    if (t == 0u) return clen - 1u;
+    if (t == clen - 1u) return 0u;
+    return (t & 1u) ? t + 1u : t - 1u;
+}
+
+__device__ __forceinline__ void arcs_build(const uint32_t (&cpos)[kLkMaxChain], uint32_t clen, uint32_t n, Arcs &A)
 {
     A.k = clen / 2;
-    for (uint32_t m = 0; m < A.k; ++m) {
-        const uint32_t pu = pos[chain[2 * m]], pv = pos[chain[2 * m + 1]];
+#pragma unroll
+    for (int m = 0; m < kLkMaxDepth + 1; ++m) {
+        if ((uint32_t)m >= A.k) break;
+        const uint32_t pu = cpos[2 * m], pv = cpos[2 * m + 1];
         // adjacent positions: the edge sits after the one whose successor is the other
         A.lo[m] = ((pu + 1u == pv) || (pu == n - 1u && pv == 0u)) ? pu : pv;
     }
@@ -386,16 +418,20 @@ __device__ __forceinline__ uint32_t chain_partner(const uint32_t (&chain)[kLkMax
 __device__ bool chain_valid(const uint32_t (&chain)[kLkMaxChain], uint32_t clen, const uint32_t *tour, const uint32_t *pos, uint32_t n)
 {
     if (clen < 4) return false;
+    uint32_t cpos[kLkMaxChain];
+    chain_positions(chain, clen, pos, cpos);
     Arcs A;
-    arcs_build(chain, clen, pos, n, A);
-    uint32_t city = chain[0], arcs = 0;
+    arcs_build(cpos, clen, n, A);
+    uint32_t ti = 0, arcs = 0;  // chain cities are distinct: back at index 0 <=> back at chain[0]
     do {
-        const uint32_t p = pos[city];
+        const uint32_t p = sel_at(cpos, ti);
         const uint32_t other = arc_is_start(A, p, n) ? arc_end_from_start(A, p) : arc_start_from_end(A, p, n);
         ++arcs;
         if (arcs > A.k) return false;
-        city = chain_partner(chain, clen, tour[other]);
-    } while (city != chain[0]);
+        const uint32_t tj = index_at(cpos, clen, other);  // the city at an arc boundary is a chain city
+        if (tj == 0xFFFFFFFFu) return false;
+        ti = partner_index(tj, clen);
+    } while (ti != 0u);
     return arcs == A.k;
 }
 
@@ -500,8 +536,10 @@ __global__ __launch_bounds__(kLkNT) void k_lk_solve(LkArgs G)
                 uint32_t chain[kLkMaxChain];
                 const uint32_t clen = s_clen;
                 for (uint32_t t = 0; t < clen; ++t) chain[t] = s_chain[t];
+                uint32_t cpos[kLkMaxChain];
+                chain_positions(chain, clen, pos, cpos);
                 Arcs A;
-                arcs_build(chain, clen, pos, n, A);
+                arcs_build(cpos, clen, n, A);
                 bool first_removed = false;  // is the edge (tour[0], tour[1]) one of the removed ones?
                 for (uint32_t m = 0; m < A.k; ++m) first_removed |= (A.lo[m] == 0u);
                 uint32_t nseg = 0, emitted = 0;
@@ -523,8 +561,7 @@ __global__ __launch_bounds__(kLkNT) void k_lk_solve(LkArgs G)
                     ++nseg;
                     emitted += len;
                     if (emitted >= n) break;
-                    const uint32_t city = chain_partner(chain, clen, tour[endp]);
-                    p = pos[city];
+                    p = sel_at(cpos, partner_index(index_at(cpos, clen, endp), clen));  // position of the boundary city's added-edge partner
                     dir = arc_is_start(A, p, n) ? +1 : -1;
                 }
                 s_nseg = nseg;
@@ -890,8 +927,10 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
         if (tid == 0) {
             uint32_t chain[kLkMaxChain];
             for (uint32_t t = 0; t < clen; ++t) chain[t] = slot[1 + t];
+            uint32_t cpos[kLkMaxChain];
+            chain_positions(chain, clen, pos, cpos);
             Arcs A;
-            arcs_build(chain, clen, pos, n, A);
+            arcs_build(cpos, clen, n, A);
             bool first_removed = false;
             for (uint32_t m = 0; m < A.k; ++m) first_removed |= (A.lo[m] == 0u);
             uint32_t nseg = 0, emitted = 0, p = 0;
@@ -907,8 +946,7 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
                 ++nseg;
                 emitted += len;
                 if (emitted >= n) break;
-                const uint32_t city = chain_partner(chain, clen, tour[endp]);
-                p = pos[city];
+                p = sel_at(cpos, partner_index(index_at(cpos, clen, endp), clen));  // position of the boundary city's added-edge partner
                 dir = arc_is_start(A, p, n) ? +1 : -1;
             }
             s_nseg = nseg;
