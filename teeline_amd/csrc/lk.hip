@@ -37,6 +37,7 @@ constexpr int kLkNT = 1024;
 #define TL_LK_WINDOW_MARGIN 2048
 #endif
 constexpr uint32_t kLkWindowMargin = TL_LK_WINDOW_MARGIN;  // pairs scanned beyond the previous hit before the whole pass is looked at
+constexpr uint32_t kLkRebuildSplitN = 1500;                // from this size on the post-move rebuild is its own chip-wide kernel
 constexpr uint32_t kLkWindowFirst = 4096;                  // prefix of a fresh pass
 
 // ---------------------------------------------------------------------------------------------- k-NN
@@ -919,6 +920,7 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
     };
 
     const uint32_t key = S->key;
+    if (tid == 0) S->applied = 0u;  // set again below if this round applies a move (k_lk_rebuild runs after every control)
     __syncthreads();
     if (key != 0xFFFFFFFFu) {
         // ---- apply_lk_chain (:397-450), then rescan (lk_pass loop :468-478)
@@ -961,15 +963,20 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
                 alt[sg.dst + t] = tour[sp];
             }
         }
-        __syncthreads();
-        for (uint32_t r = tid; r < n; r += kLkNT) {  // copy back and rebuild rank / successor / predecessor in the same pass
-            const uint32_t c = alt[r];
-            tour[r] = c;
-            pos[c] = r;
-            next[c] = alt[r + 1u == n ? 0u : r + 1u];
-            prev[c] = alt[r == 0u ? n - 1u : r - 1u];
+        // the new tour is in `alt`: copy it back and rebuild rank / successor / predecessor — here for small tours, in
+        // k_lk_rebuild on all CUs for large ones (3n scattered stores are slow from one CU)
+        if (n < kLkRebuildSplitN) {
+            __syncthreads();
+            for (uint32_t r = tid; r < n; r += kLkNT) {
+                const uint32_t c = alt[r];
+                tour[r] = c;
+                pos[c] = r;
+                next[c] = alt[r + 1u == n ? 0u : r + 1u];
+                prev[c] = alt[r == 0u ? n - 1u : r - 1u];
+            }
         }
         if (tid == 0) {
+            S->applied = n < kLkRebuildSplitN ? 0u : 1u;
             S->scans += 1;
             S->searches += (uint64_t)key + 1u;
             S->moves += 1;
@@ -1059,6 +1066,20 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
     }
 }
 
+// after a move: tour = alt, rank / successor / predecessor of every city — spread over the chip
+__global__ __launch_bounds__(256) void k_lk_rebuild(LkArgs G)
+{
+    LkState *S = G.state;
+    if (S->finished || !S->applied) return;
+    const uint32_t n = G.n, r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t c = G.alt[r];
+    G.tour[r] = c;
+    G.pos[c] = r;
+    G.next[c] = G.alt[r + 1u == n ? 0u : r + 1u];
+    G.prev[c] = G.alt[r == 0u ? n - 1u : r - 1u];
+}
+
 // first lk_pass of solve(): city_ids = tour, next/prev/pos from tour, state reset
 __global__ __launch_bounds__(kLkNT) void k_lk_begin(LkArgs G)
 {
@@ -1082,6 +1103,7 @@ __global__ __launch_bounds__(kLkNT) void k_lk_begin(LkArgs G)
         S->draws = 0;
         S->scans = S->searches = S->moves = S->exchanged = 0;
         S->window = kLkWindowFirst < 2u * n ? kLkWindowFirst : 2u * n;
+        S->applied = 0u;
     }
 }
 
@@ -1108,6 +1130,7 @@ hipError_t launch_lk_round(const LkArgs &G, hipStream_t s)
         }
     }
     hipLaunchKernelGGL(k_lk_control, dim3(1), dim3(kLkNT), 0, s, G);
+    if (G.n >= kLkRebuildSplitN) hipLaunchKernelGGL(k_lk_rebuild, dim3((G.n + 255u) / 256u), dim3(256), 0, s, G);
     return hipGetLastError();
 }
 

@@ -122,7 +122,7 @@ struct LkState {             // device-side state machine of the multi-CU LK var
     uint64_t draws;
     uint64_t scans, searches, moves, exchanged;
     uint32_t window;         // pairs [0, window) the next scan looks at (a prefix: the lowest pair index wins anyway)
-    uint32_t pad_;
+    uint32_t applied;        // k_lk_control applied a move into `alt`: k_lk_rebuild copies it back and rebuilds pos / next / prev
 };
 struct LkArgs {
     const float2 *xy;
