@@ -288,7 +288,7 @@ static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uin
         if ((rc2 = ensure(c, c->dmfull, (size_t)n * n * 4))) return rc2;
         HIPCHK(c, launch_dm_expand_full(d_dm, n, (float *)c->dmfull.p, s));
         A.dm_full = (const float *)c->dmfull.p;
-        HIPCHK(c, launch_two_opt_ref_dm(A, count, s));
+        HIPCHK(c, launch_two_opt_ref_dm(A, count, c->lds_bytes, s));
     } else {
         const uint32_t nmax = lds_max_n(c->lds_bytes);
         if (n > nmax)

@@ -36,7 +36,7 @@ hipError_t launch_two_opt_ref_lds(const TwoOptBatchArgs &A, uint32_t count, bool
 
 // two_opt_dm.hip — same algorithm, distances gathered from the packed matrix in HBM/L2
 size_t two_opt_ref_dm_lds_bytes(uint32_t n);
-hipError_t launch_two_opt_ref_dm(const TwoOptBatchArgs &A, uint32_t count, hipStream_t s);
+hipError_t launch_two_opt_ref_dm(const TwoOptBatchArgs &A, uint32_t count, int lds_budget, hipStream_t s);
 hipError_t launch_dm_expand_full(const float *packed, uint32_t n, float *full, hipStream_t s);
 
 // two_opt_best.hip — BEST_SWEEP mode (whole chip per sweep)

@@ -53,6 +53,10 @@ __global__ __launch_bounds__(256) void k_dm_expand_full(const float *__restrict_
     }
 }
 
+// STAGE (small tours: 32 matrix rows fit the LDS next to the tour, n <= ~1170 — pr1002 does): in a wide block every wave
+// copies its two matrix rows a and b into LDS with coalesced loads and gathers D[a][c], D[b][e] from there; a fully
+// divergent global gather costs the CU's address unit ~64 cycles per wave instruction, an LDS gather a few.
+template <bool STAGE>
 __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -62,6 +66,7 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
     float *edge = reinterpret_cast<float *>(perm + nq);             // edge[j] = D[perm[j]][perm[j+1]], j < n-1
     uint32_t *keys = reinterpret_cast<uint32_t *>(edge + nq);       // 4 slots
     float *hv = reinterpret_cast<float *>(keys + 4);                // per wave: D[a][c], D[b][e] of its first improving lane
+    float *rowbuf = hv + 2 * (kDmNT / 64);                          // STAGE: per wave two matrix rows of nq floats
     const float *__restrict__ dm = A.dm_full;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t d = blockIdx.x;
@@ -85,6 +90,7 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     constexpr uint32_t NWv = kDmNT / 64;
     uint32_t since_rows = 0;  // rows scanned since the last move
+    uint32_t gap_rows = 0;    // ... and its running average over the recent moves: the block shape follows the larger of the two
 
     while (n >= 4) {
         const uint32_t slot = step % 3u;
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
         //  dense — moves every few rows: one row per step, its columns dealt to the 16 waves.
         // Either way the lexicographically first improving (i, j) wins (ds_min_u32 on i << 16 | j) and the scan
         // resumes at (i, j+1) like the reference.
-        const bool wide = since_rows >= 4u;
+        const bool wide = (since_rows > gap_rows ? since_rows : gap_rows) >= 4u;
         const uint32_t R = wide ? NWv : 1u;
         const uint32_t jbase = j0 - (j0 & 63u);
         if (wide) {
@@ -105,6 +111,26 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
                 const float dab = edge[i];
                 const float *__restrict__ rowa = dm + (size_t)a * n;
                 const float *__restrict__ rowb = dm + (size_t)b * n;
+                float *la = rowbuf + (size_t)(2u * wave) * nq, *lb = la + nq;
+                if (STAGE) {
+                    for (uint32_t c0 = lane; c0 < n; c0 += 256u) {  // four coalesced loads of each row in flight
+                        float va[4], vb[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t c = c0 + 64u * (uint32_t)u;
+                            va[u] = c < n ? rowa[c] : 0.0f;
+                            vb[u] = c < n ? rowb[c] : 0.0f;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t c = c0 + 64u * (uint32_t)u;
+                            if (c < n) {
+                                la[c] = va[u];
+                                lb[c] = vb[u];
+                            }
+                        }
+                    }
+                }
                 const uint32_t jmin = wave == 0u ? j0 : i + 2u;
                 bool done = false;
                 for (uint32_t jb = jmin - (jmin & 63u); jb <= n - 2u && !done; jb += 64u * kDmTiles) {
@@ -116,8 +142,8 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
                         const uint32_t j = jb + 64u * (uint32_t)u + lane;
                         const uint32_t jj = j <= n - 2u ? j : n - 2u;  // lanes beyond the row read a valid column and are masked below
                         const uint32_t c = perm[jj], e = perm[jj + 1u];
-                        dac[u] = rowa[c];
-                        dbe[u] = rowb[e];
+                        dac[u] = STAGE ? la[c] : rowa[c];
+                        dbe[u] = STAGE ? lb[e] : rowb[e];
                         dce[u] = edge[jj];
                     }
 #pragma unroll
@@ -174,8 +200,9 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
             j0 = i0 + 2u;
             since_rows += R;
         } else {
-            since_rows = 0;
             const uint32_t is = key >> 16, js = key & 0xFFFFu;
+            gap_rows = (gap_rows + since_rows + (is - i0) + 1u) >> 1;  // running estimate of the rows between moves
+            since_rows = 0;
             const uint32_t lo = is + 1u, hi = js;  // swap_2opt(path, i+1, j), two_opt.rs:69-79
             // the wave that posted the winning key: its row in a wide block, its tile of the row in a dense one
             const uint32_t ww = wide ? is - i0 : ((js - jbase) >> 6) & (NWv - 1u);
@@ -243,6 +270,7 @@ size_t two_opt_ref_dm_lds_bytes(uint32_t n)
 {
     return (size_t)((n + 1u + 3u) & ~3u) * 8 + 16 + (size_t)(kDmNT / 64) * 8;
 }
+static size_t two_opt_ref_dm_stage_bytes(uint32_t n) { return (size_t)((n + 1u + 3u) & ~3u) * 4 * 2 * (kDmNT / 64); }
 
 hipError_t launch_dm_expand_full(const float *packed, uint32_t n, float *full, hipStream_t s)
 {
@@ -251,13 +279,15 @@ hipError_t launch_dm_expand_full(const float *packed, uint32_t n, float *full, h
     return hipGetLastError();
 }
 
-hipError_t launch_two_opt_ref_dm(const TwoOptBatchArgs &A, uint32_t count, hipStream_t s)
+hipError_t launch_two_opt_ref_dm(const TwoOptBatchArgs &A, uint32_t count, int lds_budget, hipStream_t s)
 {
-    const size_t lds = two_opt_ref_dm_lds_bytes(A.n);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_two_opt_ref_dm),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t base = two_opt_ref_dm_lds_bytes(A.n), staged = base + two_opt_ref_dm_stage_bytes(A.n);
+    const bool stage = staged <= (size_t)lds_budget;
+    const size_t lds = stage ? staged : base;
+    auto kern = stage ? k_two_opt_ref_dm<true> : k_two_opt_ref_dm<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_two_opt_ref_dm, dim3(count), dim3(kDmNT), lds, s, A);
+    hipLaunchKernelGGL(kern, dim3(count), dim3(kDmNT), lds, s, A);
     return hipGetLastError();
 }
 
