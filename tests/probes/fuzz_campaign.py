@@ -13,6 +13,8 @@ with TA.Context(0) as ctx, TA.Context(0, TA.TL_FLAG_NO_PRUNE) as ctx2:
         seed += 1
         rng = np.random.default_rng(seed)
         n = int(rng.integers(4, 3200)) if seed % 4 else int(rng.integers(4, 200))
+        if os.environ.get("FUZZ_BIG"):  # long rows: deferred reversals over many register slots, all tile groups
+            n = int(rng.integers(3200, 14500))
         kind = seed % 6
         if kind == 0: xy = rng.random((n, 2)) * 1000
         elif kind == 1: xy = rng.integers(0, int(rng.integers(2, 40)), (n, 2))
