@@ -402,19 +402,6 @@ __device__ __forceinline__ uint32_t arc_start_from_end(const Arcs &A, uint32_t p
     if (best == 0xFFFFFFFFu) best = A.lo[A.k - 1];
     return best + 1u == n ? 0u : best + 1u;
 }
-__device__ __forceinline__ uint32_t chain_partner(const uint32_t (&chain)[kLkMaxChain], uint32_t clen, uint32_t city)
-{
-    // the city joined to `city` by an added edge
-    for (uint32_t t = 0; t < clen; ++t) {
-        if (chain[t] == city) {
-            if (t == 0u) return chain[clen - 1u];
-            if (t == clen - 1u) return chain[0];
-            return (t & 1u) ? chain[t + 1u] : chain[t - 1u];
-        }
-    }
-    return 0xFFFFFFFFu;
-}
-
 // chain_is_valid_tour (lin_kernighan.rs:181-250): one Hamiltonian cycle <=> the arc walk sees all k arcs
 __device__ bool chain_valid(const uint32_t (&chain)[kLkMaxChain], uint32_t clen, const uint32_t *tour, const uint32_t *pos, uint32_t n)
 {

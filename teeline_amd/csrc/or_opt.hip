@@ -112,32 +112,35 @@ __global__ __launch_bounds__(kOrWaves * 64) void k_or_scan(OrOptArgs A, uint32_t
                 const uint32_t i = i0 + (uint32_t)r;
                 if (i >= n) break;
                 const uint32_t prev = i == 0u ? n - 1u : i - 1u;
+                // the five placements of (i, j); an invalid one (row or column excluded, :90-92, :98-100, :123-125) reads +inf.
+                // Only when the smallest of them can still beat this lane's best are the 64-bit keys looked at.
+                float val[5];
+                const bool okj = real & (j != prev);
+                const float inf = __builtin_inff();
 #pragma unroll
                 for (int len = 1; len <= 3; ++len) {
                     const int rl = (len - 1) * kOrIR + r;
-                    if (!((rowmask >> rl) & 1ull)) continue;  // wave-uniform
-                    const bool ok = real & (j != prev) & !((j - i) < (uint32_t)len);  // :123-125
+                    const bool ok = okj & !((j - i) < (uint32_t)len) & (bool)((rowmask >> rl) & 1ull);
                     const float nr = readlane_f(nrg, rl);
-                    const unsigned long long order = ((unsigned long long)((uint32_t)(len - 1) * n + i) * n + j) * 2ull;
-                    {
-                        const float fwd = nr + dX[r] + dY[r + len - 1] - e;  // :136-139  -rg + d(x,first) + d(last,y) - d(x,y)
-                        const bool cnd = ok & (fwd < -1e-3f) & (fwd <= bestd);
-                        if (__builtin_amdgcn_ballot_w64(cnd)) {
-                            const unsigned long long key = ((unsigned long long)(~__builtin_bit_cast(uint32_t, fwd)) << 32) | order;
-                            if (cnd && key < best) {
-                                best = key;
-                                bestd = fwd;
-                            }
-                        }
-                    }
+                    const float fwd = nr + dX[r] + dY[r + len - 1] - e;  // :136-139  -rg + d(x,first) + d(last,y) - d(x,y)
+                    val[len == 1 ? 0 : 2 * len - 3] = ok ? fwd : inf;
                     if (len > 1) {
                         const float rev = nr + dX[r + len - 1] + dY[r] - e;  // :148-151  -rg + d(x,last) + d(first,y) - d(x,y)
-                        const bool cnd = ok & (rev < -1e-3f) & (rev <= bestd);
-                        if (__builtin_amdgcn_ballot_w64(cnd)) {
-                            const unsigned long long key = ((unsigned long long)(~__builtin_bit_cast(uint32_t, rev)) << 32) | (order + 1ull);
-                            if (cnd && key < best) {
+                        val[2 * len - 2] = ok ? rev : inf;
+                    }
+                }
+                const float vmin = fminf(fminf(fminf(val[0], val[1]), fminf(val[2], val[3])), val[4]);  // NaN deltas drop out like in `<`
+                if (__builtin_amdgcn_ballot_w64((vmin < -1e-3f) & (vmin <= bestd))) {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) {  // loop order within (i, j): len 1 fwd; len 2 fwd, rev; len 3 fwd, rev — the order index decides ties
+                        const int len = q == 0 ? 1 : (q + 3) / 2;
+                        const unsigned long long order = ((unsigned long long)((uint32_t)(len - 1) * n + i) * n + j) * 2ull + (unsigned long long)(q != 0 && (q & 1) == 0);
+                        const float v = val[q];
+                        if ((v < -1e-3f) & (v <= bestd)) {
+                            const unsigned long long key = ((unsigned long long)(~__builtin_bit_cast(uint32_t, v)) << 32) | order;
+                            if (key < best) {
                                 best = key;
-                                bestd = rev;
+                                bestd = v;
                             }
                         }
                     }
