@@ -93,3 +93,7 @@ def test_key_packing_matches_c_abi_definition():
     for i, c in enumerate(costs.tolist()):
         assert lib.tl_pack_cost_key(c, 10 + i) == int(keys[i])
     assert ms.shard(3, 256) == (768, 256)
+    # one process, no process group: the "shared" tour is the local winner's
+    tours = torch.arange(4 * 6, dtype=torch.int32).reshape(4, 6)
+    best = ms.allreduce_best(keys, None)
+    assert int(best) == int(keys[1]) and ms.share_best_tour(keys, tours, best, None).tolist() == tours[1].tolist()
