@@ -803,13 +803,36 @@ __device__ __forceinline__ bool lk_run_sub(const LkArgs &G, uint32_t (&chain)[kL
     return lk_subsearch<uint32_t>(V, chain, clen, p1, t1, t2, p2, g0, sub / k1, sub % k1);
 }
 
-__global__ __launch_bounds__(256) void k_lk_scan_sub(LkArgs G)
+// BLOCK3D: one workgroup = one pair, threadIdx = (s2, s1, q1) — the sub-search digits come for free; the flat form (for
+// k(k+1)^2 > 1024) recovers them with a 64-bit and three 32-bit divisions per lane, which is most of what a lane that fails
+// its first test executes.
+template <bool BLOCK3D>
+__global__ __launch_bounds__(1024) void k_lk_scan_sub(LkArgs G)
 {
     if (G.state->finished) return;
     const uint32_t n = G.n, subs = lk_subs(G);
-    const uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (g >= (uint64_t)2u * n * subs) return;
-    const uint32_t idx = (uint32_t)(g / subs), sub = (uint32_t)(g % subs);
+    uint32_t idx, sub, q1, s1, s2;
+    uint64_t g;
+    if (BLOCK3D) {
+        idx = blockIdx.x;
+        const uint32_t k1 = G.k + 1u;
+        if (G.split_levels == 3u) {
+            q1 = threadIdx.z; s1 = threadIdx.y; s2 = threadIdx.x;
+            sub = (q1 * k1 + s1) * k1 + s2;
+        } else {
+            q1 = threadIdx.y; s1 = threadIdx.x; s2 = 0u;
+            sub = q1 * k1 + s1;
+        }
+        g = (uint64_t)idx * subs + sub;
+    } else {
+        g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (g >= (uint64_t)2u * n * subs) return;
+        idx = (uint32_t)(g / subs);
+        sub = (uint32_t)(g % subs);
+        const uint32_t k1 = G.k + 1u;
+        if (G.split_levels == 3u) { q1 = sub / (k1 * k1); s1 = (sub / k1) % k1; s2 = sub % k1; }
+        else { q1 = sub / k1; s1 = sub % k1; s2 = 0u; }
+    }
     if (idx >= G.state->window) return;  // prefix window (k_lk_control)
     const uint32_t t1 = G.city_ids[idx >> 1];
     const uint32_t t2 = (idx & 1u) ? G.prev[t1] : G.next[t1];
@@ -819,7 +842,10 @@ __global__ __launch_bounds__(256) void k_lk_scan_sub(LkArgs G)
     chain[0] = t1;
     chain[1] = t2;
     const float g0 = t1 == t2 ? 0.0f : dist(p1, p2);
-    if (lk_run_sub(G, chain, clen, p1, t1, t2, p2, g0, sub)) {
+    LkView V{G.xy, G.cand, G.next, G.k, G.max_depth};
+    const bool got = G.split_levels == 3u ? lk_subsearch3<uint32_t>(V, chain, clen, p1, t2, p2, g0, q1, s1, s2)
+                                          : lk_subsearch<uint32_t>(V, chain, clen, p1, t1, t2, p2, g0, q1, s1);
+    if (got) {
         if (G.subchains) {  // keep the chain: the pick step reads the winner's instead of walking it again
             uint32_t *slot = G.subchains + g * kLkSubSlot;
             slot[0] = clen;
@@ -1104,7 +1130,13 @@ hipError_t launch_lk_round(const LkArgs &G, hipStream_t s)
 {
     if (G.pairmin) {  // split scan
         const uint64_t lanes = (uint64_t)2u * G.n * G.k * (G.k + 1u) * (G.split_levels == 3u ? G.k + 1u : 1u);
-        hipLaunchKernelGGL(k_lk_scan_sub, dim3((uint32_t)((lanes + 255u) / 256u)), dim3(256), 0, s, G);
+        const uint32_t k1 = G.k + 1u, per_pair = lk_subs(G);
+        if (per_pair <= 1024u) {  // one workgroup per pair, thread coordinates = sub-search digits
+            const dim3 blk = G.split_levels == 3u ? dim3(k1, k1, G.k) : dim3(k1, G.k, 1);
+            hipLaunchKernelGGL(k_lk_scan_sub<true>, dim3(2u * G.n), blk, 0, s, G);
+        } else {
+            hipLaunchKernelGGL(k_lk_scan_sub<false>, dim3((uint32_t)((lanes + 255u) / 256u)), dim3(256), 0, s, G);
+        }
         hipLaunchKernelGGL(k_lk_scan_pick, dim3((2u * G.n + 255u) / 256u), dim3(256), 0, s, G);
     } else {
         const size_t lds = (size_t)G.n * 10;

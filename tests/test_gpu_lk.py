@@ -119,6 +119,14 @@ def test_lk_other_instances(ctx, case, tsplib_dir):
                         O.lin_kernighan(xy, seed=1, epochs=20, max_depth=depth, n_nearest=k))
 
 
+def test_lk_wide_candidate_lists(ctx):
+    # k(k+1)^2 > 1024 sub-searches per pair: the flat (divided) lane index instead of one workgroup per pair
+    xy = O.synth_xy(300, seed=12)
+    for k, depth in ((10, 5), (12, 3), (16, 4)):
+        assert_same(gpu_lk(ctx, xy, seed=3, epochs=6, n_nearest=k, max_depth=depth),
+                    O.lin_kernighan(xy, seed=3, epochs=6, n_nearest=k, max_depth=depth))
+
+
 def test_lk_variants_are_identical(ctx, tsplib_dir, monkeypatch):
     # default = scans spread over all CUs, each pair's chain search split into k*(k+1)^2 sub-searches (TL_LK_SPLIT2: k*(k+1)), device-side control
     # state machine, kept sub-search chains.  The unsplit scan, the single persistent workgroup and the pick step that walks the
