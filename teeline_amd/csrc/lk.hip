@@ -24,6 +24,7 @@
 // tour is those arcs copied in walk order starting at tour[0] — forward if the edge (tour[0],tour[1]) survives,
 // else backward, which is what the reference's trace from `adj[start][0]` does.
 #include "tl_kernels.h"
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -120,9 +121,9 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)  // the minimum ove
 // (2kn bytes, when n < 65536 and they fit) and, if there is room left, the coordinates for the fallback scans
 // (8n bytes).  Wave 0 walks (lane t checks the t-th nearest); the fallback scan is the whole workgroup in two u32 passes (smallest
 // squared distance, then the lowest position at the rounded minimum), DPP wave reductions, one LDS atomicMin per wave.
-constexpr int kNnRegs = 16;  // cities per thread whose coordinates stay in registers for the fallback scans (n <= 16 384)
+// NQ: cities per thread whose coordinates stay in registers for the fallback scans (n <= NQ * 1024; 0 = none, loop form)
 
-template <bool LDS_CAND, bool LDS_XY>
+template <bool LDS_CAND, bool LDS_XY, int NQ>
 __global__ __launch_bounds__(kLkNT) void k_nn_seed(const float2 *__restrict__ xy, uint32_t n, const uint32_t *__restrict__ cand,
                                                    uint32_t k, uint32_t *__restrict__ path)
 {
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(kLkNT) void k_nn_seed(const float2 *__restrict__ xy
         for (size_t e = tid; e < (size_t)n * k; e += kLkNT) lc[e] = (uint16_t)cand[e];    // 0xFFFFFFFF (no neighbour) -> 0xFFFF
     if (LDS_XY)
         for (uint32_t p = tid; p < n; p += kLkNT) lxy[p] = xy[p];
-    const bool regs = n <= (uint32_t)kNnRegs * kLkNT;
+    constexpr int kNnRegs = NQ > 0 ? NQ : 1;
+    const bool regs = NQ > 0;
     float2 rxy[kNnRegs];
 #pragma unroll
     for (int m = 0; m < kNnRegs; ++m) {
@@ -1181,10 +1183,19 @@ hipError_t launch_nn_seed(const float2 *xy, uint32_t n, const uint32_t *cand, ui
         hipLaunchKernelGGL(kern, dim3(1), dim3(kLkNT), lds, s, xy, n, cand, k, path);
         return hipGetLastError();
     };
-    if (lds_cand && lds_xy) return go(k_nn_seed<true, true>);
-    if (lds_cand) return go(k_nn_seed<true, false>);
-    if (lds_xy) return go(k_nn_seed<false, true>);
-    return go(k_nn_seed<false, false>);
+    auto pick = [&](auto cand_t, auto xy_t) -> hipError_t {
+        constexpr bool LC = decltype(cand_t)::value, LX = decltype(xy_t)::value;
+        const uint32_t per = (n + (uint32_t)kLkNT - 1u) / (uint32_t)kLkNT;  // cities per thread
+        if (per <= 4u) return go(k_nn_seed<LC, LX, 4>);
+        if (per <= 8u) return go(k_nn_seed<LC, LX, 8>);
+        if (per <= 12u) return go(k_nn_seed<LC, LX, 12>);
+        if (per <= 16u) return go(k_nn_seed<LC, LX, 16>);
+        return go(k_nn_seed<LC, LX, 0>);
+    };
+    if (lds_cand && lds_xy) return pick(std::true_type{}, std::true_type{});
+    if (lds_cand) return pick(std::true_type{}, std::false_type{});
+    if (lds_xy) return pick(std::false_type{}, std::true_type{});
+    return pick(std::false_type{}, std::false_type{});
 }
 
 hipError_t launch_lk_solve(const LkArgs &G, hipStream_t s)
