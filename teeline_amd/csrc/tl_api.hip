@@ -949,6 +949,21 @@ static int nn_seed_dev(tl_ctx *c, const float2 *d_xy, uint32_t n, uint32_t n_nea
     int rc;
     if ((size_t)n + 1024 > (size_t)c->lds_bytes)
         return fail(c, TL_ERR_UNSUPPORTED, "nearest_neighbor: n=%u exceeds the LDS-resident visited flags (%d bytes of LDS)", n, c->lds_bytes);
+    // The walk takes "the first unvisited among the n_nearest closest, else the globally nearest unvisited" — both in the
+    // same (distance, position) order, so the tour does not depend on how long the lists are: any length gives "the first
+    // unvisited city in (distance, position) order", and a longer list only turns workgroup-wide fallback scans into
+    // list steps.  The list length used on the device is therefore what fits the LDS best (lists as u16 next to the
+    // visited flags; the fallback scans hold their coordinates in registers up to n = 16 384).
+    if (n <= 16384u && n - 1u >= 1u) {
+        uint32_t kint = k;
+        const size_t cap = (size_t)c->lds_bytes - 1024;
+        // measured: 7 at n = 10^4 (6.5 -> 5.6 ms), 5 at n = 13 509 (9.3 -> 7.8 ms: what fits), 4 below ~8 K (the k <= 4 list
+        // builder is the cheaper one and few steps fall back there)
+        for (uint32_t kk = n < 8192u ? 4u : 7u; kk > k; --kk)
+            if (kk <= n - 1u && (size_t)n + 16 + (size_t)n * kk * 2u + 16 <= cap) { kint = kk; break; }
+        if (const char *e = getenv("TL_NN_KINT")) kint = (uint32_t)atoi(e) > n - 1u ? n - 1u : (uint32_t)atoi(e);
+        k = kint;
+    }
     const size_t cand_b = ((size_t)n * (k ? k : 1) * 4 + 255) & ~(size_t)255;
     if ((rc = ensure(c, c->misc, cand_b))) return rc;
     uint32_t *d_cand = (uint32_t *)c->misc.p;
