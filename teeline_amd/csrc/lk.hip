@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_knn(const float2 *__restrict__ xy, uint
     uint32_t bp[KMAX];
 #pragma unroll
     for (int t = 0; t < KMAX; ++t) { bd[t] = __builtin_inff(); bp[t] = 0xFFFFFFFFu; }
-    float radius = __builtin_inff();
+    float radius = __builtin_inff(), rlim = __builtin_inff();
     for (uint32_t base = 0; base < n; base += 256u) {
         __syncthreads();
         if (base + threadIdx.x < n) tile[threadIdx.x] = xy[base + threadIdx.x];
@@ -60,8 +60,12 @@ __global__ __launch_bounds__(256) void k_knn(const float2 *__restrict__ xy, uint
         const uint32_t lim = (n - base) < 256u ? (n - base) : 256u;
         for (uint32_t t = 0; t < lim; ++t) {
             const uint32_t p = base + t;
+            // sqrt is monotone: a squared distance above (radius (1 + 2^-20))^2 cannot give d < radius.  Almost every candidate
+            // fails that for all 64 cities of the wave, and the correctly rounded root is only taken for the rest.
+            const float sq = sqdist(tile[t], pc);
+            if (!__builtin_amdgcn_ballot_w64((sq <= rlim) & (p != c))) continue;
             if (p == c) continue;                    // self excluded (mod.rs:1840-1842)
-            const float d = dist(tile[t], pc);       // kdtree.rs:194 self.point.distance(target)
+            const float d = sqrt_rn(sq);             // kdtree.rs:194 self.point.distance(target)
             // insert iff d < search_radius (INF until the buffer holds k, then the k-th kept distance), at
             // partition_point(r.distance <= d): AFTER equal distances, then truncate to k
             if (d < radius) {
@@ -84,6 +88,7 @@ __global__ __launch_bounds__(256) void k_knn(const float2 *__restrict__ xy, uint
 #pragma unroll
                 for (int s = 0; s < KMAX; ++s)
                     if ((uint32_t)s + 1u == k) radius = bd[s];
+                rlim = radius * radius * 1.000002f;  // inf while the buffer is not full (and on overflow: no filtering)
             }
         }
     }
