@@ -118,6 +118,92 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)  // the minimum ove
     return ab < cd ? ab : cd;
 }
 
+// Four lanes per city (a DPP quad): lane q takes the candidates p = q, q+4, ... of every tile with its own k-buffer (the
+// same insertion rule; positions ascend inside a lane, so ties stay stable), then the four sorted buffers are merged by k
+// rounds of "smallest head of the quad" on the packed key (d bits << 32 | position) — the k smallest in (distance,
+// position) order, exactly what one lane scanning everything keeps.  Four times the lanes of k_knn: at n ~ 10^4 one lane
+// per city leaves most of the chip idle.
+__device__ __forceinline__ unsigned long long quad_min_u64(unsigned long long v)
+{
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    {
+        const uint32_t olo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);
+        const uint32_t ohi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xf, 0xf, false);
+        const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+        v = o < v ? o : v;
+    }
+    {
+        const uint32_t lo2 = (uint32_t)v, hi2 = (uint32_t)(v >> 32);
+        const uint32_t olo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo2, 0x4E /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false);
+        const uint32_t ohi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi2, 0x4E, 0xf, 0xf, false);
+        const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void k_knn_quad(const float2 *__restrict__ xy, uint32_t n, uint32_t k, uint32_t *__restrict__ cand)
+{
+    __shared__ float2 tile[256];
+    const uint32_t c = blockIdx.x * 64u + (threadIdx.x >> 2), q = threadIdx.x & 3u;
+    const float2 pc = xy[c < n ? c : 0u];
+    float bd[KMAX];
+    uint32_t bp[KMAX];
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t) { bd[t] = __builtin_inff(); bp[t] = 0xFFFFFFFFu; }
+    float radius = __builtin_inff(), rlim = __builtin_inff();
+    for (uint32_t base = 0; base < n; base += 256u) {
+        __syncthreads();
+        if (base + threadIdx.x < n) tile[threadIdx.x] = xy[base + threadIdx.x];
+        __syncthreads();
+        const uint32_t lim = (n - base) < 256u ? (n - base) : 256u;
+        for (uint32_t t = q; t < ((lim + 3u) & ~3u); t += 4u) {  // the quad walks together (wave-uniform trip count)
+            const uint32_t p = base + t;
+            const bool in = t < lim && p != c;
+            const float sq = sqdist(tile[t < lim ? t : 0u], pc);
+            if (!__builtin_amdgcn_ballot_w64((sq <= rlim) & in)) continue;
+            const float d = sqrt_rn(sq);
+            if (in && d < radius) {
+                float cd = d;
+                uint32_t cp = p;
+                bool shifting = false;
+#pragma unroll
+                for (int s = 0; s < KMAX; ++s) {
+                    if ((uint32_t)s < k && (shifting || cd < bd[s])) {
+                        const float td = bd[s];
+                        const uint32_t tp = bp[s];
+                        bd[s] = cd;
+                        bp[s] = cp;
+                        cd = td;
+                        cp = tp;
+                        shifting = true;
+                    }
+                }
+                radius = __builtin_inff();
+#pragma unroll
+                for (int s = 0; s < KMAX; ++s)
+                    if ((uint32_t)s + 1u == k) radius = bd[s];
+                rlim = radius * radius * 1.000002f;
+            }
+        }
+    }
+    // merge the quad's four sorted buffers
+    uint32_t head = 0;
+    for (uint32_t r = 0; r < k; ++r) {
+        float hd = __builtin_inff();
+        uint32_t hp = 0xFFFFFFFFu;
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) {
+            if ((uint32_t)s == head) { hd = bd[s]; hp = bp[s]; }
+        }
+        const unsigned long long key = (head < k && hp != 0xFFFFFFFFu) ? (((unsigned long long)__builtin_bit_cast(uint32_t, hd) << 32) | hp) : ~0ULL;
+        const unsigned long long best = quad_min_u64(key);
+        if (key == best && best != ~0ULL) ++head;
+        if (q == 0u && c < n) cand[(size_t)c * k + r] = best == ~0ULL ? 0xFFFFFFFFu : (uint32_t)best;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- NN seed
 // nearest_neighbor::solve (nearest_neighbor.rs:8-76) is one sequential walk: n steps, each "first unvisited among the
 // n_nearest closest" (:44-49) or, failing that, the globally nearest unvisited city (:50-63; ties -> lowest position, the
@@ -1164,6 +1250,13 @@ size_t lk_chain_slot_words() { return (size_t)kLkMaxChain + 2; }
 
 hipError_t launch_knn(const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, hipStream_t s)
 {
+    if (!getenv("TL_KNN_NO_QUAD")) {  // four lanes per city
+        const uint32_t gq = (n + 63u) / 64u;
+        if (k <= 4) hipLaunchKernelGGL(k_knn_quad<4>, dim3(gq), dim3(256), 0, s, xy, n, k, cand);
+        else if (k <= 8) hipLaunchKernelGGL(k_knn_quad<8>, dim3(gq), dim3(256), 0, s, xy, n, k, cand);
+        else hipLaunchKernelGGL(k_knn_quad<16>, dim3(gq), dim3(256), 0, s, xy, n, k, cand);
+        return hipGetLastError();
+    }
     const uint32_t grid = (n + 255u) / 256u;
     if (k <= 4) hipLaunchKernelGGL(k_knn<4>, dim3(grid), dim3(256), 0, s, xy, n, k, cand);
     else if (k <= 8) hipLaunchKernelGGL(k_knn<8>, dim3(grid), dim3(256), 0, s, xy, n, k, cand);
