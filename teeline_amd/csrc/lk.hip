@@ -118,7 +118,7 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)  // the minimum ove
     return ab < cd ? ab : cd;
 }
 
-// Four lanes per city (a DPP quad): lane q takes the candidates p = q, q+4, ... of every tile with its own k-buffer (the
+// Several lanes per city (a DPP quad or a row of 16): lane q takes the candidates p = q, q+G, ... of every tile with its own k-buffer (the
 // same insertion rule; positions ascend inside a lane, so ties stay stable), then the four sorted buffers are merged by k
 // rounds of "smallest head of the quad" on the packed key (d bits << 32 | position) — the k smallest in (distance,
 // position) order, exactly what one lane scanning everything keeps.  Four times the lanes of k_knn: at n ~ 10^4 one lane
@@ -142,11 +142,32 @@ __device__ __forceinline__ unsigned long long quad_min_u64(unsigned long long v)
     return v;
 }
 
-template <int KMAX>
+// the same over a row of 16 lanes: butterfly of row rotations, every lane ends with the minimum
+template <int CTRL>
+__device__ __forceinline__ unsigned long long row_min_step_u64(unsigned long long v)
+{
+    const uint32_t olo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xf, 0xf, false);
+    const uint32_t ohi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, false);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    return o < v ? o : v;
+}
+__device__ __forceinline__ unsigned long long row16_min_u64(unsigned long long v)
+{
+    v = row_min_step_u64<0x128>(v);  // row_ror:8
+    v = row_min_step_u64<0x124>(v);  // row_ror:4
+    v = row_min_step_u64<0x122>(v);  // row_ror:2
+    v = row_min_step_u64<0x121>(v);  // row_ror:1
+    return v;
+}
+
+// GROUP lanes per city (4 = a DPP quad, 16 = a DPP row)
+template <int KMAX, int GROUP>
 __global__ __launch_bounds__(256) void k_knn_quad(const float2 *__restrict__ xy, uint32_t n, uint32_t k, uint32_t *__restrict__ cand)
 {
     __shared__ float2 tile[256];
-    const uint32_t c = blockIdx.x * 64u + (threadIdx.x >> 2), q = threadIdx.x & 3u;
+    static_assert(GROUP == 4 || GROUP == 16, "lanes per city");
+    constexpr uint32_t G = GROUP, CPB = 256u / G;  // cities per block
+    const uint32_t c = blockIdx.x * CPB + (threadIdx.x / G), q = threadIdx.x % G;
     const float2 pc = xy[c < n ? c : 0u];
     float bd[KMAX];
     uint32_t bp[KMAX];
@@ -158,7 +179,7 @@ __global__ __launch_bounds__(256) void k_knn_quad(const float2 *__restrict__ xy,
         if (base + threadIdx.x < n) tile[threadIdx.x] = xy[base + threadIdx.x];
         __syncthreads();
         const uint32_t lim = (n - base) < 256u ? (n - base) : 256u;
-        for (uint32_t t = q; t < ((lim + 3u) & ~3u); t += 4u) {  // the quad walks together (wave-uniform trip count)
+        for (uint32_t t = q; t < ((lim + G - 1u) & ~(G - 1u)); t += G) {  // the group walks together (wave-uniform trip count)
             const uint32_t p = base + t;
             const bool in = t < lim && p != c;
             const float sq = sqdist(tile[t < lim ? t : 0u], pc);
@@ -198,7 +219,7 @@ __global__ __launch_bounds__(256) void k_knn_quad(const float2 *__restrict__ xy,
             if ((uint32_t)s == head) { hd = bd[s]; hp = bp[s]; }
         }
         const unsigned long long key = (head < k && hp != 0xFFFFFFFFu) ? (((unsigned long long)__builtin_bit_cast(uint32_t, hd) << 32) | hp) : ~0ULL;
-        const unsigned long long best = quad_min_u64(key);
+        const unsigned long long best = GROUP == 4 ? quad_min_u64(key) : row16_min_u64(key);
         if (key == best && best != ~0ULL) ++head;
         if (q == 0u && c < n) cand[(size_t)c * k + r] = best == ~0ULL ? 0xFFFFFFFFu : (uint32_t)best;
     }
@@ -1250,11 +1271,18 @@ size_t lk_chain_slot_words() { return (size_t)kLkMaxChain + 2; }
 
 hipError_t launch_knn(const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, hipStream_t s)
 {
-    if (!getenv("TL_KNN_NO_QUAD")) {  // four lanes per city
+    if (!getenv("TL_KNN_NO_QUAD")) {  // several lanes per city: 16 while that still fills the chip (n <= 32 K), else 4
+        if (n <= 32768u && !getenv("TL_KNN_GROUP4")) {
+            const uint32_t gq = (n + 15u) / 16u;
+            if (k <= 4) hipLaunchKernelGGL((k_knn_quad<4, 16>), dim3(gq), dim3(256), 0, s, xy, n, k, cand);
+            else if (k <= 8) hipLaunchKernelGGL((k_knn_quad<8, 16>), dim3(gq), dim3(256), 0, s, xy, n, k, cand);
+            else hipLaunchKernelGGL((k_knn_quad<16, 16>), dim3(gq), dim3(256), 0, s, xy, n, k, cand);
+            return hipGetLastError();
+        }
         const uint32_t gq = (n + 63u) / 64u;
-        if (k <= 4) hipLaunchKernelGGL(k_knn_quad<4>, dim3(gq), dim3(256), 0, s, xy, n, k, cand);
-        else if (k <= 8) hipLaunchKernelGGL(k_knn_quad<8>, dim3(gq), dim3(256), 0, s, xy, n, k, cand);
-        else hipLaunchKernelGGL(k_knn_quad<16>, dim3(gq), dim3(256), 0, s, xy, n, k, cand);
+        if (k <= 4) hipLaunchKernelGGL((k_knn_quad<4, 4>), dim3(gq), dim3(256), 0, s, xy, n, k, cand);
+        else if (k <= 8) hipLaunchKernelGGL((k_knn_quad<8, 4>), dim3(gq), dim3(256), 0, s, xy, n, k, cand);
+        else hipLaunchKernelGGL((k_knn_quad<16, 4>), dim3(gq), dim3(256), 0, s, xy, n, k, cand);
         return hipGetLastError();
     }
     const uint32_t grid = (n + 255u) / 256u;
