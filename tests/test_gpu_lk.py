@@ -37,6 +37,19 @@ def test_candidate_lists(ctx, k, tsplib_dir):
         assert got.shape == want.shape and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("env", ["TL_KNN_GROUP4", "TL_KNN_NO_QUAD"])
+def test_candidate_list_builders_agree(ctx, env, monkeypatch):
+    # default: sixteen lanes per city; TL_KNN_GROUP4: the four-lane form used beyond n = 32 K; TL_KNN_NO_QUAD: one lane per
+    # city — all must give the oracle's lists (ascending f32 distance, ties -> lowest position), duplicates included
+    import teeline_amd as TA
+    monkeypatch.setenv(env, "1")
+    dup = np.concatenate([lattice(7, 3), lattice(7, 3)[:20]]).astype(np.float32)
+    for xy in (O.synth_xy(777, seed=8), dup, O.synth_xy(5, seed=1)):
+        for k in (1, 4, 7, 16):
+            got = TA.lin_kernighan.build_candidates(prob(xy), k, ctx=ctx)
+            assert np.array_equal(got, O.build_candidates(xy, k))
+
+
 def test_nearest_neighbor_seed(ctx, tsplib_dir):
     import teeline_amd as TA
     want = {"berlin52": "8980.91797", "att532": "112099.42188", "a280": "3148.10962"}  # bench/baseline-solvers.tsv:2-16
