@@ -132,6 +132,30 @@ int tlo_lin_kernighan(const float *xy, uint32_t n, const uint32_t *init, uint32_
                       uint32_t platoo_epochs, uint32_t n_nearest, uint32_t max_depth,
                       uint64_t seed, uint32_t *out_perm, float *out_cost, tlo_stats *stats);
 
+/* the same with precomputed candidate lists (n x min(n_nearest, n-1) positions), e.g. tlo_build_candidates_kdtree's */
+int tlo_lin_kernighan_cand(const float *xy, uint32_t n, const uint32_t *init, uint32_t epochs,
+                           uint32_t platoo_epochs, uint32_t n_nearest, uint32_t max_depth, uint64_t seed,
+                           const uint32_t *cand, uint32_t *out_perm, float *out_cost, tlo_stats *stats);
+/* lin_kernighan.rs:134-145 */
+void tlo_flat_to_next_prev(const uint32_t *tour, uint32_t n, uint32_t *next, uint32_t *prev);
+/* lin_kernighan.rs:345-389 on a flat tour (city_ids = the tour, as the reference's unit tests call it); out_chain needs
+ * 2 * max_depth + 4 entries; returns the chain length (0 = None). */
+int tlo_find_lk_move(const float *xy, uint32_t n, const uint32_t *tour, const uint32_t *cand, uint32_t k,
+                     uint32_t max_depth, uint32_t *out_chain);
+/* lin_kernighan.rs:397-450 */
+int tlo_apply_lk_chain(uint32_t *tour, uint32_t n, const uint32_t *chain, uint32_t clen);
+
+/* ---- kd-tree (kdtree.rs), tl_oracle_kdtree.c ---- */
+/* lin_kernighan.rs:12-27 through the reference's kd-tree (kdtree.rs:19-73 build, :193-212 nearest, mod.rs:1839-1889
+ * k-buffer).  *tie_free = 1 iff no median selection met elements comparing Equal (kdtree.rs:301-317) around the pivot,
+ * i.e. iff the tree is independent of Rust's select_nth_unstable_by implementation (kdtree.rs:63). */
+int tlo_build_candidates_kdtree(const float *xy, uint32_t n, uint32_t k, uint32_t *out, int *tie_free);
+/* KDTree::nearest (kdtree.rs:116-122): ids NULL = position; returns the result count (buffer order in out_*). */
+int tlo_kdtree_nearest(const float *xy, const uint64_t *ids, uint32_t n, float qx, float qy, uint64_t qid, uint32_t k,
+                       uint32_t *out_pos, float *out_dist);
+/* KDTree::walk (kdtree.rs:98-108): positions in in-order. */
+int tlo_kdtree_walk(const float *xy, uint32_t n, uint32_t *out_order, int *tie_free);
+
 #ifdef __cplusplus
 }
 #endif

@@ -206,7 +206,49 @@ static void apply_lk_chain(const uint32_t *chain, uint32_t clen, uint32_t *tour,
     }
 }
 
-/* lin_kernighan.rs:454-481 (lk_pass) with find_lk_move :345-389 inlined */
+/* lin_kernighan.rs:345-389 find_lk_move: first (t1 in city_ids order, next-then-prev) pair whose first profitable chain
+ * is a valid tour.  `used` must be all zero on entry and is all zero again on a miss.  Returns the chain length or 0. */
+static uint32_t find_lk_move(const float *xy, uint32_t n, const uint32_t *cand, uint32_t k, uint32_t max_depth,
+                             const uint32_t *next, const uint32_t *prev, const uint32_t *city_ids, unsigned char *used,
+                             uint32_t *chain, adjl *adj, uint32_t *prev_map, tlo_stats *st)
+{
+    lkctx c = {xy, n, cand, k, max_depth, next, prev, used, chain, 0, 0};
+    for (uint32_t ti = 0; ti < n; ++ti) { /* :357 */
+        uint32_t t1 = city_ids[ti];
+        uint32_t t2s[2] = {next[t1], prev[t1]};
+        for (int o = 0; o < 2; ++o) { /* :359 */
+            uint32_t t2 = t2s[o];
+            float g0 = dd(&c, t1, t2);
+            c.clen = 0;
+            chain[c.clen++] = t1;
+            chain[c.clen++] = t2;
+            used[t1] = 1;
+            used[t2] = 1;
+            int found = find_lk_chain(&c, t1, t2, g0, 0);
+            if (st) st->candidates += 1;
+            if (found) {
+                if (chain_is_valid_tour(chain, c.clen, next, city_ids, n, adj, prev_map)) return c.clen;
+                for (uint32_t q = 0; q < c.clen; ++q) used[chain[q]] = 0; /* :378-380 */
+            } else {
+                used[t1] = 0;
+                used[t2] = 0;
+            }
+        }
+    }
+    return 0;
+}
+
+/* lin_kernighan.rs:134-145 */
+void tlo_flat_to_next_prev(const uint32_t *tour, uint32_t n, uint32_t *next, uint32_t *prev)
+{
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t a = tour[i], b = tour[(i + 1) % n];
+        next[a] = b;
+        prev[b] = a;
+    }
+}
+
+/* lin_kernighan.rs:454-481 */
 int tlo_lk_pass(const float *xy, uint32_t n, uint32_t *tour, const uint32_t *cand, uint32_t k,
                 uint32_t max_depth, tlo_stats *st)
 {
@@ -224,50 +266,49 @@ int tlo_lk_pass(const float *xy, uint32_t n, uint32_t *tour, const uint32_t *can
     memcpy(city_ids, tour, (size_t)n * sizeof(uint32_t)); /* :466 fixed for the whole pass */
 
     for (;;) {
-        for (uint32_t i = 0; i < n; ++i) { /* :134-145 flat_to_next_prev */
-            uint32_t a = tour[i], b = tour[(i + 1) % n];
-            next[a] = b;
-            prev[b] = a;
-        }
-        lkctx c = {xy, n, cand, k, max_depth, next, prev, used, chain, 0, 0};
+        tlo_flat_to_next_prev(tour, n, next, prev); /* :470 */
         memset(used, 0, n);
-        int found_valid = 0;
-        for (uint32_t ti = 0; ti < n && !found_valid; ++ti) { /* :357 */
-            uint32_t t1 = city_ids[ti];
-            uint32_t t2s[2] = {next[t1], prev[t1]};
-            for (int o = 0; o < 2; ++o) { /* :359 */
-                uint32_t t2 = t2s[o];
-                float g0 = dd(&c, t1, t2);
-                c.clen = 0;
-                chain[c.clen++] = t1;
-                chain[c.clen++] = t2;
-                used[t1] = 1;
-                used[t2] = 1;
-                int found = find_lk_chain(&c, t1, t2, g0, 0);
-                if (st) st->candidates += 1;
-                if (found) {
-                    if (chain_is_valid_tour(chain, c.clen, next, city_ids, n, adj, prev_map)) {
-                        found_valid = 1;
-                        break;
-                    }
-                    for (uint32_t q = 0; q < c.clen; ++q) used[chain[q]] = 0; /* :378-380 */
-                } else {
-                    used[t1] = 0;
-                    used[t2] = 0;
-                }
-            }
-            if (found_valid) {
-                apply_lk_chain(chain, c.clen, tour, n, adj);
-                improved = 1;
-                if (st) { st->moves += 1; st->reversed += c.clen / 2; }
-            }
-        }
+        const uint32_t clen = find_lk_move(xy, n, cand, k, max_depth, next, prev, city_ids, used, chain, adj, prev_map, st);
         if (st) st->sweeps += 1;
-        if (!found_valid) break;
+        if (!clen) break;
+        apply_lk_chain(chain, clen, tour, n, adj);
+        improved = 1;
+        if (st) { st->moves += 1; st->reversed += clen / 2; }
     }
 done:
     free(city_ids); free(next); free(prev); free(prev_map); free(used); free(chain); free(adj);
     return improved;
+}
+
+/* find_lk_move (:345-389) on a flat tour with city_ids = the tour, as the reference's unit tests call it
+ * (lin_kernighan.rs:656-700, 768-812).  out_chain needs 2 * max_depth + 4 entries.  Returns the chain length or 0. */
+int tlo_find_lk_move(const float *xy, uint32_t n, const uint32_t *tour, const uint32_t *cand, uint32_t k,
+                     uint32_t max_depth, uint32_t *out_chain)
+{
+    if (n < 2) return 0;
+    if (k > n - 1) k = n - 1;
+    uint32_t *next = (uint32_t *)malloc((size_t)n * sizeof(uint32_t));
+    uint32_t *prev = (uint32_t *)malloc((size_t)n * sizeof(uint32_t));
+    uint32_t *prev_map = (uint32_t *)malloc((size_t)n * sizeof(uint32_t));
+    unsigned char *used = (unsigned char *)calloc(n, 1);
+    adjl *adj = (adjl *)malloc((size_t)n * sizeof(adjl));
+    uint32_t clen = 0;
+    if (next && prev && prev_map && used && adj) {
+        tlo_flat_to_next_prev(tour, n, next, prev);
+        clen = find_lk_move(xy, n, cand, k, max_depth, next, prev, tour, used, out_chain, adj, prev_map, NULL);
+    }
+    free(next); free(prev); free(prev_map); free(used); free(adj);
+    return (int)clen;
+}
+
+/* apply_lk_chain (:397-450) on a flat tour. */
+int tlo_apply_lk_chain(uint32_t *tour, uint32_t n, const uint32_t *chain, uint32_t clen)
+{
+    adjl *adj = (adjl *)malloc((size_t)n * sizeof(adjl));
+    if (!adj) return TLO_ERR_NOMEM;
+    apply_lk_chain(chain, clen, tour, n, adj);
+    free(adj);
+    return TLO_OK;
 }
 
 /* lin_kernighan.rs:485-499 */
@@ -302,10 +343,10 @@ static inline uint64_t sm64(uint64_t *state)
     return z ^ (z >> 31);
 }
 
-/* lin_kernighan.rs:35-100 */
-int tlo_lin_kernighan(const float *xy, uint32_t n, const uint32_t *init, uint32_t epochs,
-                      uint32_t platoo_epochs, uint32_t n_nearest, uint32_t max_depth, uint64_t seed,
-                      uint32_t *out, float *out_cost, tlo_stats *st)
+/* lin_kernighan.rs:35-100; cand_in = precomputed candidate lists (n x min(n_nearest, n-1)) or NULL (brute force) */
+int tlo_lin_kernighan_cand(const float *xy, uint32_t n, const uint32_t *init, uint32_t epochs,
+                           uint32_t platoo_epochs, uint32_t n_nearest, uint32_t max_depth, uint64_t seed,
+                           const uint32_t *cand_in, uint32_t *out, float *out_cost, tlo_stats *st)
 {
     if (!xy || !out || n == 0) return TLO_ERR_BADARG;
     if (st) memset(st, 0, sizeof(*st));
@@ -314,7 +355,8 @@ int tlo_lin_kernighan(const float *xy, uint32_t n, const uint32_t *init, uint32_
     uint32_t *cand = (uint32_t *)malloc((size_t)n * (k ? k : 1) * sizeof(uint32_t));
     uint32_t *candidate = (uint32_t *)malloc((size_t)n * sizeof(uint32_t));
     if (!cand || !candidate) { free(cand); free(candidate); return TLO_ERR_NOMEM; }
-    tlo_build_candidates(xy, n, k, cand); /* :43 */
+    if (cand_in) memcpy(cand, cand_in, (size_t)n * k * sizeof(uint32_t));
+    else tlo_build_candidates(xy, n, k, cand); /* :43 */
 
     if (init) memcpy(out, init, (size_t)n * sizeof(uint32_t)); /* :45-46 */
     else tlo_nearest_neighbor(xy, NULL, n, 3, out, NULL);      /* :47-55 default n_nearest = 3 */
@@ -345,4 +387,11 @@ int tlo_lin_kernighan(const float *xy, uint32_t n, const uint32_t *init, uint32_
     /* :99 Solution::new -> total through problem.distances.tour_length */
     if (out_cost) *out_cost = tlo_tour_length(xy, NULL, n, out);
     return TLO_OK;
+}
+
+int tlo_lin_kernighan(const float *xy, uint32_t n, const uint32_t *init, uint32_t epochs,
+                      uint32_t platoo_epochs, uint32_t n_nearest, uint32_t max_depth, uint64_t seed,
+                      uint32_t *out, float *out_cost, tlo_stats *st)
+{
+    return tlo_lin_kernighan_cand(xy, n, init, epochs, platoo_epochs, n_nearest, max_depth, seed, NULL, out, out_cost, st);
 }

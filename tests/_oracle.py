@@ -19,7 +19,7 @@ class Stats(C.Structure):
 
 def _build():
     so = os.path.join(ORACLE_DIR, "libtl_oracle.so")
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("tl_oracle.c", "tl_oracle_lk.c", "tl_oracle.h")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("tl_oracle.c", "tl_oracle_lk.c", "tl_oracle_kdtree.c", "tl_oracle.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
     return so
@@ -228,14 +228,80 @@ def double_bridge(tour, r1, r2, r3):
     return out
 
 
-def lin_kernighan(xy, init=None, epochs=100, platoo_epochs=10, n_nearest=5, max_depth=5, seed=1):
+def lin_kernighan(xy, init=None, epochs=100, platoo_epochs=10, n_nearest=5, max_depth=5, seed=1, cand=None):
+    """cand: precomputed candidate lists (n x min(n_nearest, n-1)), e.g. build_candidates_kdtree's; None = brute force."""
     xy = _xy(xy)
     n = xy.shape[0]
     init = _perm(init, n)
     out = np.empty(n, dtype=np.uint32)
     cost = C.c_float()
     st = Stats()
-    rc = lib().tlo_lin_kernighan(_p(xy), C.c_uint32(n), _p(init), C.c_uint32(epochs),
-                                 C.c_uint32(platoo_epochs), C.c_uint32(n_nearest), C.c_uint32(max_depth),
-                                 C.c_uint64(seed), _p(out), C.byref(cost), C.byref(st))
+    if cand is not None:
+        cand = np.ascontiguousarray(cand, dtype=np.uint32)
+        assert cand.shape == (n, min(n_nearest, n - 1))
+    rc = lib().tlo_lin_kernighan_cand(_p(xy), C.c_uint32(n), _p(init), C.c_uint32(epochs),
+                                      C.c_uint32(platoo_epochs), C.c_uint32(n_nearest), C.c_uint32(max_depth),
+                                      C.c_uint64(seed), _p(cand), _p(out), C.byref(cost), C.byref(st))
     return rc, out, np.float32(cost.value), st.as_dict()
+
+
+def build_candidates_kdtree(xy, k):
+    """(lists, tie_free): lin_kernighan.rs:12-27 through the restated kd-tree."""
+    xy = _xy(xy)
+    n = xy.shape[0]
+    kk = min(k, n - 1)
+    out = np.empty((n, max(kk, 1)), dtype=np.uint32)
+    tf = C.c_int(0)
+    rc = lib().tlo_build_candidates_kdtree(_p(xy), C.c_uint32(n), C.c_uint32(k), _p(out), C.byref(tf))
+    assert rc == 0
+    return out[:, :kk], bool(tf.value)
+
+
+def kdtree_nearest(xy, q, k, qid=None, ids=None):
+    """KDTree::nearest: [(pos, distance), ...] in buffer order.  qid None = u64::MAX-like sentinel (no self-exclusion)."""
+    xy = _xy(xy)
+    n = xy.shape[0]
+    op = np.empty(max(k, 1), dtype=np.uint32)
+    od = np.empty(max(k, 1), dtype=np.float32)
+    idp = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint64)
+    cnt = lib().tlo_kdtree_nearest(_p(xy), _p(idp), C.c_uint32(n), C.c_float(q[0]), C.c_float(q[1]),
+                                   C.c_uint64(0xFFFFFFFFFFFFFFFF if qid is None else qid), C.c_uint32(k), _p(op), _p(od))
+    assert cnt >= 0
+    return [(int(op[i]), np.float32(od[i])) for i in range(cnt)]
+
+
+def kdtree_walk(xy):
+    xy = _xy(xy)
+    n = xy.shape[0]
+    out = np.empty(max(n, 1), dtype=np.uint32)
+    tf = C.c_int(0)
+    lib().tlo_kdtree_walk(_p(xy), C.c_uint32(n), _p(out), C.byref(tf))
+    return out[:n], bool(tf.value)
+
+
+def flat_to_next_prev(tour):
+    tour = np.ascontiguousarray(tour, dtype=np.uint32)
+    n = len(tour)
+    nxt = np.zeros(int(tour.max()) + 1, dtype=np.uint32)
+    prv = np.zeros(int(tour.max()) + 1, dtype=np.uint32)
+    lib().tlo_flat_to_next_prev(_p(tour), C.c_uint32(n), _p(nxt), _p(prv))
+    return nxt, prv
+
+
+def find_lk_move(xy, tour, cand, max_depth):
+    """find_lk_move on a flat tour: the chain (list) or None."""
+    xy = _xy(xy)
+    tour = np.ascontiguousarray(tour, dtype=np.uint32)
+    cand = np.ascontiguousarray(cand, dtype=np.uint32)
+    chain = np.zeros(2 * max_depth + 4, dtype=np.uint32)
+    clen = lib().tlo_find_lk_move(_p(xy), C.c_uint32(len(tour)), _p(tour), _p(cand), C.c_uint32(cand.shape[1]),
+                                  C.c_uint32(max_depth), _p(chain))
+    return chain[:clen].tolist() if clen else None
+
+
+def apply_lk_chain(tour, chain):
+    tour = np.ascontiguousarray(tour, dtype=np.uint32).copy()
+    chain = np.ascontiguousarray(chain, dtype=np.uint32)
+    rc = lib().tlo_apply_lk_chain(_p(tour), C.c_uint32(len(tour)), _p(chain), C.c_uint32(len(chain)))
+    assert rc == 0
+    return tour
