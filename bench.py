@@ -6,8 +6,10 @@ workload: BASELINE configs 3/4 — synthetic EUC_2D n=10000 (xorshift64 generato
           multi-start REF_ORDER 2-opt: R seeded random restarts per GPU, every restart a full
           first-improvement descent to its local optimum (the reference's algorithm, two_opt.rs:26-61),
           one descent per CU, all concurrently.  One "step" = one such batch.
-          Weak scaling: rank k runs restarts [k*R, (k+1)*R); after every step the ranks min-all-reduce
+          Weak scaling (default): rank k runs restarts [k*R, (k+1)*R); after every step the ranks min-all-reduce
           (RCCL) the packed key (f32 cost bits << 32 | restart id) of their best tour.
+          --restarts-total T: strong scaling as BASELINE configs[3] words it — T restarts in all, sharded in
+          contiguous blocks over the ranks (reported as "scaling": "strong").
           Inputs (coordinates) are resident in HBM before the timed region; restart permutations are
           generated on the device inside the timed region (they are part of the job).
 candidates are counted as the reference's loop visits them: sweeps x (n-3)(n-2)/2 per descent.
@@ -31,7 +33,9 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ALG_BYTES_PER_CANDIDATE = 8.0   # one new tour-ordered (x,y) per j-step, on-the-fly form
-FP32_VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md chip table
+SIMDS_PER_CU = 4                # MI355X_MICROARCH.md: 4 SIMD-32 per CU
+VALU_CYCLES_PER_WAVE_INST = 2.0  # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32
+REFCLK_HZ = 100e6               # s_memrealtime ticks (constant 100 MHz)
 
 
 def parse():
@@ -40,7 +44,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=10000)
-    ap.add_argument("--restarts", type=int, default=256, help="restarts per GPU per step (one per CU)")
+    ap.add_argument("--restarts", type=int, default=256, help="restarts per GPU per step (one per CU); weak scaling")
+    ap.add_argument("--restarts-total", type=int, default=0,
+                    help="strong scaling: this many restarts in all, sharded over the ranks (BASELINE configs[3]: 256)")
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-descent / no-prune / matrix-build extras")
@@ -60,7 +66,7 @@ def cpu_baseline(n, seed, xy):
     def work(k):
         init = O.restart_perm(n, seed, k)
         rc, p, c, st = O.two_opt(xy, None, n, init=init, flavor=0)
-        res[k] = (st["candidates"], float(c))
+        res[k] = (st["candidates"], np.float32(c), st["sweeps"], st["moves"])
 
     t0 = time.perf_counter()
     th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
@@ -72,7 +78,7 @@ def cpu_baseline(n, seed, xy):
     t1 = time.perf_counter()
     rc, p, c, st = O.two_opt(xy, None, n, init=O.restart_perm(n, seed, 0), flavor=1, max_candidates=1)
     wall_f = time.perf_counter() - t1
-    return {
+    return res, {
         "value": total / wall, "unit": "candidates/s", "cores": cores, "kind": "port",
         "sample": f"{cores} full restart descents (restarts 0..{cores - 1}, n={n}, ~{total / cores:.2e} candidates each), "
                   f"one per core, on-the-fly f32 distances (best-effort flavour); wall {wall:.1f} s",
@@ -82,6 +88,53 @@ def cpu_baseline(n, seed, xy):
                                          f"two SipHash-1-3 id lookups per distance (distance_matrix.rs:197-212), "
                                          f"incl. 200 MB matrix build; wall {wall_f:.1f} s"},
     }
+
+
+def latest_profile(pattern):
+    import glob
+    f = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return f[-1] if f else None
+
+
+def valu_roofline(n, R, seed, first, info, k_ms, clock_hz, work, cand_per_launch, launches):
+    """What bounds k_two_opt_ref_lds is VALU issue, not HBM (the tour never leaves LDS: DESIGN.md §4.2).
+    achieved = wave64 VALU instructions per launch / kernel time; peak = SIMDs x clock / 2 (a wave64 VALU instruction
+    occupies a SIMD-32 for 2 cycles).  The instruction count is SQ_INSTS_VALU of a rocprofv3 --pmc pass over this same
+    launch (profiles/rNN_valu_roofline.json): the launch is deterministic (seeded restarts), and the in-kernel work
+    counters measured live here must equal the ones recorded with the PMC pass for the count to be used.  Kernel time
+    and the shader clock are measured live."""
+    simds = info["cus"] * SIMDS_PER_CU
+    r = {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave64-VALU-instructions/s", "frac": None,
+         "traffic": None, "kernel": "k_two_opt_ref_lds", "kernel_ms_avg": k_ms, "launches": launches,
+         "simds": simds, "clock_mhz_live": clock_hz / 1e6,
+         "formula": "frac = SQ_INSTS_VALU / (simds * kernel_s * clock_hz / 2)",
+         "algorithmic_hbm_view": {"bytes_per_candidate": ALG_BYTES_PER_CANDIDATE,
+                                  "GBps": cand_per_launch * ALG_BYTES_PER_CANDIDATE / (k_ms * 1e-3) / 1e9,
+                                  "note": "SURVEY.md §8(d)'s 8 B per candidate against 8 TB/s would read above 1: the kernel "
+                                          "does not move those bytes (tour in LDS, exact tile bounds), so HBM is not the bound"}}
+    if clock_hz > 0:
+        r["peak"] = simds * clock_hz / VALU_CYCLES_PER_WAVE_INST / 1e9
+    prof = latest_profile("r*_valu_roofline.json")
+    if prof and first == 0:
+        try:
+            pj = json.load(open(prof))
+            r["source"] = os.path.relpath(prof, ROOT)
+            same = (pj.get("n") == n and pj.get("restarts") == R and pj.get("seed") == seed and
+                    all(int(pj.get("work", {}).get(k, -1)) == v for k, v in work.items()))
+            r["work_matches_profile"] = bool(same)
+            if same and r["peak"]:
+                insts = float(pj["SQ_INSTS_VALU"])
+                r["valu_insts_per_launch"] = insts
+                r["achieved"] = insts / (k_ms * 1e-3) / 1e9
+                r["frac"] = r["achieved"] / r["peak"]
+                r["traffic"] = pj.get("hbm_traffic_bytes_per_launch")
+                for k in ("SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
+                          "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CU_CYCLES"):
+                    if k in pj:
+                        r.setdefault("pmc", {})[k] = pj[k]
+        except Exception as exc:  # a malformed profile file must not break the bench line
+            r["source_error"] = repr(exc)
+    return r
 
 
 def main():
@@ -104,7 +157,14 @@ def main():
 
     import teeline_amd as TA
     from teeline_amd import _capi
-    n, R = a.n, a.restarts
+    n = a.n
+    strong = a.restarts_total > 0
+    if strong:
+        first, R = TA.multistart.shard_total(rank, world, a.restarts_total)
+    else:
+        first, R = TA.multistart.shard(rank, a.restarts)
+    if R == 0:
+        raise SystemExit(f"--restarts-total {a.restarts_total} leaves rank {rank} without a restart")
     xy = TA.synth.synth_xy(n)
     ctx = TA.Context(local)
     info = ctx.device_info()
@@ -114,7 +174,6 @@ def main():
     d_pos = torch.empty((R, n), dtype=torch.int32, device=dev)
     d_cost = torch.empty(R, dtype=torch.float32, device=dev)
     d_stats = torch.zeros((R, _capi.TL_DEV_STATS_STRIDE), dtype=torch.int64, device=dev)
-    first, _ = TA.multistart.shard(rank, R)
     per_sweep = (n - 3) * (n - 2) // 2
     # Everything of a step is enqueued on ONE explicit stream: the descent kernel (through the C ABI), the key packing
     # and the collective.  (A NULL stream would mean the context's own non-blocking stream, unordered with torch's.)
@@ -164,6 +223,14 @@ def main():
     dt = time.perf_counter() - t0
     kernel_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
     cands = int(sweeps_dev.item()) * per_sweep
+    st_host = d_stats.cpu().numpy().astype(np.uint64)       # the last launch (every launch does the same work)
+    cost_host = d_cost.cpu().numpy()
+    # work the cascade really did (in-kernel SALU counters, st[5..8]) and the clock the CUs held (st[9] shader clocks
+    # over st[10] ticks of the constant 100 MHz reference)
+    work = {"l0_tile_bounds": int(st_host[:, 5].sum()), "l1_candidates": int(st_host[:, 6].sum()),
+            "l2_candidates": int(st_host[:, 7].sum()), "l3_candidates": int(st_host[:, 8].sum())}
+    ticks = st_host[:, 10].astype(np.float64)
+    clock_hz = float(np.mean(st_host[:, 9].astype(np.float64) / np.maximum(ticks, 1.0))) * REFCLK_HZ if ticks.min() > 0 else 0.0
 
     total, dt_max = TA.multistart.aggregate_throughput(cands, dt, dev, dist)
     best_cost, best_restart = TA.multistart.unpack_key(key.item())
@@ -178,7 +245,6 @@ def main():
     status_bad = int((d_stats[:, 3] != 0).sum().item())
     k_ms = float(np.mean(kernel_ms))
     cand_per_launch = cands / a.steps
-    achieved = cand_per_launch * ALG_BYTES_PER_CANDIDATE / (k_ms * 1e-3) / 1e9
     out = {
         "metric": "2-opt candidate swaps evaluated/sec + final tour cost, TSPLIB EUC_2D n=10000",
         "value": total / dt_max,
@@ -186,60 +252,31 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt_max / a.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"configs[2]/[3]: synthetic EUC_2D n={n} (xorshift64 seed 88172645463325252), multi-start "
                                f"REF_ORDER 2-opt to local optimum, {R} seeded random restarts per GPU (one descent per CU), "
                                f"on-the-fly f32 distances, tour resident in LDS",
-                   "n": n, "restarts_per_gpu": R, "restarts_total": R * world, "mode": "REF_ORDER",
+                   "n": n, "restarts_per_gpu": R, "restarts_total": a.restarts_total if strong else R * world, "mode": "REF_ORDER",
                    "restart_seed": a.seed, "collective": "RCCL min-all-reduce of (cost_bits<<32|restart) per step + SUM-all-reduce of the winner's tour (n x 4 B)" if world > 1 else "none (1 GPU)"},
         "final_tour_cost": best_cost, "best_restart": best_restart,
         "candidates_per_step_per_gpu": cand_per_launch,
         "descents_not_converged": status_bad,
         "device": info,
-        "roofline": {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": None,
-            "kernel": "k_two_opt_ref_lds", "kernel_ms_avg": k_ms, "launches": a.steps,
-            "algorithmic_bytes_per_candidate": ALG_BYTES_PER_CANDIDATE,
-            "note": "algorithmic bytes = 8 B per candidate (SURVEY.md §8(d)) as the contract defines `achieved`; the tour lives in LDS "
-                    "for the whole descent and the L0/L1 bounds discard most candidates without touching them, so `frac` can "
-                    "exceed 1 and says nothing about HBM: real HBM traffic is `traffic` (~13 MB per launch). What binds the kernel "
-                    "is per-SIMD instruction issue, LDS bandwidth of the segment reversals and workgroup barriers (`binding`, "
-                    "DESIGN.md §4.2)",
-        },
+        "roofline": None,
     }
-    spath = os.path.join(ROOT, "profiles", "r01_pmc_sq_two_opt.csv")
-    if os.path.exists(spath) and n == 10000 and R == 256:
-        try:
-            sq = {}
-            for line in open(spath).read().strip().splitlines()[1:]:
-                name, val, _ = line.split(",")
-                sq[name] = float(val)
-            wc = sq["SQ_WAVE_CYCLES"]
-            out["roofline"]["binding"] = {
-                "source": "profiles/r01_pmc_sq_two_opt.csv (rocprofv3 --pmc SQ_*, one launch)",
-                "waves_per_simd": 4,
-                "valu_active_frac_per_wave": sq.get("SQ_ACTIVE_INST_VALU", 0.0) / wc,
-                "valu_busy_frac_per_simd_est": 4 * sq.get("SQ_ACTIVE_INST_VALU", 0.0) / wc,
-                "wave_parked_frac": sq.get("SQ_WAIT_ANY", 0.0) / wc,
-                "issue_stall_frac": sq.get("SQ_WAIT_INST_ANY", 0.0) / wc,
-                "lds_active_frac_per_wave": sq.get("SQ_ACTIVE_INST_LDS", 0.0) / wc,
-            }
-        except Exception:
-            pass
-    # traffic from a committed PMC pass, if one exists for this round
-    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if os.path.exists(tpath) and n == 10000 and R == 256:
-        try:
-            tj = json.load(open(tpath))
-            out["roofline"]["traffic"] = tj.get("traffic_bytes_per_launch")
-            out["roofline"]["traffic_source"] = tj.get("source")
-        except Exception:
-            pass
-
+    out["candidates_touched"] = {
+        **work,
+        "l1_candidates_per_s": work["l1_candidates"] / (k_ms * 1e-3),
+        "fraction_of_algorithmic": work["l1_candidates"] / max(cand_per_launch, 1.0),
+        "note": "per launch, counted in the kernel: tile bounds evaluated by L0 (64 tiles per wave pass), candidates whose "
+                "squared-distance test L1 ran, candidates that went on to the v_sqrt_f32 test L2, and to the exact L3; "
+                "`value` counts candidates as the reference's loop visits them (SURVEY.md §8(d)), L0 decides most of "
+                "them a tile at a time",
+    }
+    out["roofline"] = valu_roofline(n, R, a.seed, first, info, k_ms, clock_hz, work, cand_per_launch, a.steps)
     if world == 1 and not a.no_extras:
         extras = {}
         prob = TA.TspProblem(np.arange(n), xy)
@@ -273,8 +310,8 @@ def main():
                "traffic": None, "kernel": "k_dm_build_packed_rows", "kernel_ms_avg": ms,
                "note": "4 B written per distance; a plain fill of the same 200 MB reaches 6.65 TB/s on this part (scripts/hbm_fill_probe.py), "
                        "the build is at the VALU/HBM crossover (DESIGN.md §4.1)"}
-        dpath = os.path.join(ROOT, "profiles", "r01_dm_build_hbm_traffic.json")
-        if os.path.exists(dpath) and n == 10000:
+        dpath = latest_profile("r*_dm_build_hbm_traffic.json")
+        if dpath and n == 10000:
             try:
                 dj = json.load(open(dpath))
                 rdm["traffic"] = dj.get("traffic_bytes_per_launch")
@@ -318,7 +355,20 @@ def main():
                                        "placements": 6 * n5 * n5, "note": "3 segment lengths x n starts x n insertion points x {fwd, rev} (or_opt.rs:80-164)"}
         out["extras"] = extras
     if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(n, a.seed, xy)
+        res, out["cpu_baseline"] = cpu_baseline(n, a.seed, xy)
+        # the oracle's descents of restarts 0..cores-1 are the same units the GPU just ran: cost bits and sweep / move
+        # counters must agree, or the headline number counts something else than the reference's loop
+        bad = []
+        for k, (cnd, c, sw, mv) in enumerate(res):
+            if first <= k < first + R:
+                j = k - first
+                if np.float32(cost_host[j]).tobytes() != np.float32(c).tobytes() or int(st_host[j, 0]) != sw or int(st_host[j, 1]) != mv:
+                    bad.append((k, float(cost_host[j]), float(c), int(st_host[j, 0]), sw, int(st_host[j, 1]), mv))
+        out["parity_checked_restarts"] = sum(1 for k in range(len(res)) if first <= k < first + R)
+        out["parity_mismatches"] = bad
+        if bad:
+            print(json.dumps(out))
+            raise SystemExit(f"bench.py: GPU restarts differ from the oracle: {bad[:4]}")
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define TL_ABI_VERSION 1
+#define TL_ABI_VERSION 2
 
 typedef struct tl_ctx tl_ctx;
 
@@ -70,6 +70,15 @@ typedef enum tl_mode {
  * squared-distance pre-test (see DESIGN.md "Exact pruning").  Results are identical; only speed
  * changes.  Used by bench.py to report the un-pruned rate next to the default one. */
 #define TL_FLAG_NO_PRUNE 1u
+/* Alternative forms of a kernel, kept as cross-checks of each other (the parity tests run every form against the oracle):
+ * results are identical, only speed changes.  The library never reads the environment. */
+#define TL_FLAG_2OPT_FORCE_HBM (1u << 1)   /* tl_two_opt: the HBM-resident REF_ORDER variant (n > LDS limit) at every n      */
+#define TL_FLAG_LK_ONE_WORKGROUP (1u << 2) /* tl_lk: the whole ILS in one persistent workgroup instead of chip-wide scans  */
+#define TL_FLAG_LK_NO_SPLIT (1u << 3)      /* tl_lk: one lane per (t1, orientation) pair, no sub-search split               */
+#define TL_FLAG_LK_SPLIT2 (1u << 4)        /* tl_lk: two split levels (k(k+1) sub-searches per pair) instead of three       */
+#define TL_FLAG_LK_NO_SUBCHAINS (1u << 5)  /* tl_lk: the pick step walks the winning chain again instead of reading it      */
+#define TL_FLAG_KNN_4LANES (1u << 6)       /* candidate lists: four lanes per city (the form used beyond n = 32 K)          */
+#define TL_FLAG_KNN_1LANE (1u << 7)        /* candidate lists: one lane per city                                            */
 
 /* matrix layouts for tl_dm_build */
 #define TL_DM_PACKED_LOWER 0 /* reference layout, n(n-1)/2 floats (distance_matrix.rs:122-153) */
@@ -146,9 +155,13 @@ int tl_three_opt_find_best_move(tl_ctx *ctx, const float *xy, uint32_t n, const 
                                 uint32_t *k, int *kase, float *savings);
 
 /* ---- Lin–Kernighan: replaces lin_kernighan::solve (lin_kernighan.rs:35-100) ----------------- */
-/* seed drives the double-bridge kicks (the reference uses an unseeded thread RNG, :73). */
-int tl_lk(tl_ctx *ctx, const float *xy, uint32_t n, const uint32_t *init_pos, const tl_lk_opts *opts,
-          uint64_t seed, uint32_t *out_pos, float *out_cost, tl_stats *stats);
+/* seed drives the double-bridge kicks (the reference uses an unseeded thread RNG, :73).
+ * The search itself is always Euclidean over xy: the reference rebuilds its own matrix from the city coordinates
+ * (lin_kernighan.rs:41) whatever problem.distances holds.  dm_packed (optional; pass problem.distances for GEO / EXPLICIT
+ * problems) is used exactly where the reference uses problem.distances: the nearest-neighbour seed when init_pos is NULL
+ * (:47-55) and the reported total (:99 Solution::new -> tour_length). */
+int tl_lk(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
+          const tl_lk_opts *opts, uint64_t seed, uint32_t *out_pos, float *out_cost, tl_stats *stats);
 
 /* ---- Or-opt: replaces or_opt::solve (or_opt.rs:18-74) — SURVEY.md §8(f) "next" row ------------ */
 /* Best-improvement relocation of 1/2/3-city segments (forward and, for 2/3, reversed), threshold -1e-3 (:86). */
@@ -163,12 +176,14 @@ int tl_or_opt_find_best_move(tl_ctx *ctx, const float *xy, uint32_t n, const flo
  * order is implementation-defined, kdtree.rs:63). */
 int tl_build_candidates(tl_ctx *ctx, const float *xy, uint32_t n, uint32_t k, uint32_t *out);
 
-/* ---- NN seed: replaces nearest_neighbor::solve (nearest_neighbor.rs:8-76), EUC_2D ------------- */
+/* ---- NN seed: replaces nearest_neighbor::solve (nearest_neighbor.rs:8-76) ---------------------- */
 /* First unvisited among the n_nearest closest (stable ties, mod.rs:1848-1855), else the globally
  * nearest unvisited (tie -> lowest position; the reference iterates a HashSet there).  The walk's visited flags
- * live in one CU's LDS (n bytes): n <= ~160 000 (TL_ERR_UNSUPPORTED beyond); n_nearest <= 16. */
-int tl_nearest_neighbor(tl_ctx *ctx, const float *xy, uint32_t n, uint32_t n_nearest, uint32_t *out_pos,
-                        float *out_cost);
+ * live in one CU's LDS (n bytes): n <= ~160 000 (TL_ERR_UNSUPPORTED beyond); n_nearest <= 16.
+ * dm_packed NULL: EUC_2D from xy; otherwise every distance is read from the packed matrix (GEO / EXPLICIT problems,
+ * distance_matrix.rs:259-297) and xy may be NULL. */
+int tl_nearest_neighbor(tl_ctx *ctx, const float *xy, const float *dm_packed, uint32_t n, uint32_t n_nearest,
+                        uint32_t *out_pos, float *out_cost);
 
 /* ---- multi-start 2-opt (north-star config 4; no counterpart in the reference) ---------------- */
 /* Runs restarts [first, first+count) — restart r starts from the Fisher–Yates permutation drawn
@@ -193,7 +208,9 @@ int tl_two_opt_population(tl_ctx *ctx, const float *xy, uint32_t n, const float 
 /* ---- device-resident batch entry (bench / pipelines that keep data in HBM) ------------------- */
 /* All d_* are DEVICE pointers on the context's device.  d_init: count x n u32 (NULL: seeded restarts
  * first..first+count as above; seed ignored otherwise).  d_out_pos: count x n u32, d_out_cost: count f32,
- * d_out_stats: count x TL_DEV_STATS_STRIDE u64 {sweeps, moves, reversed, status, steps, reserved...}.  stream: the hipStream_t to enqueue on,
+ * d_out_stats: count x TL_DEV_STATS_STRIDE u64 {sweeps, moves, reversed, status (0 ok, 1 sweep cap reached, 2 d_init holds a
+ * position >= n: that descent is refused, its cost is NaN), steps, L0 tile bounds evaluated, candidates into L1, into L2,
+ * into L3, shader clocks, 100 MHz ticks, reserved...}.  stream: the hipStream_t to enqueue on,
  * or NULL for the context's own stream — which is NON-BLOCKING, i.e. not ordered with the legacy default stream: a
  * caller that passes NULL must wait on tl_last_kernel_ms() (or a device synchronise) before touching the outputs.
  * Asynchronous: returns after enqueueing. */

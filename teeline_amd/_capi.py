@@ -16,6 +16,9 @@ TL_ERR_BADARG, TL_ERR_REF_PANICS, TL_ERR_NO_DEVICE, TL_ERR_HIP = -1, -2, -3, -4
 TL_ERR_NOMEM, TL_ERR_UNSUPPORTED, TL_ERR_NO_CONVERGE = -5, -6, -7
 TL_MODE_REF_ORDER, TL_MODE_BEST_SWEEP = 0, 1
 TL_FLAG_NONE, TL_FLAG_NO_PRUNE = 0, 1
+# alternative kernel forms (identical results; cross-checks of each other)
+TL_FLAG_2OPT_FORCE_HBM, TL_FLAG_LK_ONE_WORKGROUP, TL_FLAG_LK_NO_SPLIT, TL_FLAG_LK_SPLIT2 = 1 << 1, 1 << 2, 1 << 3, 1 << 4
+TL_FLAG_LK_NO_SUBCHAINS, TL_FLAG_KNN_4LANES, TL_FLAG_KNN_1LANE = 1 << 5, 1 << 6, 1 << 7
 TL_DM_PACKED_LOWER, TL_DM_FULL = 0, 1
 TL_DIST_EUC2D, TL_DIST_GEO = 0, 1
 
@@ -82,7 +85,7 @@ def load():
     L.tl_three_opt.argtypes = [vp, vp, u32, vp, vp, vp, f32p, C.POINTER(TlStats)]
     L.tl_three_opt_find_best_move.argtypes = [vp, vp, u32, vp, vp, C.POINTER(i32), C.POINTER(u32),
                                               C.POINTER(u32), C.POINTER(u32), C.POINTER(i32), f32p]
-    L.tl_lk.argtypes = [vp, vp, u32, vp, C.POINTER(TlLkOpts), u64, vp, f32p, C.POINTER(TlStats)]
+    L.tl_lk.argtypes = [vp, vp, u32, vp, vp, C.POINTER(TlLkOpts), u64, vp, f32p, C.POINTER(TlStats)]
     L.tl_two_opt_multistart.argtypes = [vp, vp, u32, u64, u32, u32, i32, vp, f32p, C.POINTER(u32), vp,
                                         C.POINTER(TlStats)]
     L.tl_two_opt_population.argtypes = [vp, vp, u32, vp, vp, u32, vp, vp, C.POINTER(TlStats)]
@@ -92,7 +95,7 @@ def load():
     L.tl_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_double)]
     L.tl_dm_build_dev.argtypes = [vp, vp, u32, i32, i32, vp, vp]
     L.tl_build_candidates.argtypes = [vp, vp, u32, u32, vp]
-    L.tl_nearest_neighbor.argtypes = [vp, vp, u32, u32, vp, f32p]
+    L.tl_nearest_neighbor.argtypes = [vp, vp, vp, u32, u32, vp, f32p]
     L.tl_selftest_sqrt.argtypes = [vp, u32, u64, C.POINTER(u64), C.POINTER(u32)]
     L.tl_or_opt.argtypes = [vp, vp, u32, vp, vp, vp, f32p, C.POINTER(TlStats)]
     L.tl_or_opt_find_best_move.argtypes = [vp, vp, u32, vp, vp, C.POINTER(i32), f32p, C.POINTER(u32), C.POINTER(u32),

@@ -1255,7 +1255,7 @@ hipError_t launch_lk_round(const LkArgs &G, hipStream_t s)
     } else {
         const size_t lds = (size_t)G.n * 10;
         if (G.n < 65536u && lds <= (size_t)G.lds_budget) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_lk_scan<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = allow_max_lds(reinterpret_cast<const void *>(k_lk_scan<true>));
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(k_lk_scan<true>, dim3((2u * G.n + 255u) / 256u), dim3(256), lds, s, G);
         } else {
@@ -1269,10 +1269,10 @@ hipError_t launch_lk_round(const LkArgs &G, hipStream_t s)
 
 size_t lk_chain_slot_words() { return (size_t)kLkMaxChain + 2; }
 
-hipError_t launch_knn(const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, hipStream_t s)
+hipError_t launch_knn(const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, hipStream_t s, int form)
 {
-    if (!getenv("TL_KNN_NO_QUAD")) {  // several lanes per city: 16 while that still fills the chip (n <= 32 K), else 4
-        if (n <= 32768u && !getenv("TL_KNN_GROUP4")) {
+    if (form != 1) {  // several lanes per city: 16 while that still fills the chip (n <= 32 K), else 4 (form 4 forces it)
+        if (n <= 32768u && form != 4) {
             const uint32_t gq = (n + 15u) / 16u;
             if (k <= 4) hipLaunchKernelGGL((k_knn_quad<4, 16>), dim3(gq), dim3(256), 0, s, xy, n, k, cand);
             else if (k <= 8) hipLaunchKernelGGL((k_knn_quad<8, 16>), dim3(gq), dim3(256), 0, s, xy, n, k, cand);
@@ -1304,7 +1304,7 @@ hipError_t launch_nn_seed(const float2 *xy, uint32_t n, const uint32_t *cand, ui
     const bool lds_xy = b_vis + (lds_cand ? b_cand : 0) + b_xy <= cap;
     const size_t lds = b_vis + (lds_cand ? b_cand : 0) + (lds_xy ? b_xy : 0);
     auto go = [&](auto kern) -> hipError_t {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = allow_max_lds(reinterpret_cast<const void *>(kern));
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(1), dim3(kLkNT), lds, s, xy, n, cand, k, path);
         return hipGetLastError();
@@ -1322,6 +1322,61 @@ hipError_t launch_nn_seed(const float2 *xy, uint32_t n, const uint32_t *cand, ui
     if (lds_cand) return pick(std::true_type{}, std::false_type{});
     if (lds_xy) return pick(std::false_type{}, std::true_type{});
     return pick(std::false_type{}, std::false_type{});
+}
+
+// ---------------------------------------------------------------------------------------------- NN seed, matrix form
+// nearest_neighbor::solve over an EXPLICIT / GEO problem (nearest_neighbor.rs:8-76 with problem.distances =
+// the packed matrix, distance_matrix.rs:259-297): every step takes the first unvisited city in (distance, position)
+// order — what both the k-buffer rule (mod.rs:1848-1855, scan in position order, insert after equals) and the fallback
+// (:50-63; ties -> lowest position, the oracle's rule where the reference iterates a HashSet) pick.  One workgroup, the
+// visited flags in LDS, one row of the matrix per step: argmin of the packed key (sortable distance bits << 32 | position).
+__global__ __launch_bounds__(kLkNT) void k_nn_seed_dm(const float *__restrict__ dm, uint32_t n, uint32_t *__restrict__ path)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char nn_smem[];
+    __shared__ unsigned long long s_best[2];
+    unsigned char *visited = nn_smem;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t p = tid; p < n; p += kLkNT) visited[p] = p == 0u;  // :28-30 starts at cities[0]
+    if (tid < 2) s_best[tid] = ~0ull;
+    if (tid == 0) path[0] = 0u;
+    __syncthreads();
+    uint32_t cur = 0;
+    for (uint32_t step = 1; step < n; ++step) {
+        unsigned long long best = ~0ull;
+        for (uint32_t p = tid; p < n; p += kLkNT) {
+            if (visited[p]) continue;
+            const uint32_t b = __builtin_bit_cast(uint32_t, dm_lookup(dm, cur, p));
+            const uint32_t key = (b & 0x80000000u) ? ~b : (b | 0x80000000u);  // f32 order as u32 order
+            const unsigned long long kk = ((unsigned long long)key << 32) | p;
+            best = kk < best ? kk : best;
+        }
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)best, sft), hi = (uint32_t)__shfl_xor((int)(uint32_t)(best >> 32), sft);
+            const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+            best = o < best ? o : best;
+        }
+        unsigned long long *slot = &s_best[step & 1u];
+        if ((tid & 63u) == 0u) atomicMin(slot, best);
+        __syncthreads();
+        cur = (uint32_t)(*slot & 0xFFFFFFFFull);
+        if (tid == 0) {
+            path[step] = cur;
+            visited[cur] = 1;
+            s_best[(step + 1u) & 1u] = ~0ull;
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_nn_seed_dm(const float *dm, uint32_t n, uint32_t *path, int lds_bytes, hipStream_t s)
+{
+    const size_t lds = ((size_t)n + 15u) & ~(size_t)15u;
+    if (lds + 1024 > (size_t)lds_bytes) return hipErrorInvalidValue;  // callers check
+    hipError_t e = allow_max_lds(reinterpret_cast<const void *>(k_nn_seed_dm));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_nn_seed_dm, dim3(1), dim3(kLkNT), lds, s, dm, n, path);
+    return hipGetLastError();
 }
 
 hipError_t launch_lk_solve(const LkArgs &G, hipStream_t s)

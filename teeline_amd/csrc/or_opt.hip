@@ -228,7 +228,7 @@ hipError_t launch_or_opt_pass(const OrOptArgs &A, bool dm, int apply, hipStream_
         hipLaunchKernelGGL(k_or_prepare<false>, dim3(pg), dim3(256), 0, s, A);
         hipLaunchKernelGGL(k_or_scan<false>, dim3(gx, gy), dim3(kOrWaves * 64), 0, s, A, or_opt_chunks(A.n));
     }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_or_pick), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)A.n * 4));
+    hipError_t e = allow_max_lds(reinterpret_cast<const void *>(k_or_pick));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_or_pick, dim3(1), dim3(1024), (size_t)A.n * 4, s, A, nblocks, apply);
     return hipGetLastError();

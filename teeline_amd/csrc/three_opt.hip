@@ -248,10 +248,10 @@ hipError_t launch_three_opt_pass(const ThreeOptArgs &A, uint32_t nblocks, bool d
         hipLaunchKernelGGL(k_three_opt_prepare<false>, dim3(pg), dim3(256), 0, s, A);
         hipLaunchKernelGGL(k_three_opt_build_dt<false>, dg, dim3(256), 0, s, A);
     }
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_three_opt_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = allow_max_lds(reinterpret_cast<const void *>(k_three_opt_scan));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_three_opt_scan, dim3(nblocks), dim3(kT3), lds, s, A);
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_three_opt_pick), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)A.n * 4));
+    e = allow_max_lds(reinterpret_cast<const void *>(k_three_opt_pick));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_three_opt_pick, dim3(1), dim3(1024), (size_t)A.n * 4, s, A, nblocks, apply);
     return hipGetLastError();

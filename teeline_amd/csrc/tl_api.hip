@@ -35,7 +35,9 @@ struct tl_ctx {
     int dm_layout = -1;
 };
 
-static std::string g_create_err;
+static thread_local std::string g_create_err;  // tl_last_error(NULL): the calling thread's last tl_create failure
+
+static int knn_form(const tl_ctx *c);
 
 static int fail(tl_ctx *c, int code, const char *fmt, ...)
 {
@@ -277,11 +279,18 @@ static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uin
     A.n = n;
     A.max_sweeps = 1u << 20;
     A.init_mode = init_mode;
-    HIPCHK(c, hipEventRecord(c->ev0, s));
+    // every size / mode check comes before the first event record: a rejected call must leave the event pair of the
+    // previous kernel sequence intact
     if (d_dm) {
         if (init_mode == TL_INIT_SEEDED) return fail(c, TL_ERR_UNSUPPORTED, "seeded restarts need coordinates (dm_packed must be NULL)");
         if (two_opt_ref_dm_lds_bytes(n) > (size_t)c->lds_bytes || n > 65535)
             return fail(c, TL_ERR_UNSUPPORTED, "two_opt (matrix form): n=%u exceeds the LDS tour capacity", n);
+    } else if (n > lds_max_n(c->lds_bytes)) {
+        return fail(c, TL_ERR_UNSUPPORTED, "two_opt (on-the-fly form): n=%u exceeds the LDS-resident limit %u", n, lds_max_n(c->lds_bytes));
+    }
+    c->ev_valid = false;
+    HIPCHK(c, hipEventRecord(c->ev0, s));
+    if (d_dm) {
         // the packed triangle (reference layout) is expanded to a full row-major matrix once per call: a row scan then
         // gathers inside one 4n-byte row instead of one cache line per column (two_opt_dm.hip)
         int rc2;
@@ -290,9 +299,6 @@ static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uin
         A.dm_full = (const float *)c->dmfull.p;
         HIPCHK(c, launch_two_opt_ref_dm(A, count, c->lds_bytes, s));
     } else {
-        const uint32_t nmax = lds_max_n(c->lds_bytes);
-        if (n > nmax)
-            return fail(c, TL_ERR_UNSUPPORTED, "two_opt (on-the-fly form): n=%u exceeds the LDS-resident limit %u", n, nmax);
         HIPCHK(c, launch_two_opt_ref_lds(A, count, !(c->flags & TL_FLAG_NO_PRUNE), s));
     }
     HIPCHK(c, hipEventRecord(c->ev1, s));
@@ -403,7 +409,7 @@ extern "C" int tl_two_opt(tl_ctx *c, const float *xy, uint32_t n, const float *d
     if (n < 3) return fail(c, TL_ERR_REF_PANICS, "two_opt: n=%u < 3 — the reference underflows `n_indices - 2` (two_opt.rs:17,29)", n);
     if (init_pos && !is_permutation(init_pos, n)) return fail(c, TL_ERR_BADARG, "tl_two_opt: init tour is not a permutation of 0..n-1");
     if (mode == TL_MODE_BEST_SWEEP) return two_opt_best_sweep(c, xy, n, dm_packed, init_pos, out_pos, out_cost, stats);
-    if (!dm_packed && (n > lds_max_n(c->lds_bytes) || getenv("TL_FORCE_LARGE_2OPT"))) {
+    if (!dm_packed && (n > lds_max_n(c->lds_bytes) || (c->flags & TL_FLAG_2OPT_FORCE_HBM))) {
         if (n < 4) {  // n == 3: the reference's loops are empty
             for (uint32_t i = 0; i < n; ++i) out_pos[i] = init_pos ? init_pos[i] : i;
             if (stats) { memset(stats, 0, sizeof(*stats)); stats->sweeps = 1; }
@@ -443,11 +449,7 @@ extern "C" int tl_two_opt(tl_ctx *c, const float *xy, uint32_t n, const float *d
     HIPCHK(c, hipMemcpyAsync(&cost, c->out_cost.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(raw, c->out_stats.p, TL_STATS_STRIDE * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (getenv("TL_DUMP_STATS")) {
-        fprintf(stderr, "[tl] raw stats:");
-        for (int q = 0; q < TL_STATS_STRIDE; ++q) fprintf(stderr, " %llu", (unsigned long long)raw[q]);
-        fprintf(stderr, "\n");
-    }
+    if (raw[3] == 2) return fail(c, TL_ERR_BADARG, "two_opt: the initial tour holds a position >= n");
     if (raw[3] != 0) return fail(c, TL_ERR_NO_CONVERGE, "two_opt: sweep cap reached");
     if (out_cost) *out_cost = cost;
     double kms = 0;
@@ -633,9 +635,12 @@ struct ThreeOptSetup {
     bool dm = false;
 };
 
-static uint32_t three_opt_max_n(const tl_ctx *)
+static uint32_t three_opt_max_n(const tl_ctx *c)
 {
-    return 65535u;  // (i, j) and (k, case) travel as packed 16-bit fields; the workspace holds an n x (n+1) f32 matrix
+    // (i, j) and (k, case) travel as packed 16-bit fields; k_three_opt_pick stages the tour in LDS (4 B per city next to
+    // its static block); the workspace holds an n x (n+1) f32 matrix
+    const uint32_t by_lds = (uint32_t)((c->lds_bytes > 2048 ? c->lds_bytes - 2048 : 0) / 4);
+    return by_lds < 65535u ? by_lds : 65535u;
 }
 
 // uploads inputs, lays out the workspace in c->work and fills the kernel argument block
@@ -919,7 +924,8 @@ extern "C" int tl_or_opt(tl_ctx *c, const float *xy, uint32_t n, const float *dm
     return TL_OK;
 }
 
-static bool max_depth_ge2_split(uint32_t) { return true; }  // the split scan handles every max_depth >= 1
+static bool max_depth_ge2_split(uint32_t) { return true; }
+static int knn_form(const tl_ctx *c) { return (c->flags & TL_FLAG_KNN_1LANE) ? 1 : (c->flags & TL_FLAG_KNN_4LANES) ? 4 : 0; }  // the split scan handles every max_depth >= 1
 
 // ------------------------------------------------------------------------------------------------
 // candidate lists, NN seed, Lin-Kernighan
@@ -935,7 +941,7 @@ extern "C" int tl_build_candidates(tl_ctx *c, const float *xy, uint32_t n, uint3
     int rc;
     if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->misc, (size_t)n * k * 4))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, launch_knn((const float2 *)c->xy.p, n, k, (uint32_t *)c->misc.p, c->stream));
+    HIPCHK(c, launch_knn((const float2 *)c->xy.p, n, k, (uint32_t *)c->misc.p, c->stream, knn_form(c)));
     HIPCHK(c, hipMemcpyAsync(out, c->misc.p, (size_t)n * k * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return TL_OK;
@@ -961,40 +967,64 @@ static int nn_seed_dev(tl_ctx *c, const float2 *d_xy, uint32_t n, uint32_t n_nea
         // builder is the cheaper one and few steps fall back there)
         for (uint32_t kk = n < 8192u ? 4u : 7u; kk > k; --kk)
             if (kk <= n - 1u && (size_t)n + 16 + (size_t)n * kk * 2u + 16 <= cap) { kint = kk; break; }
-        if (const char *e = getenv("TL_NN_KINT")) kint = (uint32_t)atoi(e) > n - 1u ? n - 1u : (uint32_t)atoi(e);
         k = kint;
     }
     const size_t cand_b = ((size_t)n * (k ? k : 1) * 4 + 255) & ~(size_t)255;
     if ((rc = ensure(c, c->misc, cand_b))) return rc;
     uint32_t *d_cand = (uint32_t *)c->misc.p;
-    if (k) HIPCHK(c, launch_knn(d_xy, n, k, d_cand, c->stream));
+    if (k) HIPCHK(c, launch_knn(d_xy, n, k, d_cand, c->stream, knn_form(c)));
     HIPCHK(c, launch_nn_seed(d_xy, n, d_cand, k, d_path, c->lds_bytes, c->stream));
     return TL_OK;
 }
 
-extern "C" int tl_nearest_neighbor(tl_ctx *c, const float *xy, uint32_t n, uint32_t n_nearest, uint32_t *out_pos, float *out_cost)
+extern "C" int tl_nearest_neighbor(tl_ctx *c, const float *xy, const float *dm_packed, uint32_t n, uint32_t n_nearest,
+                                   uint32_t *out_pos, float *out_cost)
 {
-    if (!c || !xy || !out_pos) return fail(c, TL_ERR_BADARG, "tl_nearest_neighbor: NULL argument");
+    if (!c || (!xy && !dm_packed) || !out_pos) return fail(c, TL_ERR_BADARG, "tl_nearest_neighbor: NULL argument");
     if (n == 0) return fail(c, TL_ERR_REF_PANICS, "nearest_neighbor: cities[0] on an empty problem (nearest_neighbor.rs:28)");
+    if (n == 1) {  // the walk is [cities[0]]; tour_length of fewer than two cities is 0 (distance_matrix.rs:236-238)
+        out_pos[0] = 0;
+        if (out_cost) *out_cost = 0.0f;
+        return TL_OK;
+    }
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
-    if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->out_pos, (size_t)n * 4)) || (rc = ensure(c, c->out_cost, 4))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    if ((rc = nn_seed_dev(c, (const float2 *)c->xy.p, n, n_nearest, (uint32_t *)c->out_pos.p))) return rc;
+    if ((rc = ensure(c, c->out_pos, (size_t)n * 4)) || (rc = ensure(c, c->out_cost, 4))) return rc;
+    const float2 *dxy = nullptr;
+    const float *ddm = nullptr;
+    if (dm_packed) {
+        if ((size_t)n + 1024 > (size_t)c->lds_bytes)
+            return fail(c, TL_ERR_UNSUPPORTED, "nearest_neighbor: n=%u exceeds the LDS-resident visited flags (%d bytes of LDS)", n, c->lds_bytes);
+        const size_t b = (size_t)n * (n - 1) / 2 * 4;
+        if ((rc = ensure(c, c->dm, b))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->dm.p, dm_packed, b, hipMemcpyHostToDevice, c->stream));
+        ddm = (const float *)c->dm.p;
+        HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+        HIPCHK(c, launch_nn_seed_dm(ddm, n, (uint32_t *)c->out_pos.p, c->lds_bytes, c->stream));
+    } else {
+        if (!xy) return fail(c, TL_ERR_BADARG, "tl_nearest_neighbor: xy is NULL");
+        if ((rc = ensure(c, c->xy, (size_t)n * 8))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+        dxy = (const float2 *)c->xy.p;
+        HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+        if ((rc = nn_seed_dev(c, dxy, n, n_nearest, (uint32_t *)c->out_pos.p))) {
+            c->ev_valid = false;
+            return rc;
+        }
+    }
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->ev_valid = true;
     HIPCHK(c, hipMemcpyAsync(out_pos, c->out_pos.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     if (out_cost) {
-        HIPCHK(c, launch_tour_length((const float2 *)c->xy.p, nullptr, n, (const uint32_t *)c->out_pos.p, (float *)c->out_cost.p, c->stream));
+        HIPCHK(c, launch_tour_length(dxy, ddm, n, (const uint32_t *)c->out_pos.p, (float *)c->out_cost.p, c->stream));
         HIPCHK(c, hipMemcpyAsync(out_cost, c->out_cost.p, 4, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return TL_OK;
 }
 
-extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const uint32_t *init_pos, const tl_lk_opts *opts, uint64_t seed,
-                     uint32_t *out_pos, float *out_cost, tl_stats *stats)
+extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos, const tl_lk_opts *opts,
+                     uint64_t seed, uint32_t *out_pos, float *out_cost, tl_stats *stats)
 {
     if (!c || !xy || !out_pos) return fail(c, TL_ERR_BADARG, "tl_lk: NULL argument");
     if (n == 0) return fail(c, TL_ERR_BADARG, "tl_lk: n == 0");
@@ -1006,6 +1036,16 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const uint32_t *ini
     if (o.n_nearest > 16) return fail(c, TL_ERR_UNSUPPORTED, "tl_lk: n_nearest=%u > 16", o.n_nearest);
     if (init_pos && !is_permutation(init_pos, n)) return fail(c, TL_ERR_BADARG, "tl_lk: init tour is not a permutation of 0..n-1");
     const auto t0 = std::chrono::steady_clock::now();
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (n < 4) {
+        // lin_kernighan.rs:45-59: the initial tour (given, or the NN seed over problem.distances) is returned untouched
+        int rc;
+        if (init_pos) memcpy(out_pos, init_pos, (size_t)n * 4);
+        else if ((rc = tl_nearest_neighbor(c, xy, dm_packed, n, 3, out_pos, nullptr))) return rc;
+        if (out_cost && (rc = tl_tour_length(c, dm_packed ? nullptr : xy, dm_packed, n, out_pos, out_cost))) return rc;
+        if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return TL_OK;
+    }
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
     const uint32_t k = o.n_nearest > n - 1 ? n - 1 : o.n_nearest;
@@ -1014,31 +1054,43 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const uint32_t *ini
     const size_t o_cand = 0, o_tour = up((size_t)n * (k ? k : 1) * 4), o_alt = o_tour + arr, o_pos = o_alt + arr, o_next = o_pos + arr,
                  o_prev = o_next + arr, o_ids = o_prev + arr, o_best = o_ids + arr, o_cnt = o_best + arr, o_state = o_cnt + 256,
                  o_chains = o_state + 256;
-    // default: scans spread over all CUs (faster at every size measured, berlin52 included); TL_LK_MULTI_MIN_N raises the
-    // size below which the whole ILS runs in one persistent workgroup instead (kept as a cross-check of the state machine)
-    const bool multi_cu = n >= (getenv("TL_LK_MULTI_MIN_N") ? (uint32_t)atoi(getenv("TL_LK_MULTI_MIN_N")) : 0u);
+    // default: scans spread over all CUs; TL_FLAG_LK_ONE_WORKGROUP runs the whole ILS in one persistent workgroup instead
+    // (kept as a cross-check of the state machine)
+    const bool multi_cu = !(c->flags & TL_FLAG_LK_ONE_WORKGROUP);
     const size_t o_pairmin = o_chains + (multi_cu ? up((size_t)2 * n * lk_chain_slot_words() * 4) : 0);
-    const bool split_scan = multi_cu && max_depth_ge2_split(o.max_depth) && !getenv("TL_LK_NO_SPLIT");
+    const bool split_scan = multi_cu && max_depth_ge2_split(o.max_depth) && !(c->flags & TL_FLAG_LK_NO_SPLIT);
     // every successful sub-search keeps its chain (64 B) so that the pick step does not walk the winner again; sized for
     // 288 GB of HBM (45 MB at n = 13 509, k = 5), skipped beyond 4 GB
     // three split levels (k(k+1)^2 sub-searches per pair: the sequential part of a walk shrinks to k^2 nodes) while their
     // kept chains fit 4 GB, else two
-    const uint32_t levels = (split_scan && !getenv("TL_LK_SPLIT2") && (size_t)2 * n * k * (k + 1) * (k + 1) * 64 <= ((size_t)4 << 30)) ? 3u : 2u;
+    const uint32_t levels = (split_scan && !(c->flags & TL_FLAG_LK_SPLIT2) && (size_t)2 * n * k * (k + 1) * (k + 1) * 64 <= ((size_t)4 << 30)) ? 3u : 2u;
     const size_t sub_b = split_scan ? (size_t)2 * n * k * (k + 1) * (levels == 3u ? k + 1 : 1) * 64 : 0;
-    const bool keep_sub = split_scan && sub_b <= ((size_t)4 << 30) && !getenv("TL_LK_NO_SUBCHAINS");
+    const bool keep_sub = split_scan && sub_b <= ((size_t)4 << 30) && !(c->flags & TL_FLAG_LK_NO_SUBCHAINS);
     const size_t o_sub = o_pairmin + (split_scan ? up((size_t)2 * n * 4) : 0);
     const size_t total = o_sub + (keep_sub ? up(sub_b) : 0);
     if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->work, total)) || (rc = ensure(c, c->out_cost, 4))) return rc;
     unsigned char *w = (unsigned char *)c->work.p;
     HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    const float *ddm = nullptr;
+    if (dm_packed) {  // problem.distances of a GEO / EXPLICIT problem: the NN seed and the reported total read it
+        const size_t b = (size_t)n * (n - 1) / 2 * 4;
+        if ((rc = ensure(c, c->dm, b))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->dm.p, dm_packed, b, hipMemcpyHostToDevice, c->stream));
+        ddm = (const float *)c->dm.p;
+    }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    c->ev_valid = false;
     if (init_pos) {
         HIPCHK(c, hipMemcpyAsync(w + o_tour, init_pos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    } else if (ddm) {
+        if ((size_t)n + 1024 > (size_t)c->lds_bytes)
+            return fail(c, TL_ERR_UNSUPPORTED, "nearest_neighbor: n=%u exceeds the LDS-resident visited flags", n);
+        HIPCHK(c, launch_nn_seed_dm(ddm, n, (uint32_t *)(w + o_tour), c->lds_bytes, c->stream));
     } else {
         // lin_kernighan.rs:47-55: nearest_neighbor::solve with HeuristicOptions::default() (n_nearest = 3)
         if ((rc = nn_seed_dev(c, (const float2 *)c->xy.p, n, 3, (uint32_t *)(w + o_tour)))) return rc;
     }
-    if (k) HIPCHK(c, launch_knn((const float2 *)c->xy.p, n, k, (uint32_t *)(w + o_cand), c->stream));  // :43 build_candidates
+    if (k) HIPCHK(c, launch_knn((const float2 *)c->xy.p, n, k, (uint32_t *)(w + o_cand), c->stream, knn_form(c)));  // :43 build_candidates
     HIPCHK(c, hipMemsetAsync(w + o_cnt, 0, 64, c->stream));
     LkArgs G{};
     G.xy = (const float2 *)c->xy.p;
@@ -1081,8 +1133,8 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const uint32_t *ini
         cnt[2] = hs.moves;
         cnt[3] = hs.exchanged;
     }
-    // lin_kernighan.rs:99 Solution::new -> total through tour_length (closing edge first)
-    HIPCHK(c, launch_tour_length(G.xy, nullptr, n, G.best, (float *)c->out_cost.p, c->stream));
+    // lin_kernighan.rs:99 Solution::new -> total through problem.distances.tour_length (closing edge first)
+    HIPCHK(c, launch_tour_length(ddm ? nullptr : G.xy, ddm, n, G.best, (float *)c->out_cost.p, c->stream));
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->ev_valid = true;
     float cost = 0.f;
@@ -1092,7 +1144,6 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const uint32_t *ini
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (out_cost) *out_cost = cost;
     if (stats) {
-        memset(stats, 0, sizeof(*stats));
         stats->sweeps = cnt[0];
         stats->candidates = cnt[1];
         stats->moves = cnt[2];

@@ -6,7 +6,34 @@
 #define TL_TWO_OPT_NT 1024  // threads per descent workgroup (16 waves, 4 per SIMD)
 #endif
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 namespace tl {
+
+// MaxDynamicSharedMemorySize is an attribute of the FUNCTION (per device), not of a launch or a stream: setting it per launch
+// to the size of that launch lets two host threads solving different n race (set 110 KB, set 30 KB, launch with 110 KB ->
+// invalid configuration).  Every launcher therefore raises it ONCE per (kernel, device) to all the LDS the device has left
+// beside the kernel's static allocation, and passes its real size only as the launch parameter.
+inline hipError_t allow_max_lds(const void *kern)
+{
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> g(mu);
+    if (done.count({kern, dev})) return hipSuccess;
+    int maxlds = 0;
+    if ((e = hipDeviceGetAttribute(&maxlds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev)) != hipSuccess) return e;
+    hipFuncAttributes fa;
+    if ((e = hipFuncGetAttributes(&fa, kern)) != hipSuccess) return e;
+    const int dyn = maxlds - (int)fa.sharedSizeBytes;
+    if ((e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, dyn)) != hipSuccess) return e;
+    done.insert({kern, dev});
+    return hipSuccess;
+}
 
 // u64 words per descent in out_stats: sweeps, moves, reversed, status, steps, then profile words
 #define TL_STATS_STRIDE 16
@@ -145,8 +172,10 @@ struct LkArgs {
     uint32_t lds_budget;    // LDS bytes a scan workgroup may use for its xy/next copies
     uint32_t split_levels;  // split scan: 2 = k(k+1) sub-searches per pair, 3 = k(k+1)^2
 };
-hipError_t launch_knn(const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, hipStream_t s);
+// form: 0 = default (16 lanes per city up to n = 32 K, 4 beyond), 4 = four lanes per city, 1 = one lane per city
+hipError_t launch_knn(const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, hipStream_t s, int form = 0);
 hipError_t launch_nn_seed(const float2 *xy, uint32_t n, const uint32_t *cand, uint32_t k, uint32_t *path, int lds_bytes, hipStream_t s);
+hipError_t launch_nn_seed_dm(const float *dm, uint32_t n, uint32_t *path, int lds_bytes, hipStream_t s);
 hipError_t launch_lk_solve(const LkArgs &G, hipStream_t s);
 hipError_t launch_lk_begin(const LkArgs &G, hipStream_t s);
 hipError_t launch_lk_round(const LkArgs &G, hipStream_t s);

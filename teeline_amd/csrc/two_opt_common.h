@@ -66,12 +66,19 @@ __device__ __forceinline__ float box_lb(float px, float py, float4 box)
 static constexpr uint32_t kDenseLead = TL_DENSE_LEAD;  // waves active in round 1 of a dense step
 static constexpr uint32_t kMaxChainHits = 16;  // hits one wave may chain inside its tile before handing back
 
+// Work the cascade really does, counted per wave with wave-uniform (SALU) adds: candidates (lanes) that entered L1, that
+// survived L1 into L2, that needed the exact L3, and tile bounds evaluated by L0 (lanes = tiles).  bench.py reports them
+// as "candidates touched" next to the algorithmic candidate count.
+struct TileCounts {
+    uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+};
+
 // The improving columns of row (a, b) inside one 64-wide j tile (lane l holds c = P[tb+l], e = P[tb+l+1]) as a lane mask,
 // decided by the L1 -> L2 -> L3 cascade.  Straight-line code, every branch wave-uniform, the result in SGPRs.
 // sqab = sq(a, b) is a row constant the caller already holds.
 template <bool PRUNE>
 __device__ __forceinline__ uint64_t tile_mask_core(float2 c, float2 e, uint32_t j, uint32_t n, uint32_t jmin,
-                                                   float ax, float ay, float bx, float by, float sqab)
+                                                   float ax, float ay, float bx, float by, float sqab, TileCounts &tc)
 {
     const float sqce = sqdist(c, e);
     const float s1 = sqdist(make_float2(ax, ay), c);
@@ -79,8 +86,11 @@ __device__ __forceinline__ uint64_t tile_mask_core(float2 c, float2 e, uint32_t 
     bool test = (j - jmin) <= (n - 2u - jmin);  // jmin <= j <= n-2 in one unsigned compare (callers keep jmin <= n-2)
     bool imp;
     if (PRUNE) {
+        tc.l1 += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(test));
         test = test & ((s1 < sqab) | (s2 < sqce));                       // L1
-        if (!__builtin_amdgcn_ballot_w64(test)) return 0;                // the common case late in a sweep
+        const uint64_t m1 = __builtin_amdgcn_ballot_w64(test);
+        if (!m1) return 0;                                               // the common case late in a sweep
+        tc.l2 += (uint32_t)__builtin_popcountll(m1);
         const float neu_a = __builtin_amdgcn_sqrtf(s1) + __builtin_amdgcn_sqrtf(s2);  // L2
         const float cur_a = __builtin_amdgcn_sqrtf(sqab) + __builtin_amdgcn_sqrtf(sqce);
         const float margin = cur_a * 1.9073486e-6f;                      // 2^-19
@@ -91,7 +101,9 @@ __device__ __forceinline__ uint64_t tile_mask_core(float2 c, float2 e, uint32_t 
         const uint32_t smin = min(min(__builtin_bit_cast(uint32_t, s1), __builtin_bit_cast(uint32_t, sqce)),
                                   min(__builtin_bit_cast(uint32_t, s2), __builtin_bit_cast(uint32_t, sqab)));
         const bool tie = test & !imp & ((neu_a <= cur_a + margin) | (smin < 0x0DA24260u /* 1e-30f */) | !(cur_a < 3.0e38f));
-        if (__builtin_amdgcn_ballot_w64(tie)) {                          // L3
+        const uint64_t mt = __builtin_amdgcn_ballot_w64(tie);
+        if (mt) {                                                        // L3
+            tc.l3 += (uint32_t)__builtin_popcountll(mt);
             // the opaque copies keep the compiler from hoisting the loop-invariant exact roots into a tile or row
             // prologue, where every tile (row) would pay ~40 VALU for a path that almost never runs
             float s1v = s1, scev = sqce, sabv = sqab;
@@ -101,6 +113,7 @@ __device__ __forceinline__ uint64_t tile_mask_core(float2 c, float2 e, uint32_t 
             imp = tie ? (neu < cur) : imp;
         }
     } else {
+        tc.l3 += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(test));
         const float neu = sqrt_rn(s1) + sqrt_rn(s2);
         const float cur = sqrt_rn(sqab) + sqrt_rn(sqce);
         imp = test & (neu < cur);  // two_opt.rs:35-49
@@ -110,10 +123,11 @@ __device__ __forceinline__ uint64_t tile_mask_core(float2 c, float2 e, uint32_t 
 
 template <bool PRUNE>
 __device__ __forceinline__ uint64_t tile_improving_mask(const float2 *P, uint32_t n, uint32_t tb, uint32_t jmin,
-                                                        float ax, float ay, float bx, float by, float sqab, int lane)
+                                                        float ax, float ay, float bx, float by, float sqab, int lane,
+                                                        TileCounts &tc)
 {
     const uint32_t j = tb + (uint32_t)lane;
-    return tile_mask_core<PRUNE>(P[j], P[j + 1u], j, n, jmin, ax, ay, bx, by, sqab);
+    return tile_mask_core<PRUNE>(P[j], P[j + 1u], j, n, jmin, ax, ay, bx, by, sqab, tc);
 }
 
 template <bool PRUNE>
@@ -121,7 +135,8 @@ __device__ __forceinline__ bool tile_first_hit(const float2 *P, uint32_t n, uint
                                                float ax, float ay, float bx, float by, float sqab,
                                                uint32_t *keyslot, int lane)
 {
-    const uint64_t m = tile_improving_mask<PRUNE>(P, n, tb, jmin, ax, ay, bx, by, sqab, lane);
+    TileCounts tc;
+    const uint64_t m = tile_improving_mask<PRUNE>(P, n, tb, jmin, ax, ay, bx, by, sqab, lane, tc);
     if (m == 0) return false;
     if (lane == 0) atomicMin(keyslot, (i << 16) | (tb + (uint32_t)(__builtin_ffsll((long long)m) - 1)));
     return true;
@@ -135,11 +150,11 @@ __device__ __forceinline__ bool tile_first_hit(const float2 *P, uint32_t n, uint
 template <bool PRUNE>
 __device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint32_t i, uint32_t tb, uint32_t jmin,
                                                float ax, float ay, float bx, float by, float sqab,
-                                               uint32_t *hl, uint32_t *keyslot, int lane)
+                                               uint32_t *hl, uint32_t *keyslot, int lane, TileCounts &tc)
 {
     const uint32_t j = tb + (uint32_t)lane;
     const float2 c = P[j], e = P[j + 1u];
-    uint64_t m = tile_mask_core<PRUNE>(c, e, j, n, jmin, ax, ay, bx, by, sqab);
+    uint64_t m = tile_mask_core<PRUNE>(c, e, j, n, jmin, ax, ay, bx, by, sqab, tc);
     if (m == 0) return 0;  // the common case: no chain state was ever set up
     uint32_t from = jmin, nh = 0, hitv = 0;  // lane h of hitv holds the h-th hit column
     for (;;) {
@@ -154,7 +169,7 @@ __device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint
         by = readlane_f(c.y, l);
         const float dx = ax - bx, dy = ay - by;
         sqab = dx * dx + dy * dy;
-        m = tile_mask_core<PRUNE>(c, e, j, n, from, ax, ay, bx, by, sqab);
+        m = tile_mask_core<PRUNE>(c, e, j, n, from, ax, ay, bx, by, sqab, tc);
         if (m == 0) break;
     }
     if ((uint32_t)lane < nh) hl[2u + (uint32_t)lane] = hitv;

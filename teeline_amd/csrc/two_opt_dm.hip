@@ -285,7 +285,7 @@ hipError_t launch_two_opt_ref_dm(const TwoOptBatchArgs &A, uint32_t count, int l
     const bool stage = staged <= (size_t)lds_budget;
     const size_t lds = stage ? staged : base;
     auto kern = stage ? k_two_opt_ref_dm<true> : k_two_opt_ref_dm<false>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = allow_max_lds(reinterpret_cast<const void *>(kern));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(count), dim3(kDmNT), lds, s, A);
     return hipGetLastError();

@@ -56,6 +56,7 @@ constexpr int kMaxGroups = 4;         // 64-tile groups: n_pad <= 4 * 64 * 64 = 
 
 struct Ctl {
     uint32_t keys[4];
+    unsigned long long cnt[4];  // cascade work of the descent (TileCounts summed over the waves), 64-byte block in all
 };
 
 // Deferred reversals (dense mode).  The hits (i, g_0 < g_1 < ... < g_{k-1}) of ONE row all reverse a prefix that starts at
@@ -181,8 +182,24 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 
     // ---------------------------------------------------------------- initial tour
     if (A.init_mode == TL_INIT_ARRAY) {
+        // a device-resident initial tour has not been through the host's permutation check (tl_two_opt_batch_dev): an
+        // entry >= n would index xy out of bounds, so the descent is refused (status 2, cost NaN, tour untouched)
         const uint32_t *__restrict__ src = A.init + (size_t)d * n;
-        for (uint32_t k = tid; k < n; k += NT) perm[k] = (uint16_t)src[k];
+        int bad = 0;
+        for (uint32_t k = tid; k < n; k += NT) {
+            const uint32_t v = src[k];
+            bad |= v >= n;
+            perm[k] = (uint16_t)v;
+        }
+        if (__syncthreads_or(bad)) {
+            if (tid == 0) {
+                A.out_cost[d] = __builtin_nanf("");
+                uint64_t *st = A.out_stats + (size_t)d * TL_STATS_STRIDE;
+                for (int q = 0; q < TL_STATS_STRIDE; ++q) st[q] = 0;
+                st[3] = 2;
+            }
+            return;
+        }
     } else {
         for (uint32_t k = tid; k < n; k += NT) perm[k] = (uint16_t)k;  // two_opt.rs:18-20
     }
@@ -205,7 +222,10 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             }
         }
     }
-    if (tid < 4) ctl->keys[tid] = kNoKey;
+    if (tid < 4) {
+        ctl->keys[tid] = kNoKey;
+        ctl->cnt[tid] = 0ull;
+    }
     for (uint32_t k = tid; k < (uint32_t)kMaxGroups * 64u; k += NT) {
         const float inf = __builtin_inff();
         tbox[k] = make_float4(inf, inf, -inf, -inf);  // empty box: never live
@@ -241,6 +261,8 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #ifdef TL_PROFILE2
     uint64_t q2[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+    TileCounts tc;      // work really done by this wave's cascade (SALU counters)
+    const uint64_t clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
     uint32_t slot = 0;  // step % 3
     while (n >= 4) {
 #ifdef TL_PROFILE2
@@ -339,6 +361,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                         const uint32_t tl = ((uint32_t)gI << 6) + (uint32_t)lane;
                         const bool near_a = box_lb(ax, ay, box[gI]) < sqab, near_b = box_lb(bx, by, box[gI]) < msq[gI];
                         const bool live = (tl >= tmin) & (near_a | near_b);  // no short-circuit: both bounds are cheaper than a branch
+                        tc.l0 += 64u;
                         uint64_t m = __builtin_amdgcn_ballot_w64(live);
                         uint64_t hm = 0;
                         uint32_t t = 0;
@@ -348,7 +371,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #ifdef TL_PROFILE
                             ++livetiles;
 #endif
-                            hm = tile_improving_mask<PRUNE>(P, n, t << 6, jmin, ax, ay, bx, by, sqab, lane);
+                            hm = tile_improving_mask<PRUNE>(P, n, t << 6, jmin, ax, ay, bx, by, sqab, lane, tc);
                         }
                         if (hm) {
                             if (lane == 0) atomicMin(keyslot, (i << 16) | ((t << 6) + (uint32_t)(__builtin_ffsll((long long)hm) - 1)));
@@ -380,7 +403,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #ifdef TL_PROFILE
                 ++livetiles;
 #endif
-                dense_tile<PRUNE>(P, n, i, t << 6, j0, ax, ay, bx, by, sqab, queues + ((t & 15u) | hpar) * kQCap, keyslot, lane);
+                dense_tile<PRUNE>(P, n, i, t << 6, j0, ax, ay, bx, by, sqab, queues + ((t & 15u) | hpar) * kQCap, keyslot, lane, tc);
             }
             __syncthreads();
             if ((uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot) == kNoKey) {
@@ -390,7 +413,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #ifdef TL_PROFILE
                     ++livetiles;
 #endif
-                    if (dense_tile<PRUNE>(P, n, i, t << 6, j0, ax, ay, bx, by, sqab, queues + ((t & 15u) | hpar) * kQCap, keyslot, lane)) break;
+                    if (dense_tile<PRUNE>(P, n, i, t << 6, j0, ax, ay, bx, by, sqab, queues + ((t & 15u) | hpar) * kQCap, keyslot, lane, tc)) break;
                 }
             }
         }
@@ -520,6 +543,13 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 
     // Solution::from_parts -> tour_length_by_pos (distance_matrix.rs:235-245): sequential f32 sum,
     // closing edge first.  Edge lengths in parallel, the sum by one lane in tour order.
+    const uint64_t clk1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) {
+        atomicAdd(&ctl->cnt[0], (unsigned long long)tc.l0);
+        atomicAdd(&ctl->cnt[1], (unsigned long long)tc.l1);
+        atomicAdd(&ctl->cnt[2], (unsigned long long)tc.l2);
+        atomicAdd(&ctl->cnt[3], (unsigned long long)tc.l3);
+    }
     float total = 0.0f;
     if (n >= 2) total = dist(P[n - 1], P[0]);
     __syncthreads();
@@ -559,6 +589,16 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         st[2] = reversed;
         st[3] = status;
         st[4] = step;
+#if !defined(TL_PROFILE) && !defined(TL_PROFILE2)
+        // [5..8] cascade work: L0 tile bounds, candidates into L1, into L2, into L3; [9] shader clocks of the descent
+        // (s_memtime), [10] the same interval in constant 100 MHz ticks (s_memrealtime) -> the clock the CU really held
+        st[5] = ctl->cnt[0];
+        st[6] = ctl->cnt[1];
+        st[7] = ctl->cnt[2];
+        st[8] = ctl->cnt[3];
+        st[9] = clk1 - clk0;
+        st[10] = rt1 - rt0;
+#endif
 #ifdef TL_PROFILE2
         // [5..7] pruned hit steps: count, cycles, rows advanced; [8..10] pruned no-hit steps: count, cycles, rows;
         // [11..12] dense hit steps: count, cycles; [13..14] dense no-hit: count, cycles; [15] flush cycles
@@ -603,8 +643,7 @@ template <int NT, bool PRUNE>
 static hipError_t launch_one(const TwoOptBatchArgs &A, uint32_t count, size_t lds, hipStream_t s)
 {
     auto kern = k_two_opt_ref_lds<NT, PRUNE>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = allow_max_lds(reinterpret_cast<const void *>(kern));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(count), dim3(NT), lds, s, A);
     return hipGetLastError();

@@ -158,11 +158,16 @@ class TspProblem:
         return self._id2pos
 
     def positions_of(self, route_ids):
+        """City ids -> positions for a tour that crosses the C ABI as n u32 values: the length is checked HERE, before any
+        pointer is taken (a shorter tour would be read past its end by the library)."""
         m = self.id2pos()
         try:
-            return np.asarray([m[int(v)] for v in route_ids], dtype=np.uint32)
+            pos = np.asarray([m[int(v)] for v in route_ids], dtype=np.uint32)
         except KeyError as e:  # the reference: .expect("two_opt: invalid city pair") -> panic
             raise ReferencePanics(_capi.TL_ERR_REF_PANICS, f"invalid city id {e.args[0]} in init_tour") from None
+        if len(pos) != len(self.ids):
+            raise TeelineGpuError(_capi.TL_ERR_BADARG, f"tour has {len(pos)} cities, the problem {len(self.ids)}")
+        return pos
 
     def explicit_packed(self):
         """Packed matrix to hand to the kernels, or None when distances are plain EUC_2D (the kernels

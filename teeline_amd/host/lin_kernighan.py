@@ -16,7 +16,11 @@ def solve(problem, opts=None, progress_tx=None, init_tour=None, *, ctx=None, see
     out = np.empty(n, dtype=np.uint32)
     cost = C.c_float()
     st = _capi.TlStats()
+    # GEO / EXPLICIT problems: the search is Euclidean over the city coordinates (lin_kernighan.rs:41 rebuilds its own
+    # matrix), but the NN seed (:47-55) and the reported total (:99) go through problem.distances
+    packed = problem.explicit_packed()
     ctx.check(ctx.lib.tl_lk(ctx.handle, problem.xy.ctypes.data_as(C.c_void_p), n,
+                            None if packed is None else packed.ctypes.data_as(C.c_void_p),
                             None if init_pos is None else init_pos.ctypes.data_as(C.c_void_p), C.byref(o), int(seed),
                             out.ctypes.data_as(C.c_void_p), C.byref(cost), C.byref(st)))
     route = problem.ids[out]

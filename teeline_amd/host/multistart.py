@@ -16,6 +16,14 @@ def shard(rank, restarts_per_rank):
     return first, restarts_per_rank
 
 
+def shard_total(rank, world, total):
+    """Strong scaling (BASELINE configs[3]: "256 random restarts sharded 1/2/4/8 GPUs"): `total` restarts in all, rank k
+    owns the k-th contiguous block; the first total % world ranks take one restart more.  Returns (first, count)."""
+    base, extra = divmod(int(total), int(world))
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
 def pack_keys(costs, first):
     """costs: float32 tensor [R] (any device) of restarts first..first+R -> int64 keys [R]."""
     ids = torch.arange(first, first + costs.numel(), dtype=torch.int64, device=costs.device)

@@ -17,8 +17,6 @@ def solve(problem, opts=None, progress_tx=None, init_tour=None, *, ctx=None, mod
     ctx = ctx or default_context()
     n = len(problem)
     init_pos = problem.positions_of(init_tour) if init_tour is not None else None
-    if init_pos is not None and len(init_pos) != n:
-        raise _capi.TeelineGpuError(_capi.TL_ERR_BADARG, "init_tour length differs from the number of cities")
     if progress_tx is not None:
         start = [int(v) for v in (init_tour if init_tour is not None else problem.ids)]
         progress_tx("PathUpdate", (start, 0.0))
@@ -65,10 +63,7 @@ def solve_population(problem, init_tours, *, ctx=None):
     count = len(init_tours)
     init = np.empty((count, n), dtype=np.uint32)
     for k, tour in enumerate(init_tours):
-        pos = problem.positions_of(tour)
-        if len(pos) != n:
-            raise _capi.TeelineGpuError(_capi.TL_ERR_BADARG, f"tour {k}: length differs from the number of cities")
-        init[k] = pos
+        init[k] = problem.positions_of(tour)
     packed = problem.explicit_packed()
     out = np.empty((count, n), dtype=np.uint32)
     costs = np.empty(count, dtype=np.float32)

@@ -141,6 +141,8 @@ struct TspProblem {  // mod.rs:1731-1741
             if (it == idx.end()) throw ReferencePanic("two_opt: invalid city pair");  // two_opt.rs:37-47 .expect(...)
             out.push_back(it->second);
         }
+        // a tour crosses the C ABI as n u32 values: a shorter one would be read past its end by the library
+        if (out.size() != cities.size()) throw std::runtime_error("tour length differs from the number of cities");
         return out;
     }
 };
@@ -212,7 +214,6 @@ inline std::vector<Solution> solve_population(Context &ctx, const TspProblem &pr
     std::vector<uint32_t> init((size_t)count * n), out((size_t)count * n);
     for (uint32_t k = 0; k < count; ++k) {
         const auto pos = problem.positions_of(init_tours[k]);
-        if (pos.size() != n) throw std::runtime_error("solve_population: tour length differs from the number of cities");
         std::copy(pos.begin(), pos.end(), init.begin() + (size_t)k * n);
     }
     std::vector<float> costs(count);
@@ -261,12 +262,13 @@ namespace nearest_neighbor {  // nearest_neighbor.rs:8-76
 inline Solution solve(Context &ctx, const TspProblem &problem, const HeuristicOptions &opts, const ProgressFn *progress_tx,
                       const std::vector<size_t> * /*_init_tour*/)
 {
-    if (problem.explicit_packed()) throw std::runtime_error("nearest_neighbor on the GPU needs EUC_2D coordinates");
+    if (opts.n_nearest == 0) throw std::runtime_error("n_nearest must be >= 1");  // mod.rs:677-682
     const auto xy = problem.xy();
     const uint32_t n = (uint32_t)problem.cities.size();
     std::vector<uint32_t> out(n);
     float cost = 0.f;
-    ctx.check(tl_nearest_neighbor(ctx.get(), xy.data(), n, (uint32_t)opts.n_nearest, out.data(), &cost));
+    // GEO / EXPLICIT: the walk reads problem.distances (distance_matrix.rs:259-297)
+    ctx.check(tl_nearest_neighbor(ctx.get(), xy.data(), problem.explicit_packed(), n, (uint32_t)opts.n_nearest, out.data(), &cost));
     return detail::finish(problem, out, cost, tl_stats{}, progress_tx);
 }
 }  // namespace nearest_neighbor
@@ -284,7 +286,8 @@ inline Solution solve(Context &ctx, const TspProblem &problem, const LKOptions &
     tl_lk_opts o{(uint32_t)opts.heuristic.epochs, (uint32_t)opts.heuristic.platoo_epochs, (uint32_t)opts.heuristic.n_nearest, (uint32_t)opts.max_depth};
     float cost = 0.f;
     tl_stats st{};
-    ctx.check(tl_lk(ctx.get(), xy.data(), n, init_tour ? init.data() : nullptr, &o, seed, out.data(), &cost, &st));
+    // problem.distances (GEO / EXPLICIT) feeds the NN seed and the reported total only; the search is Euclidean (lin_kernighan.rs:41,47-55,99)
+    ctx.check(tl_lk(ctx.get(), xy.data(), n, problem.explicit_packed(), init_tour ? init.data() : nullptr, &o, seed, out.data(), &cost, &st));
     return detail::finish(problem, out, cost, st, progress_tx);
 }
 }  // namespace lin_kernighan

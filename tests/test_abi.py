@@ -33,7 +33,7 @@ def test_header_declares_what_the_binding_lists():
 def test_library_exports_every_declared_symbol(lib):
     for name in header_symbols():
         assert hasattr(lib, name), f"libteeline_gpu.so does not export {name}"
-    assert lib.tl_abi_version() == 1
+    assert lib.tl_abi_version() == 2
     assert b"gfx950" in lib.tl_version()
 
 

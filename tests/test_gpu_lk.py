@@ -37,17 +37,17 @@ def test_candidate_lists(ctx, k, tsplib_dir):
         assert got.shape == want.shape and np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("env", ["TL_KNN_GROUP4", "TL_KNN_NO_QUAD"])
-def test_candidate_list_builders_agree(ctx, env, monkeypatch):
-    # default: sixteen lanes per city; TL_KNN_GROUP4: the four-lane form used beyond n = 32 K; TL_KNN_NO_QUAD: one lane per
-    # city — all must give the oracle's lists (ascending f32 distance, ties -> lowest position), duplicates included
+@pytest.mark.parametrize("flag", ["TL_FLAG_KNN_4LANES", "TL_FLAG_KNN_1LANE"])
+def test_candidate_list_builders_agree(flag):
+    # default: sixteen lanes per city; TL_FLAG_KNN_4LANES: the four-lane form used beyond n = 32 K; TL_FLAG_KNN_1LANE: one
+    # lane per city — all must give the oracle's lists (ascending f32 distance, ties -> lowest position), duplicates included
     import teeline_amd as TA
-    monkeypatch.setenv(env, "1")
     dup = np.concatenate([lattice(7, 3), lattice(7, 3)[:20]]).astype(np.float32)
-    for xy in (O.synth_xy(777, seed=8), dup, O.synth_xy(5, seed=1)):
-        for k in (1, 4, 7, 16):
-            got = TA.lin_kernighan.build_candidates(prob(xy), k, ctx=ctx)
-            assert np.array_equal(got, O.build_candidates(xy, k))
+    with TA.Context(0, getattr(TA, flag)) as c2:
+        for xy in (O.synth_xy(777, seed=8), dup, O.synth_xy(5, seed=1)):
+            for k in (1, 4, 7, 16):
+                got = TA.lin_kernighan.build_candidates(prob(xy), k, ctx=c2)
+                assert np.array_equal(got, O.build_candidates(xy, k))
 
 
 def test_nearest_neighbor_seed(ctx, tsplib_dir):
@@ -140,8 +140,8 @@ def test_lk_wide_candidate_lists(ctx):
                     O.lin_kernighan(xy, seed=3, epochs=6, n_nearest=k, max_depth=depth))
 
 
-def test_lk_variants_are_identical(ctx, tsplib_dir, monkeypatch):
-    # default = scans spread over all CUs, each pair's chain search split into k*(k+1)^2 sub-searches (TL_LK_SPLIT2: k*(k+1)), device-side control
+def test_lk_variants_are_identical(tsplib_dir):
+    # default = scans spread over all CUs, each pair's chain search split into k*(k+1)^2 sub-searches (TL_FLAG_LK_SPLIT2: k*(k+1)), device-side control
     # state machine, kept sub-search chains.  The unsplit scan, the single persistent workgroup and the pick step that walks the
     # winning chain again must reproduce the same results (= the oracle's).
     xy = T.parse_tsplib(os.path.join(tsplib_dir, "berlin52.tsp"))["xy"]
@@ -149,18 +149,17 @@ def test_lk_variants_are_identical(ctx, tsplib_dir, monkeypatch):
     xy2 = O.synth_xy(200, seed=4)
     sq = np.array([[0, 0], [1, 1], [1, 0], [0, 1]], np.float32)
     tri = np.array([[0, 0], [1, 0], [0.5, 1]], np.float32)
-    for env in ({"TL_LK_NO_SPLIT": "1"}, {"TL_LK_MULTI_MIN_N": "1000000"}, {"TL_LK_NO_SUBCHAINS": "1"}, {"TL_LK_SPLIT2": "1"}):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        for seed in (1, 2):
-            assert_same(gpu_lk(ctx, xy, seed=seed), O.lin_kernighan(xy, seed=seed))
-        assert_same(gpu_lk(ctx, lat, seed=11, epochs=40), O.lin_kernighan(lat, seed=11, epochs=40))
-        assert_same(gpu_lk(ctx, sq, init=[0, 1, 2, 3], max_depth=1, epochs=0), O.lin_kernighan(sq, init=[0, 1, 2, 3], epochs=0, max_depth=1))
-        assert gpu_lk(ctx, tri, init=[2, 0, 1])[0].tolist() == [2, 0, 1]
-        for depth, k in ((1, 5), (2, 3), (6, 5)):
-            assert_same(gpu_lk(ctx, xy2, seed=1, epochs=20, max_depth=depth, n_nearest=k),
-                        O.lin_kernighan(xy2, seed=1, epochs=20, max_depth=depth, n_nearest=k))
-        for k in env:
-            monkeypatch.delenv(k)
+    import teeline_amd as TA
+    for flag in (TA.TL_FLAG_LK_NO_SPLIT, TA.TL_FLAG_LK_ONE_WORKGROUP, TA.TL_FLAG_LK_NO_SUBCHAINS, TA.TL_FLAG_LK_SPLIT2):
+        with TA.Context(0, flag) as ctx:
+            for seed in (1, 2):
+                assert_same(gpu_lk(ctx, xy, seed=seed), O.lin_kernighan(xy, seed=seed))
+            assert_same(gpu_lk(ctx, lat, seed=11, epochs=40), O.lin_kernighan(lat, seed=11, epochs=40))
+            assert_same(gpu_lk(ctx, sq, init=[0, 1, 2, 3], max_depth=1, epochs=0), O.lin_kernighan(sq, init=[0, 1, 2, 3], epochs=0, max_depth=1))
+            assert gpu_lk(ctx, tri, init=[2, 0, 1])[0].tolist() == [2, 0, 1]
+            for depth, k in ((1, 5), (2, 3), (6, 5)):
+                assert_same(gpu_lk(ctx, xy2, seed=1, epochs=20, max_depth=depth, n_nearest=k),
+                            O.lin_kernighan(xy2, seed=1, epochs=20, max_depth=depth, n_nearest=k))
     big = O.synth_xy(2000, seed=6)
-    assert_same(gpu_lk(ctx, big, seed=5, epochs=8), O.lin_kernighan(big, seed=5, epochs=8))
+    with TA.Context(0) as ctx:
+        assert_same(gpu_lk(ctx, big, seed=5, epochs=8), O.lin_kernighan(big, seed=5, epochs=8))

@@ -264,16 +264,17 @@ def test_lds_limit_random_start_matches_oracle(ctx):
     assert_same(gpu_two_opt(ctx, xy, None, n, rp), O.two_opt(xy, None, n, init=rp), n)
 
 
-def test_large_n_path_matches_oracle(ctx, monkeypatch):
-    # HBM-resident REF_ORDER path, forced on sizes the oracle finishes quickly: identical tours / costs / counters
-    monkeypatch.setenv("TL_FORCE_LARGE_2OPT", "1")
-    for n, seed in ((3, 1), (4, 1), (5, 2), (64, 3), (65, 4), (700, 5), (3000, 6)):
-        xy = O.synth_xy(n, seed=seed)
-        assert_same(gpu_two_opt(ctx, xy, None, n), O.two_opt(xy, None, n), n)
-        if n >= 64:
-            rp = O.restart_perm(n, 8, seed)
-            assert_same(gpu_two_opt(ctx, xy, None, n, rp), O.two_opt(xy, None, n, init=rp), n)
-    monkeypatch.delenv("TL_FORCE_LARGE_2OPT")
+def test_large_n_path_matches_oracle(ctx):
+    # HBM-resident REF_ORDER path, forced (TL_FLAG_2OPT_FORCE_HBM) on sizes the oracle finishes quickly: identical tours /
+    # costs / counters
+    import teeline_amd as TA
+    with TA.Context(0, TA.TL_FLAG_2OPT_FORCE_HBM) as c2:
+        for n, seed in ((3, 1), (4, 1), (5, 2), (64, 3), (65, 4), (700, 5), (3000, 6)):
+            xy = O.synth_xy(n, seed=seed)
+            assert_same(gpu_two_opt(c2, xy, None, n), O.two_opt(xy, None, n), n)
+            if n >= 64:
+                rp = O.restart_perm(n, 8, seed)
+                assert_same(gpu_two_opt(c2, xy, None, n, rp), O.two_opt(xy, None, n, init=rp), n)
     # n = 20 000 from the NN seed (oracle: ~2.4e9 candidates, too slow for the suite): size-independent checks
     n = 20000
     xy = O.synth_xy(n)
