@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-descent / no-prune / matrix-build extras")
+    ap.add_argument("--no-work-count", action="store_true",
+                    help="skip the one untimed launch of the counting kernel variant (PMC passes: only the timed kernel runs)")
     return ap.parse_args()
 
 
@@ -115,12 +117,15 @@ def valu_roofline(n, R, seed, first, info, k_ms, clock_hz, work, cand_per_launch
     if clock_hz > 0:
         r["peak"] = simds * clock_hz / VALU_CYCLES_PER_WAVE_INST / 1e9
     prof = latest_profile("r*_valu_roofline.json")
-    if prof and first == 0:
+    if prof and first == 0 and work["l1_candidates"]:
         try:
             pj = json.load(open(prof))
             r["source"] = os.path.relpath(prof, ROOT)
+            # same batch, same work: the speculative tiles a wave decides past the row's first hit depend on wave timing, so
+            # the counters (and SQ_INSTS_VALU) of two launches of the same batch differ by a few 0.1 %: 2 % tolerance
+            pw = pj.get("work", {})
             same = (pj.get("n") == n and pj.get("restarts") == R and pj.get("seed") == seed and
-                    all(int(pj.get("work", {}).get(k, -1)) == v for k, v in work.items()))
+                    all(abs(int(pw.get(k, -1)) - work[k]) <= 0.02 * max(work[k], 1) for k in ("l0_tile_bounds", "l1_candidates", "l2_candidates")))
             r["work_matches_profile"] = bool(same)
             if same and r["peak"]:
                 insts = float(pj["SQ_INSTS_VALU"])
@@ -225,10 +230,22 @@ def main():
     cands = int(sweeps_dev.item()) * per_sweep
     st_host = d_stats.cpu().numpy().astype(np.uint64)       # the last launch (every launch does the same work)
     cost_host = d_cost.cpu().numpy()
-    # work the cascade really did (in-kernel SALU counters, st[5..8]) and the clock the CUs held (st[9] shader clocks
-    # over st[10] ticks of the constant 100 MHz reference)
-    work = {"l0_tile_bounds": int(st_host[:, 5].sum()), "l1_candidates": int(st_host[:, 6].sum()),
-            "l2_candidates": int(st_host[:, 7].sum()), "l3_candidates": int(st_host[:, 8].sum())}
+    # The clock the CUs held: st[9] shader clocks over st[10] ticks of the constant 100 MHz reference, per descent.
+    # The work the cascade really did: one more launch of the same batch, UNTIMED, with the counting instantiation of the
+    # kernel (TL_FLAG_COUNT_WORK; the counters cost ~8 %, so the timed kernel does not carry them): st[5..8].
+    work = {"l0_tile_bounds": 0, "l1_candidates": 0, "l2_candidates": 0, "l3_candidates": 0}
+    if not a.no_work_count:
+        with TA.Context(local, TA.TL_FLAG_COUNT_WORK) as cc:
+            d_pos2, d_cost2, d_stats2 = torch.empty_like(d_pos), torch.empty_like(d_cost), torch.zeros_like(d_stats)
+            with torch.cuda.stream(stream):
+                cc.check(lib.tl_two_opt_batch_dev(cc.handle, d_xy.data_ptr(), n, None, a.seed, first, R, _capi.TL_MODE_REF_ORDER,
+                                                  d_pos2.data_ptr(), d_cost2.data_ptr(), d_stats2.data_ptr(),
+                                                  C.c_void_p(stream.cuda_stream)))
+            torch.cuda.synchronize()
+            assert torch.equal(d_pos2, d_pos) and torch.equal(d_cost2, d_cost), "the counting kernel variant gave other tours"
+            w = d_stats2.cpu().numpy().astype(np.uint64)
+            work = {"l0_tile_bounds": int(w[:, 5].sum()), "l1_candidates": int(w[:, 6].sum()),
+                    "l2_candidates": int(w[:, 7].sum()), "l3_candidates": int(w[:, 8].sum())}
     ticks = st_host[:, 10].astype(np.float64)
     clock_hz = float(np.mean(st_host[:, 9].astype(np.float64) / np.maximum(ticks, 1.0))) * REFCLK_HZ if ticks.min() > 0 else 0.0
 
@@ -271,7 +288,8 @@ def main():
         **work,
         "l1_candidates_per_s": work["l1_candidates"] / (k_ms * 1e-3),
         "fraction_of_algorithmic": work["l1_candidates"] / max(cand_per_launch, 1.0),
-        "note": "per launch, counted in the kernel: tile bounds evaluated by L0 (64 tiles per wave pass), candidates whose "
+        "note": "per launch, counted by the kernel's counting instantiation in one untimed launch of the same batch (same tours, "
+                "asserted): tile bounds evaluated by L0 (64 tiles per wave pass), candidates whose "
                 "squared-distance test L1 ran, candidates that went on to the v_sqrt_f32 test L2, and to the exact L3; "
                 "`value` counts candidates as the reference's loop visits them (SURVEY.md §8(d)), L0 decides most of "
                 "them a tile at a time",

@@ -79,6 +79,10 @@ typedef enum tl_mode {
 #define TL_FLAG_LK_NO_SUBCHAINS (1u << 5)  /* tl_lk: the pick step walks the winning chain again instead of reading it      */
 #define TL_FLAG_KNN_4LANES (1u << 6)       /* candidate lists: four lanes per city (the form used beyond n = 32 K)          */
 #define TL_FLAG_KNN_1LANE (1u << 7)        /* candidate lists: one lane per city                                            */
+/* The LDS-resident 2-opt kernel also counts the work its exact decision cascade really does (d_out_stats words 5..8: tile
+ * bounds, candidates into L1 / L2 / L3).  Same results; ~8 % slower (the kernel is SGPR-bound), so bench.py uses it for one
+ * untimed launch only. */
+#define TL_FLAG_COUNT_WORK (1u << 8)
 
 /* matrix layouts for tl_dm_build */
 #define TL_DM_PACKED_LOWER 0 /* reference layout, n(n-1)/2 floats (distance_matrix.rs:122-153) */

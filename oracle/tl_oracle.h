@@ -132,8 +132,10 @@ int tlo_lin_kernighan(const float *xy, uint32_t n, const uint32_t *init, uint32_
                       uint32_t platoo_epochs, uint32_t n_nearest, uint32_t max_depth,
                       uint64_t seed, uint32_t *out_perm, float *out_cost, tlo_stats *stats);
 
-/* the same with precomputed candidate lists (n x min(n_nearest, n-1) positions), e.g. tlo_build_candidates_kdtree's */
-int tlo_lin_kernighan_cand(const float *xy, uint32_t n, const uint32_t *init, uint32_t epochs,
+/* the same with precomputed candidate lists (n x min(n_nearest, n-1) positions), e.g. tlo_build_candidates_kdtree's, and
+ * with problem.distances of a GEO / EXPLICIT problem (packed, may be NULL): it feeds the NN seed (:47-55) and the reported
+ * total (:99) only — the search is Euclidean over xy (:41) */
+int tlo_lin_kernighan_cand(const float *xy, const float *packed, uint32_t n, const uint32_t *init, uint32_t epochs,
                            uint32_t platoo_epochs, uint32_t n_nearest, uint32_t max_depth, uint64_t seed,
                            const uint32_t *cand, uint32_t *out_perm, float *out_cost, tlo_stats *stats);
 /* lin_kernighan.rs:134-145 */

@@ -344,7 +344,7 @@ static inline uint64_t sm64(uint64_t *state)
 }
 
 /* lin_kernighan.rs:35-100; cand_in = precomputed candidate lists (n x min(n_nearest, n-1)) or NULL (brute force) */
-int tlo_lin_kernighan_cand(const float *xy, uint32_t n, const uint32_t *init, uint32_t epochs,
+int tlo_lin_kernighan_cand(const float *xy, const float *packed, uint32_t n, const uint32_t *init, uint32_t epochs,
                            uint32_t platoo_epochs, uint32_t n_nearest, uint32_t max_depth, uint64_t seed,
                            const uint32_t *cand_in, uint32_t *out, float *out_cost, tlo_stats *st)
 {
@@ -359,7 +359,8 @@ int tlo_lin_kernighan_cand(const float *xy, uint32_t n, const uint32_t *init, ui
     else tlo_build_candidates(xy, n, k, cand); /* :43 */
 
     if (init) memcpy(out, init, (size_t)n * sizeof(uint32_t)); /* :45-46 */
-    else tlo_nearest_neighbor(xy, NULL, n, 3, out, NULL);      /* :47-55 default n_nearest = 3 */
+    else tlo_nearest_neighbor(packed ? NULL : xy, packed, n, 3, out, NULL); /* :47-55 nearest_neighbor::solve(problem):
+                                                                                 problem.distances, default n_nearest = 3 */
 
     if (n >= 4) { /* :57-59 */
         tlo_lk_pass(xy, n, out, cand, k, max_depth, st); /* :61-68 */
@@ -384,8 +385,9 @@ int tlo_lin_kernighan_cand(const float *xy, uint32_t n, const uint32_t *init, ui
     }
     free(cand);
     free(candidate);
-    /* :99 Solution::new -> total through problem.distances.tour_length */
-    if (out_cost) *out_cost = tlo_tour_length(xy, NULL, n, out);
+    /* :99 Solution::new -> total through problem.distances.tour_length (the search above used the Euclidean matrix
+     * rebuilt from the coordinates, :41) */
+    if (out_cost) *out_cost = tlo_tour_length(packed ? NULL : xy, packed, n, out);
     return TLO_OK;
 }
 
@@ -393,5 +395,5 @@ int tlo_lin_kernighan(const float *xy, uint32_t n, const uint32_t *init, uint32_
                       uint32_t platoo_epochs, uint32_t n_nearest, uint32_t max_depth, uint64_t seed,
                       uint32_t *out, float *out_cost, tlo_stats *st)
 {
-    return tlo_lin_kernighan_cand(xy, n, init, epochs, platoo_epochs, n_nearest, max_depth, seed, NULL, out, out_cost, st);
+    return tlo_lin_kernighan_cand(xy, NULL, n, init, epochs, platoo_epochs, n_nearest, max_depth, seed, NULL, out, out_cost, st);
 }

@@ -72,13 +72,20 @@ static constexpr uint32_t kMaxChainHits = 16;  // hits one wave may chain inside
 struct TileCounts {
     uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;
 };
+// The timed kernels carry NoCounts: the four live SGPR counters cost the LDS descent kernel 8 % (it is SGPR-bound: 22 -> 44
+// spilled SGPRs), so counting is a separate instantiation that bench.py launches once, untimed (TL_FLAG_COUNT_WORK).
+struct NoCounts {
+    struct Sink {
+        __device__ __forceinline__ void operator+=(uint32_t) {}
+    } l0, l1, l2, l3;
+};
 
 // The improving columns of row (a, b) inside one 64-wide j tile (lane l holds c = P[tb+l], e = P[tb+l+1]) as a lane mask,
 // decided by the L1 -> L2 -> L3 cascade.  Straight-line code, every branch wave-uniform, the result in SGPRs.
 // sqab = sq(a, b) is a row constant the caller already holds.
-template <bool PRUNE>
+template <bool PRUNE, typename TC>
 __device__ __forceinline__ uint64_t tile_mask_core(float2 c, float2 e, uint32_t j, uint32_t n, uint32_t jmin,
-                                                   float ax, float ay, float bx, float by, float sqab, TileCounts &tc)
+                                                   float ax, float ay, float bx, float by, float sqab, TC &tc)
 {
     const float sqce = sqdist(c, e);
     const float s1 = sqdist(make_float2(ax, ay), c);
@@ -121,10 +128,10 @@ __device__ __forceinline__ uint64_t tile_mask_core(float2 c, float2 e, uint32_t 
     return __builtin_amdgcn_ballot_w64(imp);
 }
 
-template <bool PRUNE>
+template <bool PRUNE, typename TC>
 __device__ __forceinline__ uint64_t tile_improving_mask(const float2 *P, uint32_t n, uint32_t tb, uint32_t jmin,
                                                         float ax, float ay, float bx, float by, float sqab, int lane,
-                                                        TileCounts &tc)
+                                                        TC &tc)
 {
     const uint32_t j = tb + (uint32_t)lane;
     return tile_mask_core<PRUNE>(P[j], P[j + 1u], j, n, jmin, ax, ay, bx, by, sqab, tc);
@@ -135,7 +142,7 @@ __device__ __forceinline__ bool tile_first_hit(const float2 *P, uint32_t n, uint
                                                float ax, float ay, float bx, float by, float sqab,
                                                uint32_t *keyslot, int lane)
 {
-    TileCounts tc;
+    NoCounts tc;
     const uint64_t m = tile_improving_mask<PRUNE>(P, n, tb, jmin, ax, ay, bx, by, sqab, lane, tc);
     if (m == 0) return false;
     if (lane == 0) atomicMin(keyslot, (i << 16) | (tb + (uint32_t)(__builtin_ffsll((long long)m) - 1)));
@@ -147,10 +154,10 @@ __device__ __forceinline__ bool tile_first_hit(const float2 *P, uint32_t n, uint
 // are untouched, hence the lanes > l are simply decided again against the new b.  Hits are recorded in `hl`
 // (hl[0] = count, hl[1] = column at which the scan resumes, hl[2..] = hit columns); the first one is posted to the key
 // slot.  Only the list of the wave that owns the globally first hit is used afterwards.  Returns the number of hits.
-template <bool PRUNE>
+template <bool PRUNE, typename TC>
 __device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint32_t i, uint32_t tb, uint32_t jmin,
                                                float ax, float ay, float bx, float by, float sqab,
-                                               uint32_t *hl, uint32_t *keyslot, int lane, TileCounts &tc)
+                                               uint32_t *hl, uint32_t *keyslot, int lane, TC &tc)
 {
     const uint32_t j = tb + (uint32_t)lane;
     const float2 c = P[j], e = P[j + 1u];

@@ -27,6 +27,8 @@
 #include "tl_kernels.h"
 #include "two_opt_common.h"
 
+#include <type_traits>
+
 #pragma clang fp contract(off)
 
 namespace tl {
@@ -54,10 +56,14 @@ constexpr int kMaxGroups = 4;         // 64-tile groups: n_pad <= 4 * 64 * 64 = 
 #define TL_STAMP(var) do { } while (0)
 #endif
 
-struct Ctl {
+struct Ctl {                     // kCtlBytes of LDS
     uint32_t keys[4];
-    unsigned long long cnt[4];  // cascade work of the descent (TileCounts summed over the waves), 64-byte block in all
+    unsigned long long cnt[4];  // cascade work of the descent (TileCounts summed over the waves; counting instantiation)
+    unsigned long long clk0, rt0;  // s_memtime / s_memrealtime at the start of the descent (kept here, not in SGPRs)
+    uint32_t bad_init;
 };
+constexpr size_t kCtlBytes = 128;
+static_assert(sizeof(Ctl) <= kCtlBytes, "Ctl block");
 
 // Deferred reversals (dense mode).  The hits (i, g_0 < g_1 < ... < g_{k-1}) of ONE row all reverse a prefix that starts at
 // lo = i+1 (two_opt.rs:50 swap_2opt(path, i+1, j)), and the rest of that row's scan reads only positions > g and
@@ -155,7 +161,7 @@ __device__ __forceinline__ uint32_t flush_deferred(float2 *P, uint16_t *perm, ui
 
 }  // namespace
 
-template <int NT, bool PRUNE>
+template <int NT, bool PRUNE, bool COUNT>
 __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     Ctl *ctl = reinterpret_cast<Ctl *>(tailp + kMaxGroups * 64 * 20);
     // chained-hit lists (kQCap words per (tile index mod 16, step parity)) during the descent; reused as NT floats for the
     // cost sum
-    uint32_t *queues = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(ctl) + 64);
+    uint32_t *queues = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(ctl) + kCtlBytes);
     float *scratch = reinterpret_cast<float *>(queues);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -185,13 +191,17 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         // a device-resident initial tour has not been through the host's permutation check (tl_two_opt_batch_dev): an
         // entry >= n would index xy out of bounds, so the descent is refused (status 2, cost NaN, tour untouched)
         const uint32_t *__restrict__ src = A.init + (size_t)d * n;
-        int bad = 0;
+        if (tid == 0) ctl->bad_init = 0u;
+        __syncthreads();
+        bool bad = false;
         for (uint32_t k = tid; k < n; k += NT) {
             const uint32_t v = src[k];
             bad |= v >= n;
             perm[k] = (uint16_t)v;
         }
-        if (__syncthreads_or(bad)) {
+        if (bad) ctl->bad_init = 1u;
+        __syncthreads();
+        if (ctl->bad_init) {
             if (tid == 0) {
                 A.out_cost[d] = __builtin_nanf("");
                 uint64_t *st = A.out_stats + (size_t)d * TL_STATS_STRIDE;
@@ -225,6 +235,10 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     if (tid < 4) {
         ctl->keys[tid] = kNoKey;
         ctl->cnt[tid] = 0ull;
+    }
+    if (tid == 0) {
+        ctl->clk0 = __builtin_amdgcn_s_memtime();
+        ctl->rt0 = __builtin_amdgcn_s_memrealtime();
     }
     for (uint32_t k = tid; k < (uint32_t)kMaxGroups * 64u; k += NT) {
         const float inf = __builtin_inff();
@@ -261,8 +275,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #ifdef TL_PROFILE2
     uint64_t q2[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    TileCounts tc;      // work really done by this wave's cascade (SALU counters)
-    const uint64_t clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+    typename std::conditional<COUNT, TileCounts, NoCounts>::type tc;  // work really done by this wave's cascade (SALU counters)
     uint32_t slot = 0;  // step % 3
     while (n >= 4) {
 #ifdef TL_PROFILE2
@@ -543,12 +556,13 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 
     // Solution::from_parts -> tour_length_by_pos (distance_matrix.rs:235-245): sequential f32 sum,
     // closing edge first.  Edge lengths in parallel, the sum by one lane in tour order.
-    const uint64_t clk1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
-    if (lane == 0) {
-        atomicAdd(&ctl->cnt[0], (unsigned long long)tc.l0);
-        atomicAdd(&ctl->cnt[1], (unsigned long long)tc.l1);
-        atomicAdd(&ctl->cnt[2], (unsigned long long)tc.l2);
-        atomicAdd(&ctl->cnt[3], (unsigned long long)tc.l3);
+    if constexpr (COUNT) {
+        if (lane == 0) {
+            atomicAdd(&ctl->cnt[0], (unsigned long long)tc.l0);
+            atomicAdd(&ctl->cnt[1], (unsigned long long)tc.l1);
+            atomicAdd(&ctl->cnt[2], (unsigned long long)tc.l2);
+            atomicAdd(&ctl->cnt[3], (unsigned long long)tc.l3);
+        }
     }
     float total = 0.0f;
     if (n >= 2) total = dist(P[n - 1], P[0]);
@@ -590,14 +604,15 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         st[3] = status;
         st[4] = step;
 #if !defined(TL_PROFILE) && !defined(TL_PROFILE2)
-        // [5..8] cascade work: L0 tile bounds, candidates into L1, into L2, into L3; [9] shader clocks of the descent
+        // [5..8] cascade work (counting instantiation only, else 0): L0 tile bounds, candidates into L1, into L2, into L3;
+        // [9] shader clocks of the descent
         // (s_memtime), [10] the same interval in constant 100 MHz ticks (s_memrealtime) -> the clock the CU really held
         st[5] = ctl->cnt[0];
         st[6] = ctl->cnt[1];
         st[7] = ctl->cnt[2];
         st[8] = ctl->cnt[3];
-        st[9] = clk1 - clk0;
-        st[10] = rt1 - rt0;
+        st[9] = __builtin_amdgcn_s_memtime() - ctl->clk0;
+        st[10] = __builtin_amdgcn_s_memrealtime() - ctl->rt0;
 #endif
 #ifdef TL_PROFILE2
         // [5..7] pruned hit steps: count, cycles, rows advanced; [8..10] pruned no-hit steps: count, cycles, rows;
@@ -632,31 +647,32 @@ size_t two_opt_ref_lds_bytes(uint32_t n, uint32_t *n_pad_out, int nt)
     const uint32_t n_pad = ((n + 64u + 63u) / 64u) * 64u;  // P[j+1] of any lane of the last tile is in range
     if (n_pad_out) *n_pad_out = n_pad;
     if (n_pad > (uint32_t)kMaxGroups * 64u * 64u) return ~(size_t)0;  // beyond the tile-table capacity
-    const size_t meta = (size_t)kMaxGroups * 64 * 20 + 64;
+    const size_t meta = (size_t)kMaxGroups * 64 * 20 + kCtlBytes;
     const size_t lists = (size_t)32 * kQCap * 4;  // chained-hit lists, also the nt floats of cost-sum scratch
     static_assert(32 * kQCap * 4 >= TL_TWO_OPT_NT * 4, "the hit lists double as the cost-sum scratch");
     (void)nt;
     return (size_t)n_pad * 10 + meta + lists;
 }
 
-template <int NT, bool PRUNE>
+template <int NT, bool PRUNE, bool COUNT>
 static hipError_t launch_one(const TwoOptBatchArgs &A, uint32_t count, size_t lds, hipStream_t s)
 {
-    auto kern = k_two_opt_ref_lds<NT, PRUNE>;
+    auto kern = k_two_opt_ref_lds<NT, PRUNE, COUNT>;
     hipError_t e = allow_max_lds(reinterpret_cast<const void *>(kern));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(count), dim3(NT), lds, s, A);
     return hipGetLastError();
 }
 
-hipError_t launch_two_opt_ref_lds(const TwoOptBatchArgs &A, uint32_t count, bool prune, hipStream_t s)
+hipError_t launch_two_opt_ref_lds(const TwoOptBatchArgs &A, uint32_t count, bool prune, hipStream_t s, bool count_work)
 {
     constexpr int NT = TL_TWO_OPT_NT;
     uint32_t n_pad = 0;
     const size_t lds = two_opt_ref_lds_bytes(A.n, &n_pad, NT);
     TwoOptBatchArgs B = A;
     B.n_pad = n_pad;
-    return prune ? launch_one<NT, true>(B, count, lds, s) : launch_one<NT, false>(B, count, lds, s);
+    if (count_work) return prune ? launch_one<NT, true, true>(B, count, lds, s) : launch_one<NT, false, true>(B, count, lds, s);
+    return prune ? launch_one<NT, true, false>(B, count, lds, s) : launch_one<NT, false, false>(B, count, lds, s);
 }
 
 }  // namespace tl

@@ -31,6 +31,9 @@ def find_best_move(problem, path_pos, *, ctx=None):
     ctx = ctx or default_context()
     n = len(problem)
     path = np.ascontiguousarray(path_pos, dtype=np.uint32)
+    if len(path) != n:  # the library reads n u32 values: checked before the pointer is taken
+        from .. import _capi
+        raise _capi.TeelineGpuError(_capi.TL_ERR_BADARG, f"path has {len(path)} positions, the problem {n} cities")
     packed = problem.explicit_packed()
     found, kase = C.c_int(), C.c_int()
     i, j, k = C.c_uint32(), C.c_uint32(), C.c_uint32()

@@ -228,7 +228,7 @@ def double_bridge(tour, r1, r2, r3):
     return out
 
 
-def lin_kernighan(xy, init=None, epochs=100, platoo_epochs=10, n_nearest=5, max_depth=5, seed=1, cand=None):
+def lin_kernighan(xy, init=None, epochs=100, platoo_epochs=10, n_nearest=5, max_depth=5, seed=1, cand=None, packed=None):
     """cand: precomputed candidate lists (n x min(n_nearest, n-1)), e.g. build_candidates_kdtree's; None = brute force."""
     xy = _xy(xy)
     n = xy.shape[0]
@@ -239,7 +239,7 @@ def lin_kernighan(xy, init=None, epochs=100, platoo_epochs=10, n_nearest=5, max_
     if cand is not None:
         cand = np.ascontiguousarray(cand, dtype=np.uint32)
         assert cand.shape == (n, min(n_nearest, n - 1))
-    rc = lib().tlo_lin_kernighan_cand(_p(xy), C.c_uint32(n), _p(init), C.c_uint32(epochs),
+    rc = lib().tlo_lin_kernighan_cand(_p(xy), _p(packed), C.c_uint32(n), _p(init), C.c_uint32(epochs),
                                       C.c_uint32(platoo_epochs), C.c_uint32(n_nearest), C.c_uint32(max_depth),
                                       C.c_uint64(seed), _p(cand), _p(out), C.byref(cost), C.byref(st))
     return rc, out, np.float32(cost.value), st.as_dict()

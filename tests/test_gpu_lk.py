@@ -163,3 +163,54 @@ def test_lk_variants_are_identical(tsplib_dir):
     big = O.synth_xy(2000, seed=6)
     with TA.Context(0) as ctx:
         assert_same(gpu_lk(ctx, big, seed=5, epochs=8), O.lin_kernighan(big, seed=5, epochs=8))
+
+
+@pytest.mark.parametrize("name", ["gr17", "bays29", "ring6_explicit", "burma14"])
+def test_nn_seed_and_lk_on_explicit_and_geo_problems(ctx, name, tsplib_dir):
+    """GEO / EXPLICIT: nearest_neighbor::solve walks problem.distances (nearest_neighbor.rs:44-63 over
+    distance_matrix.rs:259-297); lin_kernighan::solve searches over the Euclidean matrix rebuilt from the city coordinates
+    (:41) but seeds with that NN walk (:47-55) and reports problem.distances.tour_length (:99)."""
+    import teeline_amd as TA
+    e = T.parse_tsplib(os.path.join(tsplib_dir, f"{name}.tsp"))
+    xy, n = e["xy"], e["n"]
+    packed = e["packed"] if e["packed"] is not None else O.dm_build_packed(xy, geo=True)
+    kind = "explicit" if e["packed"] is not None else "geo"
+    p = TA.TspProblem(e["ids"], xy, TA.distance_matrix.DistanceMatrix(n, packed, e["ids"], kind))
+    for k in (1, 3, 5):
+        sol = TA.nearest_neighbor.solve(p, TA.HeuristicOptions(n_nearest=k), ctx=ctx)
+        rc, route, c = O.nearest_neighbor(None, packed, n, k)
+        assert list(sol.route()) == e["ids"][route].tolist() and np.float32(sol.total).tobytes() == np.float32(c).tobytes()
+    for init in (None, list(e["ids"][::-1])):
+        h = TA.HeuristicOptions(epochs=20, platoo_epochs=10, n_nearest=5)
+        sol = TA.lin_kernighan.solve(p, TA.LKOptions(h, 5), None, init, ctx=ctx, seed=3)
+        oinit = None if init is None else np.arange(n - 1, -1, -1, dtype=np.uint32)
+        rc, route, c, st = O.lin_kernighan(xy, init=oinit, epochs=20, seed=3, packed=packed)
+        assert list(sol.route()) == e["ids"][route].tolist()
+        assert np.float32(sol.total).tobytes() == np.float32(c).tobytes()
+        assert np.float32(sol.total) == O.tour_length(None, packed, route)   # the total is problem.distances', not Euclid
+
+
+def test_lk_tiny_problems_return_the_initial_tour(ctx):
+    # lin_kernighan.rs:57-59: fewer than 4 cities -> Solution::new(&best_tour) without a pass; n = 1 used to reach the GPU
+    # with an empty candidate list
+    for n in (1, 2, 3):
+        xy = O.synth_xy(n, seed=n)
+        g = gpu_lk(ctx, xy)
+        rc, route, c, st = O.lin_kernighan(xy)
+        assert g[0].tolist() == route.tolist() and np.float32(g[1]).tobytes() == np.float32(c).tobytes()
+        assert g[2]["moves"] == 0
+    g = gpu_lk(ctx, O.synth_xy(3, seed=9), init=[2, 0, 1])
+    assert g[0].tolist() == [2, 0, 1]
+
+
+def test_short_init_tours_are_rejected_on_the_host(ctx):
+    # a tour crosses the C ABI as n u32 values: a shorter list must never reach the library
+    import teeline_amd as TA
+    xy = O.synth_xy(50, seed=2)
+    p = prob(xy)
+    short = list(range(40))
+    for fn in (lambda: TA.two_opt.solve(p, None, None, short, ctx=ctx), lambda: TA.three_opt.solve(p, None, None, short, ctx=ctx),
+               lambda: TA.or_opt.solve(p, None, None, short, ctx=ctx), lambda: TA.lin_kernighan.solve(p, None, None, short, ctx=ctx),
+               lambda: TA.three_opt.find_best_move(p, short, ctx=ctx), lambda: TA.or_opt.find_best_move(p, short, ctx=ctx)):
+        with pytest.raises(TA.TeelineGpuError):
+            fn()
