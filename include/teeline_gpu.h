@@ -136,6 +136,11 @@ int tl_selftest_sqrt(tl_ctx *ctx, uint32_t first_bits, uint64_t count, uint64_t 
 int tl_dm_build(tl_ctx *ctx, const float *xy, uint32_t n, int dist, int layout, float *out_host,
                 double *kernel_ms);
 
+/* Does dm_packed hold exactly (bit for bit) the EUC_2D distances of xy?  The reference's DistanceMatrix does not keep its
+ * DistanceType (distance_matrix.rs:86-93); a shim that only has `problem.distances.distances()` asks here once and then
+ * passes dm_packed = NULL (coordinate kernels, same results) when *is_euc2d comes back 1.  Costs one upload of the matrix. */
+int tl_dm_is_euc2d(tl_ctx *ctx, const float *xy, const float *dm_packed, uint32_t n, int *is_euc2d);
+
 /* ---- tour cost: replaces DistanceMatrix::tour_length_by_pos (distance_matrix.rs:235-245) ---- */
 /* total = d(last,first), then += d(w0,w1) in tour order (sequential f32, bit-exact). */
 int tl_tour_length(tl_ctx *ctx, const float *xy, const float *dm_packed, uint32_t n,
@@ -198,6 +203,14 @@ int tl_nearest_neighbor(tl_ctx *ctx, const float *xy, const float *dm_packed, ui
 int tl_two_opt_multistart(tl_ctx *ctx, const float *xy, uint32_t n, uint64_t seed, uint32_t first,
                           uint32_t count, int mode, uint32_t *out_best_pos, float *out_best_cost,
                           uint32_t *out_best_restart, float *out_costs, tl_stats *stats);
+/* The same job over several devices of one node from ONE process (the reference is single-process; SURVEY.md §8(b)
+ * proposed tl_multistart_two_opt(..., n_gpus, ...)): ctxs holds one context per device, each from tl_create(device, ...).
+ * Restarts [first, first+count) are dealt in contiguous blocks (the first count % n_ctxs contexts take one more), all
+ * shards run concurrently, the winner is the minimum packed key over the shards — results do not depend on n_ctxs.
+ * Errors are reported on ctxs[0].  stats->kernel_ms is the slowest shard's device time. */
+int tl_two_opt_multistart_devices(tl_ctx *const *ctxs, int n_ctxs, const float *xy, uint32_t n, uint64_t seed,
+                                  uint32_t first, uint32_t count, int mode, uint32_t *out_best_pos, float *out_best_cost,
+                                  uint32_t *out_best_restart, float *out_costs, tl_stats *stats);
 /* (float_bits(cost) << 32) | restart: order-preserving for cost >= 0, ties -> lowest restart. */
 uint64_t tl_pack_cost_key(float cost, uint32_t restart);
 /* A population of `count` explicit tours (init_pos: count x n positions), each refined by its own

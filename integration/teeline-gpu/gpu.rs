@@ -1,0 +1,206 @@
+//! GPU (MI355X / gfx950) implementations of the local-search solvers, behind the crate feature `gpu`.
+//!
+//! Each `solve` below has exactly the signature of the function it replaces and is selected by the same `match` in
+//! `solve_with_context` (src/tsp/mod.rs) when the feature is on:
+//!   `gpu::two_opt::solve`        <- `two_opt::solve`        (two_opt.rs:7-12)
+//!   `gpu::three_opt::solve`      <- `three_opt::solve`      (three_opt.rs:16-21)
+//!   `gpu::lin_kernighan::solve`  <- `lin_kernighan::solve`  (lin_kernighan.rs:35-40)
+//!   `gpu::or_opt::solve`, `gpu::nearest_neighbor::solve` likewise.
+//! The work is done by libteeline_gpu.so through the `teeline-gpu` crate; this file only translates
+//! ids <-> positions ONCE per call (the CPU path does it with two HashMap lookups inside every distance call,
+//! distance_matrix.rs:197-212) and builds the `Solution` with the crate's own `Solution::new`, so the printed total is
+//! computed by `DistanceMatrix::tour_length` itself.
+//!
+//! Behaviour that differs from the CPU functions, all of it documented in INTEGRATION.md:
+//!   * progress: `PathUpdate` at the start, one `PathUpdate` with the final tour, `Done` (2-opt/3-opt/or-opt), instead
+//!     of one message per outer index / move — only the Qt front-end passes a sender;
+//!   * a library error (no gfx950 device, HIP failure) panics with the library's message, like the `.expect(..)`s of the CPU
+//!     code do on bad input: the solver functions are infallible by signature;
+//!   * Lin-Kernighan kicks: the seed of the device-side splitmix64 stream is drawn from `rand::rng()` per call (the CPU
+//!     code draws every kick from it), or taken from `TEELINE_GPU_LK_SEED` for reproducible runs.
+
+use std::sync::mpsc;
+
+use teeline_gpu as ffi;
+
+use super::progress::ProgressMessage;
+use super::route::Route;
+use super::{HeuristicOptions, LKOptions, Solution, TspProblem};
+
+/// City coordinates in matrix-position order plus the matrix the kernels should read (None = EUC_2D on the fly).
+struct Boundary<'a> {
+    problem: &'a TspProblem,
+    xy: Vec<f32>,
+}
+
+impl<'a> Boundary<'a> {
+    fn new(problem: &'a TspProblem) -> Self {
+        // `problem.cities` is the slice the matrix was built from (tsplib.rs:84-98), so index == matrix position;
+        // checked here because everything below relies on it.
+        let mut xy = Vec::with_capacity(problem.cities.len() * 2);
+        for (pos, c) in problem.cities.iter().enumerate() {
+            assert_eq!(problem.distances.city_id2pos(c.id), Some(pos), "cities order differs from the distance matrix");
+            xy.push(c.coords[0]);
+            xy.push(c.coords[1]);
+        }
+        Boundary { problem, xy }
+    }
+
+    /// ids -> positions; an unknown id panics with the message of the CPU solver's `.expect(..)`.
+    fn positions(&self, tour: &[usize], what: &str) -> Vec<u32> {
+        tour.iter()
+            .map(|&id| self.problem.distances.city_id2pos(id).unwrap_or_else(|| panic!("{what}")) as u32)
+            .collect()
+    }
+
+    fn ids(&self, pos: &[u32]) -> Vec<usize> {
+        pos.iter().map(|&p| self.problem.cities[p as usize].id).collect()
+    }
+
+    /// `DistanceMatrix` does not remember its DistanceType (distance_matrix.rs:86-93): ask the library whether the matrix
+    /// is exactly the EUC_2D matrix of the coordinates.  If so the coordinate kernels apply (same tours, no 4n^2-byte
+    /// expansion); otherwise (GEO, EXPLICIT) the matrix kernels read `problem.distances`.
+    fn matrix<'b>(&'b self, ctx: &ffi::Context) -> Result<Option<&'b [f32]>, ffi::Error> {
+        let dm = self.problem.distances.distances();
+        Ok(if ctx.dm_is_euc2d(&self.xy, dm)? { None } else { Some(dm) })
+    }
+}
+
+fn unwrap_gpu<T>(what: &str, r: Result<T, ffi::Error>) -> T {
+    r.unwrap_or_else(|e| panic!("{what}: {e}"))
+}
+
+fn start_tour(problem: &TspProblem, init_tour: Option<&[usize]>) -> Vec<usize> {
+    init_tour.map(|t| t.to_vec()).unwrap_or_else(|| problem.cities.iter().map(|c| c.id).collect())
+}
+
+fn finish(problem: &TspProblem, io: &Boundary, t: &ffi::Tour, tx: Option<&mpsc::Sender<ProgressMessage>>, done: bool) -> Solution {
+    let route = io.ids(&t.pos);
+    let sol = Solution::new(&route, problem);
+    debug_assert_eq!(sol.total.to_bits(), t.cost.to_bits(), "device total differs from DistanceMatrix::tour_length");
+    if let Some(tx) = tx {
+        let _ = tx.send(ProgressMessage::PathUpdate(Route::new(&route), sol.total));
+        if done {
+            let _ = tx.send(ProgressMessage::Done);
+        }
+    }
+    sol
+}
+
+pub mod two_opt {
+    use super::*;
+
+    pub fn solve(
+        problem: &TspProblem,
+        _opts: &HeuristicOptions,
+        progress_tx: Option<&mpsc::Sender<ProgressMessage>>,
+        init_tour: Option<&[usize]>,
+    ) -> Solution {
+        tracing::info!(cities = problem.cities.len(), "2-opt (gpu) starting");
+        let io = Boundary::new(problem);
+        let init = init_tour.map(|t| io.positions(t, "two_opt: invalid city pair"));
+        if let Some(tx) = progress_tx {
+            let _ = tx.send(ProgressMessage::PathUpdate(Route::new(&start_tour(problem, init_tour)), 0.0));
+        }
+        let t = unwrap_gpu("two_opt (gpu)", ffi::with_context(|ctx| {
+            let dm = io.matrix(ctx)?;
+            ctx.two_opt(&io.xy, dm, init.as_deref(), ffi::MODE_REF_ORDER)
+        }));
+        finish(problem, &io, &t, progress_tx, true)
+    }
+}
+
+pub mod three_opt {
+    use super::*;
+
+    pub fn solve(
+        problem: &TspProblem,
+        _opts: &HeuristicOptions,
+        progress_tx: Option<&mpsc::Sender<ProgressMessage>>,
+        init_tour: Option<&[usize]>,
+    ) -> Solution {
+        tracing::info!(cities = problem.cities.len(), "3-opt (gpu) starting");
+        let io = Boundary::new(problem);
+        let init = init_tour.map(|t| io.positions(t, "three_opt: invalid city pair"));
+        if let Some(tx) = progress_tx {
+            let _ = tx.send(ProgressMessage::PathUpdate(Route::new(&start_tour(problem, init_tour)), 0.0));
+        }
+        let t = unwrap_gpu("three_opt (gpu)", ffi::with_context(|ctx| {
+            let dm = io.matrix(ctx)?;
+            ctx.three_opt(&io.xy, dm, init.as_deref())
+        }));
+        finish(problem, &io, &t, progress_tx, true)
+    }
+}
+
+pub mod or_opt {
+    use super::*;
+
+    pub fn solve(
+        problem: &TspProblem,
+        _opts: &HeuristicOptions,
+        progress_tx: Option<&mpsc::Sender<ProgressMessage>>,
+        init_tour: Option<&[usize]>,
+    ) -> Solution {
+        let io = Boundary::new(problem);
+        let init = init_tour.map(|t| io.positions(t, "or_opt: invalid city pair"));
+        if let Some(tx) = progress_tx {
+            let _ = tx.send(ProgressMessage::PathUpdate(Route::new(&start_tour(problem, init_tour)), 0.0));
+        }
+        let t = unwrap_gpu("or_opt (gpu)", ffi::with_context(|ctx| {
+            let dm = io.matrix(ctx)?;
+            ctx.or_opt(&io.xy, dm, init.as_deref())
+        }));
+        finish(problem, &io, &t, progress_tx, true)
+    }
+}
+
+pub mod nearest_neighbor {
+    use super::*;
+
+    pub fn solve(
+        problem: &TspProblem,
+        opts: &HeuristicOptions,
+        progress_tx: Option<&mpsc::Sender<ProgressMessage>>,
+        _init_tour: Option<&[usize]>,
+    ) -> Solution {
+        let io = Boundary::new(problem);
+        let t = unwrap_gpu("nearest_neighbor (gpu)", ffi::with_context(|ctx| {
+            let dm = io.matrix(ctx)?;
+            ctx.nearest_neighbor(&io.xy, dm, opts.n_nearest as u32)
+        }));
+        finish(problem, &io, &t, progress_tx, true)
+    }
+}
+
+pub mod lin_kernighan {
+    use super::*;
+    use rand::RngExt;
+
+    pub fn solve(
+        problem: &TspProblem,
+        opts: &LKOptions,
+        progress_tx: Option<&mpsc::Sender<ProgressMessage>>,
+        init_tour: Option<&[usize]>,
+    ) -> Solution {
+        let io = Boundary::new(problem);
+        let init = init_tour.map(|t| io.positions(t, "lin_kernighan: invalid city id in init_tour"));
+        let lk = ffi::LkOpts {
+            epochs: opts.heuristic.epochs as u32,
+            platoo_epochs: opts.heuristic.platoo_epochs as u32,
+            n_nearest: opts.heuristic.n_nearest as u32,
+            max_depth: opts.max_depth as u32,
+        };
+        let seed = std::env::var("TEELINE_GPU_LK_SEED")
+            .ok()
+            .and_then(|v| v.parse::<u64>().ok())
+            .unwrap_or_else(|| rand::rng().random::<u64>());
+        let t = unwrap_gpu("lin_kernighan (gpu)", ffi::with_context(|ctx| {
+            // problem.distances feeds the NN seed and the total only; the search is Euclidean (lin_kernighan.rs:41,47-55,99)
+            let dm = io.matrix(ctx)?;
+            ctx.lin_kernighan(&io.xy, dm, init.as_deref(), lk, seed)
+        }));
+        // lin_kernighan.rs sends PathUpdate for every improvement and never Done (:71,:90)
+        finish(problem, &io, &t, progress_tx, false)
+    }
+}

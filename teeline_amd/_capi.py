@@ -29,7 +29,8 @@ SYMBOLS = [
     "tl_two_opt_lds_max_n", "tl_dm_build", "tl_tour_length", "tl_two_opt", "tl_three_opt",
     "tl_three_opt_find_best_move", "tl_lk", "tl_two_opt_multistart", "tl_pack_cost_key",
     "tl_two_opt_batch_dev", "tl_last_kernel_ms", "tl_dm_build_dev", "tl_build_candidates", "tl_nearest_neighbor",
-    "tl_or_opt", "tl_or_opt_find_best_move", "tl_selftest_sqrt", "tl_two_opt_population",
+    "tl_or_opt", "tl_or_opt_find_best_move", "tl_selftest_sqrt", "tl_two_opt_population", "tl_dm_is_euc2d",
+    "tl_two_opt_multistart_devices",
 ]
 
 
@@ -82,6 +83,7 @@ def load():
     L.tl_two_opt_lds_max_n.restype = u32
     L.tl_dm_build.argtypes = [vp, vp, u32, i32, i32, vp, C.POINTER(C.c_double)]
     L.tl_tour_length.argtypes = [vp, vp, vp, u32, vp, f32p]
+    L.tl_dm_is_euc2d.argtypes = [vp, vp, vp, u32, C.POINTER(i32)]
     L.tl_two_opt.argtypes = [vp, vp, u32, vp, vp, i32, vp, f32p, C.POINTER(TlStats)]
     L.tl_three_opt.argtypes = [vp, vp, u32, vp, vp, vp, f32p, C.POINTER(TlStats)]
     L.tl_three_opt_find_best_move.argtypes = [vp, vp, u32, vp, vp, C.POINTER(i32), C.POINTER(u32),
@@ -89,6 +91,8 @@ def load():
     L.tl_lk.argtypes = [vp, vp, u32, vp, vp, C.POINTER(TlLkOpts), u64, vp, f32p, C.POINTER(TlStats)]
     L.tl_two_opt_multistart.argtypes = [vp, vp, u32, u64, u32, u32, i32, vp, f32p, C.POINTER(u32), vp,
                                         C.POINTER(TlStats)]
+    L.tl_two_opt_multistart_devices.argtypes = [C.POINTER(vp), i32, vp, u32, u64, u32, u32, i32, vp, f32p, C.POINTER(u32), vp,
+                                                C.POINTER(TlStats)]
     L.tl_two_opt_population.argtypes = [vp, vp, u32, vp, vp, u32, vp, vp, C.POINTER(TlStats)]
     L.tl_pack_cost_key.argtypes = [C.c_float, u32]
     L.tl_pack_cost_key.restype = u64

@@ -37,6 +37,26 @@ __global__ __launch_bounds__(kDmThreads) void k_dm_build_packed_rows(const float
     }
 }
 
+// Does a caller's packed matrix hold exactly the EUC_2D distances of xy?  (The reference's DistanceMatrix does not
+// remember its DistanceType, distance_matrix.rs:86-93: a drop-in caller that only has `problem.distances` learns here
+// whether the on-the-fly coordinate kernels apply — bit for bit, NaN payloads aside — or the matrix kernels must run.)
+__global__ __launch_bounds__(kDmThreads) void k_dm_compare_packed_rows(const float2 *__restrict__ xy, uint32_t n,
+                                                                      const float *__restrict__ dm, uint32_t *__restrict__ differs)
+{
+    const uint32_t i = blockIdx.x + 1u;
+    uint32_t j = blockIdx.y * (kDmThreads * kDmPerThread) + threadIdx.x;
+    if (j >= i) return;
+    const float2 a = xy[i];
+    const float *__restrict__ row = dm + (size_t)i * (i - 1u) / 2u;
+    bool bad = false;
+    for (int k = 0; k < kDmPerThread; ++k, j += kDmThreads) {
+        if (j >= i) break;
+        const float want = dist(a, xy[j]), got = row[j];
+        bad |= __builtin_bit_cast(uint32_t, want) != __builtin_bit_cast(uint32_t, got) && !(want != want && got != got);
+    }
+    if (bad) atomicOr(differs, 1u);
+}
+
 template <bool GEO>
 __global__ __launch_bounds__(kDmThreads) void k_dm_build_full(const float2 *__restrict__ xy, uint32_t n,
                                                              float *__restrict__ out)
@@ -106,6 +126,15 @@ hipError_t launch_dm_build(const float2 *xy, uint32_t n, int dist_kind, int layo
         if (geo) hipLaunchKernelGGL(k_dm_build_full<true>, grid, dim3(kDmThreads), 0, s, xy, n, out);
         else hipLaunchKernelGGL(k_dm_build_full<false>, grid, dim3(kDmThreads), 0, s, xy, n, out);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_dm_compare(const float2 *xy, uint32_t n, const float *dm, uint32_t *differs, hipStream_t s)
+{
+    if (n < 2) return hipSuccess;
+    const uint32_t per_row = kDmThreads * kDmPerThread;
+    const dim3 grid(n - 1, (n - 1 + per_row - 1) / per_row);
+    hipLaunchKernelGGL(k_dm_compare_packed_rows, grid, dim3(kDmThreads), 0, s, xy, n, dm, differs);
     return hipGetLastError();
 }
 

@@ -226,6 +226,26 @@ extern "C" int tl_dm_build(tl_ctx *c, const float *xy, uint32_t n, int dist, int
     return TL_OK;
 }
 
+extern "C" int tl_dm_is_euc2d(tl_ctx *c, const float *xy, const float *dm_packed, uint32_t n, int *is_euc2d)
+{
+    if (!c || !xy || !dm_packed || !is_euc2d) return fail(c, TL_ERR_BADARG, "tl_dm_is_euc2d: NULL argument");
+    *is_euc2d = 1;
+    if (n < 2) return TL_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    const size_t b = (size_t)n * (n - 1) / 2 * 4;
+    if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->dm, b)) || (rc = ensure(c, c->misc, 16))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dm.p, dm_packed, b, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->misc.p, 0, 4, c->stream));
+    HIPCHK(c, launch_dm_compare((const float2 *)c->xy.p, n, (const float *)c->dm.p, (uint32_t *)c->misc.p, c->stream));
+    uint32_t differs = 0;
+    HIPCHK(c, hipMemcpyAsync(&differs, c->misc.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *is_euc2d = differs ? 0 : 1;
+    return TL_OK;
+}
+
 extern "C" int tl_tour_length(tl_ctx *c, const float *xy, const float *dm_packed, uint32_t n, const uint32_t *perm, float *out_cost)
 {
     if (!c || (!xy && !dm_packed) || !perm || !out_cost) return fail(c, TL_ERR_BADARG, "tl_tour_length: NULL argument");
@@ -465,45 +485,113 @@ extern "C" uint64_t tl_pack_cost_key(float cost, uint32_t restart)
     return ((uint64_t)bits << 32) | restart;
 }
 
-extern "C" int tl_two_opt_multistart(tl_ctx *c, const float *xy, uint32_t n, uint64_t seed, uint32_t first, uint32_t count,
-                                     int mode, uint32_t *out_best_pos, float *out_best_cost, uint32_t *out_best_restart,
-                                     float *out_costs, tl_stats *stats)
+// multi-start = enqueue (asynchronous: upload, descent kernel) + finish (read back, pick the shard's best)
+static int multistart_begin(tl_ctx *c, const float *xy, uint32_t n, uint64_t seed, uint32_t first, uint32_t count, int mode)
 {
-    if (!c || !xy || !out_best_pos) return fail(c, TL_ERR_BADARG, "tl_two_opt_multistart: NULL argument");
-    if (count == 0) return fail(c, TL_ERR_BADARG, "tl_two_opt_multistart: count == 0");
-    if (n < 3) return fail(c, TL_ERR_REF_PANICS, "two_opt: n=%u < 3", n);
-    const auto t0 = std::chrono::steady_clock::now();
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
     if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->out_pos, (size_t)count * n * 4)) ||
         (rc = ensure(c, c->out_cost, (size_t)count * 4)) || (rc = ensure(c, c->out_stats, (size_t)count * TL_STATS_STRIDE * 8)))
         return rc;
     HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
-    if ((rc = two_opt_enqueue(c, (const float2 *)c->xy.p, nullptr, n, nullptr, TL_INIT_SEEDED, seed, first, count, mode,
-                              (uint32_t *)c->out_pos.p, (float *)c->out_cost.p, (uint64_t *)c->out_stats.p, c->stream)))
-        return rc;
-    std::vector<float> costs(count);
-    std::vector<uint64_t> raw((size_t)count * TL_STATS_STRIDE);
-    HIPCHK(c, hipMemcpyAsync(costs.data(), c->out_cost.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(raw.data(), c->out_stats.p, (size_t)count * TL_STATS_STRIDE * 8, hipMemcpyDeviceToHost, c->stream));
+    return two_opt_enqueue(c, (const float2 *)c->xy.p, nullptr, n, nullptr, TL_INIT_SEEDED, seed, first, count, mode,
+                           (uint32_t *)c->out_pos.p, (float *)c->out_cost.p, (uint64_t *)c->out_stats.p, c->stream);
+}
+
+struct ShardBest {
+    uint64_t key = ~0ull;
+    uint32_t local = 0;  // index inside the shard
+};
+
+static int multistart_finish(tl_ctx *c, uint32_t n, uint32_t first, uint32_t count, float *costs /*count*/, uint64_t *raw /*count x stride*/,
+                             ShardBest &best)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(costs, c->out_cost.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(raw, c->out_stats.p, (size_t)count * TL_STATS_STRIDE * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    uint32_t best = 0;
-    uint64_t best_key = ~0ull;
     for (uint32_t r = 0; r < count; ++r) {
         if (raw[TL_STATS_STRIDE * r + 3] != 0) return fail(c, TL_ERR_NO_CONVERGE, "two_opt: sweep cap reached in restart %u", first + r);
         const uint64_t k = tl_pack_cost_key(costs[r], first + r);
-        if (k < best_key) {
-            best_key = k;
-            best = r;
+        if (k < best.key) {
+            best.key = k;
+            best.local = r;
         }
     }
-    HIPCHK(c, hipMemcpy(out_best_pos, (const uint32_t *)c->out_pos.p + (size_t)best * n, (size_t)n * 4, hipMemcpyDeviceToHost));
-    if (out_best_cost) *out_best_cost = costs[best];
-    if (out_best_restart) *out_best_restart = first + best;
+    (void)n;
+    return TL_OK;
+}
+
+extern "C" int tl_two_opt_multistart(tl_ctx *c, const float *xy, uint32_t n, uint64_t seed, uint32_t first, uint32_t count,
+                                     int mode, uint32_t *out_best_pos, float *out_best_cost, uint32_t *out_best_restart,
+                                     float *out_costs, tl_stats *stats)
+{
+    tl_ctx *one[1] = {c};
+    return tl_two_opt_multistart_devices(one, 1, xy, n, seed, first, count, mode, out_best_pos, out_best_cost, out_best_restart,
+                                         out_costs, stats);
+}
+
+// North-star config 4 from ONE host process (what the Rust caller has: the reference is single-process): the restarts
+// [first, first + count) are dealt in contiguous blocks to the caller's contexts — one per device, created once with
+// tl_create(device, ...) — every shard is enqueued before any is waited for, and the winner is the minimum of at most
+// n_ctxs packed (cost, restart) keys on the host.  No collective is needed inside the library; ranks of a multi-process
+// job (bench.py) min-all-reduce the same key over RCCL instead.
+extern "C" int tl_two_opt_multistart_devices(tl_ctx *const *ctxs, int n_ctxs, const float *xy, uint32_t n, uint64_t seed, uint32_t first,
+                                             uint32_t count, int mode, uint32_t *out_best_pos, float *out_best_cost,
+                                             uint32_t *out_best_restart, float *out_costs, tl_stats *stats)
+{
+    tl_ctx *c0 = (ctxs && n_ctxs > 0) ? ctxs[0] : nullptr;
+    if (!c0 || !xy || !out_best_pos) return fail(c0, TL_ERR_BADARG, "tl_two_opt_multistart: NULL argument");
+    for (int d = 0; d < n_ctxs; ++d)
+        if (!ctxs[d]) return fail(c0, TL_ERR_BADARG, "tl_two_opt_multistart_devices: context %d is NULL", d);
+    if (count == 0) return fail(c0, TL_ERR_BADARG, "tl_two_opt_multistart: count == 0");
+    if (n < 3) return fail(c0, TL_ERR_REF_PANICS, "two_opt: n=%u < 3", n);
+    const auto t0 = std::chrono::steady_clock::now();
+    struct Shard {
+        uint32_t first, count;
+    };
+    std::vector<Shard> shard((size_t)n_ctxs);
+    const uint32_t base = count / (uint32_t)n_ctxs, extra = count % (uint32_t)n_ctxs;
+    uint32_t at = first;
+    for (int d = 0; d < n_ctxs; ++d) {
+        shard[d] = {at, base + ((uint32_t)d < extra ? 1u : 0u)};
+        at += shard[d].count;
+    }
+    int rc;
+    for (int d = 0; d < n_ctxs; ++d)
+        if (shard[d].count && (rc = multistart_begin(ctxs[d], xy, n, seed, shard[d].first, shard[d].count, mode))) {
+            if (d) fail(c0, rc, "device shard %d: %s", d, ctxs[d]->err.c_str());
+            return rc;
+        }
+    std::vector<float> costs(count);
+    std::vector<uint64_t> raw((size_t)count * TL_STATS_STRIDE);
+    ShardBest best;
+    int best_dev = 0;
+    double kms_max = 0;
+    for (int d = 0; d < n_ctxs; ++d) {
+        if (!shard[d].count) continue;
+        const uint32_t off = shard[d].first - first;
+        ShardBest b;
+        if ((rc = multistart_finish(ctxs[d], n, shard[d].first, shard[d].count, costs.data() + off, raw.data() + (size_t)off * TL_STATS_STRIDE, b))) {
+            if (d) fail(c0, rc, "device shard %d: %s", d, ctxs[d]->err.c_str());
+            return rc;
+        }
+        if (b.key < best.key) {
+            best = b;
+            best_dev = d;
+        }
+        double kms = 0;
+        tl_last_kernel_ms(ctxs[d], &kms);
+        kms_max = kms > kms_max ? kms : kms_max;
+    }
+    tl_ctx *cb = ctxs[best_dev];
+    HIPCHK(cb, hipSetDevice(cb->device));
+    HIPCHK(cb, hipMemcpy(out_best_pos, (const uint32_t *)cb->out_pos.p + (size_t)best.local * n, (size_t)n * 4, hipMemcpyDeviceToHost));
+    const uint32_t best_restart = (uint32_t)(best.key & 0xFFFFFFFFull);
+    if (out_best_cost) *out_best_cost = costs[best_restart - first];
+    if (out_best_restart) *out_best_restart = best_restart;
     if (out_costs) memcpy(out_costs, costs.data(), (size_t)count * 4);
-    double kms = 0;
-    tl_last_kernel_ms(c, &kms);
-    fill_stats(stats, n, raw.data(), count, kms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    fill_stats(stats, n, raw.data(), count, kms_max, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     return TL_OK;
 }
 

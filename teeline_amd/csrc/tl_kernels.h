@@ -183,6 +183,7 @@ size_t lk_chain_slot_words();
 
 // dm_build.hip
 hipError_t launch_dm_build(const float2 *xy, uint32_t n, int dist, int layout, float *out, hipStream_t s);
+hipError_t launch_dm_compare(const float2 *xy, uint32_t n, const float *dm, uint32_t *differs, hipStream_t s);
 hipError_t launch_selftest_sqrt(uint32_t first_bits, uint64_t count, unsigned long long *mismatches, uint32_t *first_bad, hipStream_t s);
 hipError_t launch_tour_length(const float2 *xy, const float *dm, uint32_t n, const uint32_t *perm,
                               float *out_cost, hipStream_t s);

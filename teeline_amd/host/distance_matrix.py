@@ -95,3 +95,18 @@ def build(ids, xy, kind="euc2d", ctx=None, return_ms=False):
 def from_cities(cities, ctx=None):
     """distance_matrix::from_cities (distance_matrix.rs:78-80)."""
     return build([c.id for c in cities], [[c.coords[0], c.coords[1]] for c in cities], "euc2d", ctx)
+
+
+def is_euc2d(xy, items, ctx=None):
+    """tl_dm_is_euc2d: does the packed matrix `items` hold exactly the EUC_2D distances of xy?  (The reference's
+    DistanceMatrix has no distance type: distance_matrix.rs:86-93.)"""
+    from . import default_context
+    ctx = ctx or default_context()
+    xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+    items = np.ascontiguousarray(items, dtype=np.float32)
+    n = xy.shape[0]
+    if items.shape[0] != n * (n - 1) // 2:
+        raise ValueError("distances length != n*(n-1)/2")
+    out = C.c_int()
+    ctx.check(ctx.lib.tl_dm_is_euc2d(ctx.handle, xy.ctypes.data_as(C.c_void_p), items.ctypes.data_as(C.c_void_p), n, C.byref(out)))
+    return bool(out.value)

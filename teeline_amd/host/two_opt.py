@@ -54,6 +54,26 @@ def multistart(problem, restarts, seed=0, first=0, *, ctx=None, mode=_capi.TL_MO
     return (sol, costs) if return_costs else sol
 
 
+def multistart_devices(problem, restarts, contexts, seed=0, first=0, *, mode=_capi.TL_MODE_REF_ORDER, return_costs=False):
+    """tl_two_opt_multistart_devices: the same multi-start job dealt over several contexts (one per GPU of the node) from
+    one process; the result does not depend on how many contexts share the restarts."""
+    from . import Solution
+    n = len(problem)
+    out = np.empty(n, dtype=np.uint32)
+    costs = np.empty(restarts, dtype=np.float32)
+    cost, best = C.c_float(), C.c_uint32()
+    st = _capi.TlStats()
+    arr = (C.c_void_p * len(contexts))(*[c.handle for c in contexts])
+    c0 = contexts[0]
+    c0.check(c0.lib.tl_two_opt_multistart_devices(arr, len(contexts), problem.xy.ctypes.data_as(C.c_void_p), n, int(seed), int(first),
+                                                  int(restarts), int(mode), out.ctypes.data_as(C.c_void_p), C.byref(cost),
+                                                  C.byref(best), costs.ctypes.data_as(C.c_void_p), C.byref(st)))
+    stats = st.as_dict()
+    stats["best_restart"] = best.value
+    sol = Solution(cost.value, problem.ids[out], problem, stats)
+    return (sol, costs) if return_costs else sol
+
+
 def solve_population(problem, init_tours, *, ctx=None):
     """Refine a population of tours (lists of city ids), each by its own two_opt::solve descent, all concurrently
     (tl_two_opt_population).  Returns one Solution per tour; Solution k equals solve(problem, None, None, init_tours[k])."""

@@ -109,3 +109,48 @@ def test_cpp_host_mirror_builds_and_fails_loudly_without_gpu(tsplib_dir):
     assert r.returncode == 1 and "no CPU fallback" in r.stderr and r.stdout == ""
     r = subprocess.run([cli, "bogus"], capture_output=True, text=True)
     assert r.returncode == 2
+
+
+def _c_arg_count(decl):
+    args = decl.strip()
+    if args in ("", "void"):
+        return 0
+    return args.count(",") + 1
+
+
+def test_rust_binding_matches_the_header():
+    """integration/teeline-gpu/src/lib.rs (the FFI crate a maintainer adds to the reference workspace) cannot be compiled
+    here (no cargo/rustc): check its `extern "C"` block against the header instead — every bound symbol is declared, with
+    the same number of arguments."""
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    hdr = {m.group(1): _c_arg_count(m.group(2)) for m in re.finditer(r"\b(tl_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text)}
+    rs = open(os.path.join(ROOT, "integration", "teeline-gpu", "src", "lib.rs")).read()
+    block = rs[rs.index('unsafe extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    bound = {m.group(1): _c_arg_count(m.group(2)) for m in re.finditer(r"fn (tl_[a-z0-9_]+)\(([^)]*)\)", block, flags=re.S)}
+    assert {"tl_two_opt", "tl_three_opt", "tl_lk", "tl_or_opt", "tl_nearest_neighbor", "tl_dm_is_euc2d", "tl_create",
+            "tl_two_opt_multistart_devices"} <= set(bound)
+    for name, argc in bound.items():
+        assert name in hdr, f"{name} is not declared in teeline_gpu.h"
+        assert hdr[name] == argc, f"{name}: header has {hdr[name]} arguments, lib.rs {argc}"
+    m = re.search(r"TL_ABI_VERSION: c_int = (\d+)", rs)
+    assert m and f"#define TL_ABI_VERSION {m.group(1)}" in open(HEADER).read()
+
+
+def test_reference_patch_applies_cleanly():
+    """integration/patches/0001-gpu-feature.patch against the reference tree (present in the build container only)."""
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "src", "tsp")):
+        pytest.skip("reference tree not present")
+    patch = os.path.join(ROOT, "integration", "patches", "0001-gpu-feature.patch")
+    r = subprocess.run(["patch", "-p1", "--dry-run", "-d", ref, "-i", patch], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # the three arms SURVEY.md §8(b) names are switched, and the module added by the patch is the file kept beside the crate
+    text = open(patch).read()
+    for arm in ("two_opt_impl::solve(problem, &h, tx, init_tour)", "three_opt_impl::solve(problem, &h, tx, init_tour)",
+                "lk_impl::solve(problem, &lk, tx, init_tour)"):
+        assert "+" + " " * 8 + "Solvers::" in text and arm in text
+    gpu_rs = open(os.path.join(ROOT, "integration", "teeline-gpu", "gpu.rs")).read()
+    for sig in ("progress_tx: Option<&mpsc::Sender<ProgressMessage>>", "init_tour: Option<&[usize]>", ") -> Solution {"):
+        assert gpu_rs.count(sig) >= 4

@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, port, outq):
+def _worker(rank, port, outq, total=0):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
@@ -38,7 +38,7 @@ def _worker(rank, port, outq):
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     try:
         xy = synth.synth_xy(N)
-        first, count = ms.shard(rank, R_PER_RANK)
+        first, count = ms.shard_total(rank, WORLD, total) if total else ms.shard(rank, R_PER_RANK)
         costs, cands, tours = [], 0, []
         for r in range(first, first + count):
             init = synth.restart_perm(N, SEED, r)
@@ -81,6 +81,25 @@ def test_two_rank_min_allreduce_of_best_tour_key():
     assert res[0][3] == res[1][3] == 2.0
 
 
+def test_two_rank_strong_shard_map():
+    # BASELINE configs[3] as worded: a fixed number of restarts in all (here 5: an uneven split, 3 + 2), dealt in contiguous
+    # blocks; the winner is the one a single process finds over restarts 0..4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, q, 5)) for r in range(WORLD)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in range(WORLD))
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    from teeline_amd.host import multistart as ms
+    assert [len(r[4]) for r in res] == [3, 2]
+    all_costs = res[0][4] + res[1][4]
+    want = min(range(5), key=lambda i: (np.float32(all_costs[i]), i))
+    assert res[0][1] == res[1][1] and ms.unpack_key(res[0][1])[1] == want
+    assert res[0][6] == res[1][6] == (res[0][7] + res[1][7])[want]
+
+
 def test_key_packing_matches_c_abi_definition():
     from teeline_amd.host import multistart as ms
     costs = torch.tensor([3.5, 1.25, 1.25, 77647.55469], dtype=torch.float32)
@@ -93,6 +112,14 @@ def test_key_packing_matches_c_abi_definition():
     for i, c in enumerate(costs.tolist()):
         assert lib.tl_pack_cost_key(c, 10 + i) == int(keys[i])
     assert ms.shard(3, 256) == (768, 256)
+    # strong scaling (BASELINE configs[3]: 256 restarts in all over 1/2/4/8 GPUs): contiguous blocks that tile [0, total)
+    for world in (1, 2, 3, 4, 8):
+        for total in (256, 10, 7):
+            blocks = [ms.shard_total(r, world, total) for r in range(world)]
+            assert blocks[0][0] == 0 and sum(c for _, c in blocks) == total
+            assert all(blocks[r][0] + blocks[r][1] == blocks[r + 1][0] for r in range(world - 1))
+            assert max(c for _, c in blocks) - min(c for _, c in blocks) <= 1
+    assert ms.shard_total(3, 8, 256) == (96, 32)
     # one process, no process group: the "shared" tour is the local winner's
     tours = torch.arange(4 * 6, dtype=torch.int32).reshape(4, 6)
     best = ms.allreduce_best(keys, None)

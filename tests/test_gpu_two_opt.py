@@ -177,6 +177,71 @@ def test_multistart_matches_per_restart_oracle(ctx):
     assert list(sol.route()) == oroutes[best].tolist() and sol.total == ocosts[best]
 
 
+def test_multistart_over_several_contexts_is_independent_of_the_split(ctx):
+    # tl_two_opt_multistart_devices: one process, one context per device (here: 1, 2, 3 and 5 contexts on the one GPU of
+    # the test box); the deal of restarts over the contexts must not show in any output
+    import teeline_amd as TA
+    n, R, seed = 500, 11, 99
+    xy = O.synth_xy(n, seed=17)
+    prob = TA.TspProblem(np.arange(n), xy)
+    ref, ref_costs = TA.two_opt.multistart(prob, R, seed=seed, first=5, ctx=ctx, return_costs=True)
+    ocosts = [O.two_opt(xy, None, n, init=O.restart_perm(n, seed, r))[2] for r in range(5, 5 + R)]
+    assert [np.float32(c).tobytes() for c in ref_costs] == [np.float32(c).tobytes() for c in ocosts]
+    for k in (1, 2, 3, 5, 12):
+        cs = [TA.Context(0) for _ in range(k)]
+        try:
+            sol, costs = TA.two_opt.multistart_devices(prob, R, cs, seed=seed, first=5, return_costs=True)
+        finally:
+            [c.close() for c in cs]
+        assert costs.tobytes() == ref_costs.tobytes() and list(sol.route()) == list(ref.route())
+        assert sol.total == ref.total and sol.stats["best_restart"] == ref.stats["best_restart"]
+        for key in ("sweeps", "candidates", "moves", "reversed"):
+            assert sol.stats[key] == ref.stats[key]
+
+
+def test_dm_is_euc2d_tells_coordinate_matrices_from_explicit_ones(ctx, tsplib_dir):
+    # the reference's DistanceMatrix keeps no DistanceType (distance_matrix.rs:86-93): the shim asks the library
+    import teeline_amd as TA
+    xy = O.synth_xy(700, seed=3)
+    packed = O.dm_build_packed(xy)
+    assert TA.distance_matrix.is_euc2d(xy, packed, ctx=ctx)
+    bad = packed.copy()
+    bad[len(bad) // 3] = np.nextafter(bad[len(bad) // 3], np.float32(np.inf))
+    assert not TA.distance_matrix.is_euc2d(xy, bad, ctx=ctx)
+    bad = packed.copy()
+    bad[-1] += 1.0
+    assert not TA.distance_matrix.is_euc2d(xy, bad, ctx=ctx)
+    e = T.parse_tsplib(os.path.join(tsplib_dir, "burma14.tsp"))
+    assert not TA.distance_matrix.is_euc2d(e["xy"], O.dm_build_packed(e["xy"], geo=True), ctx=ctx)
+    assert TA.distance_matrix.is_euc2d(e["xy"], O.dm_build_packed(e["xy"]), ctx=ctx)
+    g = T.parse_tsplib(os.path.join(tsplib_dir, "gr17.tsp"))
+    assert not TA.distance_matrix.is_euc2d(g["xy"], g["packed"], ctx=ctx)
+
+
+def test_device_init_tour_with_out_of_range_entry_is_refused(ctx):
+    # tl_two_opt_batch_dev takes device-resident initial tours the host cannot check: an entry >= n must not index xy
+    import ctypes as C
+    import torch
+    from teeline_amd import _capi
+    n, R = 300, 3
+    xy = O.synth_xy(n, seed=5)
+    inits = np.stack([np.arange(n, dtype=np.uint32) for _ in range(R)])
+    inits[1, 17] = n + 5
+    dev = torch.device("cuda", 0)
+    d_xy, d_init = torch.from_numpy(xy).to(dev), torch.from_numpy(inits.astype(np.int32)).to(dev)
+    d_pos = torch.zeros((R, n), dtype=torch.int32, device=dev)
+    d_cost = torch.zeros(R, dtype=torch.float32, device=dev)
+    d_stats = torch.zeros((R, _capi.TL_DEV_STATS_STRIDE), dtype=torch.int64, device=dev)
+    s = torch.cuda.current_stream()
+    ctx.check(ctx.lib.tl_two_opt_batch_dev(ctx.handle, d_xy.data_ptr(), n, d_init.data_ptr(), 0, 0, R, 0, d_pos.data_ptr(),
+                                           d_cost.data_ptr(), d_stats.data_ptr(), C.c_void_p(s.cuda_stream)))
+    torch.cuda.synchronize()
+    st, cost = d_stats.cpu().numpy(), d_cost.cpu().numpy()
+    assert st[:, 3].tolist() == [0, 2, 0] and np.isnan(cost[1]) and not np.isnan(cost[0]) and not np.isnan(cost[2])
+    rc, p, c, _ = O.two_opt(xy, None, n)
+    assert d_pos[0].cpu().numpy().tolist() == p.tolist() == d_pos[2].cpu().numpy().tolist()
+
+
 def test_tour_length_and_dm_build(ctx, tsplib_dir):
     import teeline_amd as TA
     b = T.parse_tsplib(os.path.join(tsplib_dir, "berlin52.tsp"))
