@@ -12,7 +12,7 @@ from ._capi import (TL_FLAG_2OPT_FORCE_HBM, TL_FLAG_COUNT_WORK, TL_FLAG_KNN_1LAN
                     TL_FLAG_LK_NO_SUBCHAINS, TL_FLAG_LK_ONE_WORKGROUP, TL_FLAG_LK_SPLIT2, TL_FLAG_NONE, TL_FLAG_NO_PRUNE,
                     TL_MODE_BEST_SWEEP, TL_MODE_REF_ORDER, ReferencePanics, TeelineGpuError)
 from .host import (Context, HeuristicOptions, KDPoint, LKOptions, Solution, TspProblem, default_context,
-                   distance_matrix, lin_kernighan, multistart, nearest_neighbor, or_opt, pipeline, synth, three_opt, tsplib,
+                   distance_matrix, lin_kernighan, multistart, nearest_neighbor, opt_tour, or_opt, pipeline, synth, three_opt, tsplib,
                    two_opt,
                    validate_tour)
 

@@ -200,4 +200,4 @@ def validate_tour(tour_ids, problem):
     return ids == sorted(int(v) for v in problem.ids)
 
 
-from . import lin_kernighan, multistart, nearest_neighbor, or_opt, pipeline, synth, three_opt, tsplib, two_opt  # noqa: E402,F401
+from . import lin_kernighan, multistart, nearest_neighbor, opt_tour, or_opt, pipeline, synth, three_opt, tsplib, two_opt  # noqa: E402,F401

@@ -16,7 +16,10 @@
 
 #include <algorithm>
 #include <cctype>
+#include <charconv>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdint>
 #include <cstdlib>
 #include <fstream>
@@ -426,5 +429,300 @@ inline TspLibData read_from_file(const std::string &path)
 }
 
 }  // namespace tsplib
+
+namespace opt_tour {  // opt_tour.rs:12-107
+struct OptTour {
+    std::string name, comment;
+    size_t dimension = 0;
+    std::vector<size_t> route;
+};
+
+inline OptTour read_from_string(const std::string &text)
+{
+    std::map<std::string, std::string> meta;
+    OptTour t;
+    enum { Header, TourSection, End } state = Header;
+    std::istringstream in(text);
+    std::string raw;
+    while (std::getline(in, raw)) {
+        size_t b = raw.find_first_not_of(" \t\r\n"), e = raw.find_last_not_of(" \t\r\n");
+        std::string line = b == std::string::npos ? "" : raw.substr(b, e - b + 1);
+        for (auto &ch : line) ch = (char)std::toupper((unsigned char)ch);
+        if (line == "EOF" || state == End) break;
+        if (state == Header) {
+            if (line == "TOUR_SECTION") {
+                state = TourSection;
+                continue;
+            }
+            // ^(\w+)\s*:\s*(.+)$
+            size_t k = 0;
+            while (k < line.size() && (std::isalnum((unsigned char)line[k]) || line[k] == '_')) ++k;
+            size_t c = k;
+            while (c < line.size() && std::isspace((unsigned char)line[c])) ++c;
+            if (k == 0 || c >= line.size() || line[c] != ':') continue;
+            size_t v = c + 1;
+            while (v < line.size() && std::isspace((unsigned char)line[v])) ++v;
+            if (v >= line.size()) continue;
+            meta[line.substr(0, k)] = line.substr(v);
+        } else {
+            std::istringstream ls(line);
+            for (std::string tok; ls >> tok;) {
+                char *end = nullptr;
+                const long long id = std::strtoll(tok.c_str(), &end, 10);
+                if (!end || *end != '\0' || end == tok.c_str()) continue;  // isize::from_str failed: ignored
+                if (id == -1) {
+                    state = End;
+                    break;
+                }
+                if (id > 0) t.route.push_back((size_t)id);
+            }
+        }
+    }
+    const std::string ty = meta.count("TYPE") ? meta["TYPE"] : "";
+    if (ty != "TOUR") throw std::runtime_error("opt_tour: expected TYPE : TOUR, found TYPE : " + ty);
+    t.dimension = 0;
+    if (meta.count("DIMENSION")) {
+        char *end = nullptr;
+        const unsigned long long d = std::strtoull(meta["DIMENSION"].c_str(), &end, 10);
+        if (end && *end == '\0' && end != meta["DIMENSION"].c_str()) t.dimension = (size_t)d;
+    }
+    if (t.route.size() != t.dimension)
+        throw std::runtime_error("opt_tour: dimension mismatch — DIMENSION=" + std::to_string(t.dimension) + " but parsed " +
+                                 std::to_string(t.route.size()) + " cities");
+    t.name = meta.count("NAME") ? meta["NAME"] : "unknown";
+    t.comment = meta.count("COMMENT") ? meta["COMMENT"] : "";
+    return t;
+}
+
+inline OptTour read_from_file(const std::string &path)
+{
+    std::ifstream f(path);
+    if (!f) throw std::runtime_error("opt_tour: cannot open file: " + path);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    return read_from_string(ss.str());
+}
+}  // namespace opt_tour
+
+namespace random_shuffle {  // random_shuffle.rs:12-27, seeded (the reference draws from an unseeded thread RNG, :20)
+// Fisher-Yates `for i in (1..n).rev(): j = rng % (i+1); swap` driven by splitmix64 seeded with `seed` — the same stream the
+// device draws restart 0 of `seed` from (two_opt_ref.hip, oracle tlo_restart_perm), so a `shuffle` stage and a multi-start
+// restart agree.
+inline Solution solve(Context &ctx, const TspProblem &problem, uint64_t seed)
+{
+    const uint32_t n = (uint32_t)problem.cities.size();
+    std::vector<uint32_t> perm(n);
+    for (uint32_t i = 0; i < n; ++i) perm[i] = i;
+    uint64_t st = seed;
+    for (uint32_t i = n; i-- > 1;) {
+        uint64_t z = (st += 0x9E3779B97F4A7C15ULL);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        z ^= z >> 31;
+        std::swap(perm[i], perm[(uint32_t)(z % ((uint64_t)i + 1))]);
+    }
+    float cost = 0.f;
+    if (n >= 2) {
+        const auto xy = problem.xy();
+        ctx.check(tl_tour_length(ctx.get(), problem.explicit_packed() ? nullptr : xy.data(), problem.explicit_packed(), n, perm.data(), &cost));
+    }
+    return detail::finish(problem, perm, cost, tl_stats{}, nullptr);
+}
+}  // namespace random_shuffle
+
+// Solvers (mod.rs:47-72) this build accelerates, by the reference's names and aliases (FromStr, mod.rs:559-590)
+enum class Solvers { NearestNeighbor, TwoOpt, ThreeOpt, OrOpt, LinKernighan, RandomShuffle };
+
+inline bool solver_from_str(std::string s, Solvers &out, std::string &why)
+{
+    for (auto &ch : s) ch = (char)std::tolower((unsigned char)ch);
+    if (s == "nn" || s == "nearest_neighbor") out = Solvers::NearestNeighbor;
+    else if (s == "2opt" || s == "two_opt") out = Solvers::TwoOpt;
+    else if (s == "3opt" || s == "three_opt") out = Solvers::ThreeOpt;
+    else if (s == "or_opt" || s == "or-opt" || s == "oropt") out = Solvers::OrOpt;
+    else if (s == "lk" || s == "lin_kernighan") out = Solvers::LinKernighan;
+    else if (s == "shuffle" || s == "random_shuffle") out = Solvers::RandomShuffle;
+    else {
+        static const char *cpu_only[] = {"aco", "ant_colony", "bhk", "bellman_karp", "branch_bound", "christofides", "chr", "sav", "savings",
+                                         "cs", "cuckoo_search", "fpa", "flower_pollination", "fourier", "ga", "genetic_algorithm", "gsa",
+                                         "gravitational_search", "gec", "greedy_edge", "pso", "particle_swarm", "sa", "simulated_annealing",
+                                         "som", "kohonen", "kohonen_som", "stochastic_hill", "tabu", "tabu_search"};
+        for (const char *c : cpu_only)
+            if (s == c) {
+                why = "solver `" + s + "` is not accelerated by this build (nn, 2opt, 3opt, or_opt, lk, shuffle are)";
+                return false;
+            }
+        why = "unknown solver";  // FromStr's Err (mod.rs:588)
+        return false;
+    }
+    return true;
+}
+
+inline const char *solver_name(Solvers s)
+{
+    switch (s) {
+        case Solvers::NearestNeighbor: return "nn";
+        case Solvers::TwoOpt: return "2opt";
+        case Solvers::ThreeOpt: return "3opt";
+        case Solvers::OrOpt: return "or_opt";
+        case Solvers::LinKernighan: return "lk";
+        default: return "shuffle";
+    }
+}
+
+namespace pipeline {  // pipeline.rs
+struct StageOptions {
+    HeuristicOptions heuristic;
+    LKOptions lk;
+    int two_opt_mode = TL_MODE_REF_ORDER;
+    uint64_t seed = 1;  // LK kicks, shuffle
+};
+struct StageOutcome {  // :11-14
+    Solvers solver;
+    Solution solution;
+    uint64_t duration_ms = 0;
+};
+
+// stage_warnings (:92-132), for the solvers this build knows
+inline std::vector<std::string> stage_warnings(const std::vector<Solvers> &solvers)
+{
+    std::vector<std::string> w;
+    for (size_t i = 1; i < solvers.size(); ++i)
+        if (solvers[i] == Solvers::NearestNeighbor)
+            w.push_back("nn at stage " + std::to_string(i) + " discards the warm-start seed from the previous stage");
+    return w;
+}
+
+// run_pipeline_stages (:53-80): stage k+1 is warm-started with stage k's tour; an invalid seed is dropped with a warning,
+// an invalid stage result is a hard error
+inline std::vector<StageOutcome> run_pipeline_stages(Context &ctx, const TspProblem &problem, const std::vector<Solvers> &stages,
+                                                     const StageOptions &o)
+{
+    if (stages.empty()) throw std::runtime_error("pipeline has no stages");
+    std::vector<StageOutcome> out;
+    std::vector<size_t> seed;
+    bool have_seed = false;
+    for (Solvers s : stages) {
+        if (have_seed && !validate_tour(seed, problem.cities)) {
+            std::fprintf(stderr, "warning: pipeline: invalid seed; using default seeding\n");
+            have_seed = false;
+        }
+        const std::vector<size_t> *init = have_seed ? &seed : nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        Solution sol;
+        switch (s) {
+            case Solvers::NearestNeighbor: sol = nearest_neighbor::solve(ctx, problem, o.heuristic, nullptr, init); break;
+            case Solvers::TwoOpt: sol = two_opt::solve(ctx, problem, o.heuristic, nullptr, init, o.two_opt_mode); break;
+            case Solvers::ThreeOpt: sol = three_opt::solve(ctx, problem, o.heuristic, nullptr, init); break;
+            case Solvers::OrOpt: sol = or_opt::solve(ctx, problem, o.heuristic, nullptr, init); break;
+            case Solvers::LinKernighan: sol = lin_kernighan::solve(ctx, problem, o.lk, nullptr, init, o.seed); break;
+            case Solvers::RandomShuffle: sol = random_shuffle::solve(ctx, problem, o.seed); break;
+        }
+        const uint64_t ms = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (!validate_tour(sol.route(), problem.cities))
+            throw std::runtime_error(std::string("stage ") + solver_name(s) + " invalid tour");  // :70-71
+        seed = sol.route();
+        have_seed = true;
+        out.push_back(StageOutcome{s, std::move(sol), ms});
+    }
+    return out;
+}
+}  // namespace pipeline
+
+namespace cli {  // teeline-cli/src/main.rs output helpers
+// print_solution (main.rs:645-652): "{:.5} {flag}\n", then every id followed by ONE space, then "\n"
+inline std::string format_solution(const Solution &tour, bool is_optimized)
+{
+    char head[64];
+    std::snprintf(head, sizeof(head), "%.5f %d\n", tour.total, is_optimized ? 1 : 0);
+    std::string s = head;
+    for (size_t id : tour.route()) {
+        s += std::to_string(id);
+        s += ' ';
+    }
+    s += '\n';
+    return s;
+}
+
+struct OptimalComparison {  // main.rs:654-658
+    float optimal_cost = 0.f, gap_pct = 0.f;
+    std::string opt_name;
+};
+
+// compute_optimal_comparison (main.rs:660-684): the optimal tour's cost through the same tour_length; false on a dimension mismatch
+inline bool compute_optimal_comparison(Context &ctx, float solver_cost, const TspProblem &problem, const opt_tour::OptTour &ot,
+                                       OptimalComparison &cmp)
+{
+    if (ot.dimension != problem.cities.size()) {
+        std::fprintf(stderr, "--optimal-tour: dimension mismatch (%zu vs %zu); skipping comparison\n", ot.dimension, problem.cities.size());
+        return false;
+    }
+    // DistanceMatrix::tour_length (distance_matrix.rs:221-233): 0.0 for fewer than 2 cities or an unknown id
+    float optimal = 0.f;
+    std::unordered_map<size_t, uint32_t> idx;
+    for (size_t p = 0; p < problem.cities.size(); ++p) idx[problem.cities[p].id] = (uint32_t)p;
+    std::vector<uint32_t> pos;
+    bool known = ot.route.size() >= 2;
+    for (size_t id : ot.route) {
+        auto it = idx.find(id);
+        if (it == idx.end()) {
+            known = false;
+            break;
+        }
+        pos.push_back(it->second);
+    }
+    if (known) {
+        const auto xy = problem.xy();
+        ctx.check(tl_tour_length(ctx.get(), problem.explicit_packed() ? nullptr : xy.data(), problem.explicit_packed(),
+                                 (uint32_t)pos.size(), pos.data(), &optimal));
+    }
+    cmp.optimal_cost = optimal;
+    cmp.gap_pct = optimal > 0.0f ? (solver_cost - optimal) / optimal * 100.0f : 0.0f;  // f32 arithmetic, as the reference
+    cmp.opt_name = ot.name;
+    return true;
+}
+
+// print_optimal_comparison (main.rs:686-698), to stderr
+inline std::string format_optimal_comparison(float solver_cost, const OptimalComparison &cmp)
+{
+    char buf[256];
+    std::string s = "--- Comparison ---\n";
+    std::snprintf(buf, sizeof(buf), "Optimal  : %.5f  (from %s)\n", cmp.optimal_cost, cmp.opt_name.c_str());
+    s += buf;
+    std::snprintf(buf, sizeof(buf), "Solver   : %.5f\n", solver_cost);
+    s += buf;
+    if (std::fabs(cmp.gap_pct) < 0.001f) s += "Gap      : 0.00 % (matches optimal)\n";
+    else {
+        std::snprintf(buf, sizeof(buf), "Gap      : %+.2f %%\n", cmp.gap_pct);
+        s += buf;
+    }
+    return s;
+}
+
+// serde_json's rendering of an f32 inside json!(): widened to f64, shortest round-trip decimal, always with a fraction or
+// an exponent ("60.0", never "60")
+inline std::string json_f32(float v)
+{
+    char buf[64];
+    auto r = std::to_chars(buf, buf + sizeof(buf), (double)v);
+    std::string s(buf, r.ptr);
+    if (s.find_first_of(".eE") == std::string::npos) s += ".0";
+    return s;
+}
+
+// print_solution_json (main.rs:700-712): serde_json::Value prints object keys sorted (BTreeMap: no preserve_order), compact
+inline std::string format_solution_json(const Solution &tour, bool is_optimized, const OptimalComparison *opt)
+{
+    std::string s = "{\"cost\":" + json_f32(tour.total);
+    if (opt) s += ",\"gap_pct\":" + json_f32(opt->gap_pct) + ",\"optimal_cost\":" + json_f32(opt->optimal_cost);
+    s += std::string(",\"optimized\":") + (is_optimized ? "true" : "false") + ",\"route\":[";
+    for (size_t k = 0; k < tour.route().size(); ++k) {
+        if (k) s += ',';
+        s += std::to_string(tour.route()[k]);
+    }
+    s += "]}\n";
+    return s;
+}
+}  // namespace cli
 }  // namespace tsp
 }  // namespace teeline

@@ -1,81 +1,233 @@
-// teeline-gpu — minimal CLI façade over the GPU path, mirroring `teeline solve <solver> -i file` /
-// `teeline pipeline --steps=nn,2opt -i file` of teeline-cli (teeline-cli/src/main.rs:371-530) for the solvers
-// this build accelerates.  Output format = print_solution (main.rs:645-652): "{:.5} {0|1}\n<ids…>\n".
+// teeline-gpu — CLI façade over the GPU path, mirroring teeline-cli (teeline-cli/src/main.rs) for the solvers this build
+// accelerates: same sub-commands, same flags, byte-identical stdout.
 //
-//   teeline-gpu solve 2opt|3opt|oropt|lk|nn [-i file] [--no-seed] [--best-sweep] [--seed S] [--epochs E] [--platoo-epochs P]
-//                                     [--n-nearest K] [--max-depth D] [--device N] [--stats]
-// Like the reference, 2opt/3opt/lk are auto-seeded with a nearest-neighbour stage (mod.rs:129-139) unless --no-seed.
+//   teeline-gpu solve <solver|preset> [-i FILE] [--no-seed] [--output-format text|json] [--optimal-tour FILE]
+//                                     [--distance-type euc_2d|geo] [--epochs E] [--platoo_epochs P] [--n_nearest K] [--max-depth D]
+//   teeline-gpu pipeline --steps=nn,2opt,... [-i FILE] [same options]
+//   teeline-gpu solvers [--short]
+//     solver  : nn, 2opt, 3opt, or_opt, lk, shuffle (and their long names, mod.rs:559-590); preset: fast = nn,2opt (main.rs:354-369)
+//     solve   : 2opt / 3opt / or_opt / lk auto-expand to pipeline(nn, solver) unless --no-seed (main.rs:387-397, mod.rs:129-139)
+//     stdout  : print_solution "{:.5} {0|1}\n<id id ... >\n" (main.rs:645-652) or the JSON object of main.rs:700-712;
+//               with --optimal-tour the comparison goes to stderr in text mode and into the JSON object in JSON mode
+//   own flags (no counterpart in the reference): --seed S (LK kicks and the shuffle stage; the reference draws both from an
+//   unseeded thread RNG), --best-sweep (TL_MODE_BEST_SWEEP), --device N, --stats
 #include "teeline_gpu.hpp"
 
-#include <cstdio>
 #include <cstring>
 #include <iostream>
 
 using namespace teeline;
 using namespace teeline::tsp;
 
+namespace {
+
+struct Args {
+    std::string cmd, solver, file, steps, optimal_tour, distance_type, output_format = "text";
+    bool no_seed = false, best = false, stats = false, short_list = false;
+    int device = 0;
+    pipeline::StageOptions opt;
+};
+
+[[noreturn]] void usage_exit(const char *why)
+{
+    if (why) std::fprintf(stderr, "error: %s\n", why);
+    std::fprintf(stderr,
+                 "usage: teeline-gpu solve <nn|2opt|3opt|or_opt|lk|shuffle|fast> [-i FILE] [--no-seed] [--output-format text|json]\n"
+                 "                         [--optimal-tour FILE] [--distance-type euc_2d|geo] [--epochs E] [--platoo_epochs P]\n"
+                 "                         [--n_nearest K] [--max-depth D] [--seed S] [--best-sweep] [--device N] [--stats]\n"
+                 "       teeline-gpu pipeline --steps=nn,2opt,... [-i FILE] [options as above]\n"
+                 "       teeline-gpu solvers [--short]\n");
+    std::exit(2);  // clap's usage-error exit code
+}
+
+size_t parse_usize(const std::string &flag, const std::string &v)
+{
+    char *end = nullptr;
+    const unsigned long long x = std::strtoull(v.c_str(), &end, 10);
+    if (v.empty() || !end || *end != '\0' || v[0] == '-') {
+        std::fprintf(stderr, "error: %s must be a positive integer\n", flag.c_str());
+        std::exit(1);
+    }
+    return (size_t)x;
+}
+
+Args parse(int argc, char **argv)
+{
+    Args a;
+    if (argc < 2) usage_exit(nullptr);
+    a.cmd = argv[1];
+    // LKOptions::from_cli: heuristic = HeuristicOptions::from_cli, i.e. the CLI defaults 10000 / 500 / 3, not
+    // LKOptions::default() (mod.rs:1321-1325)
+    a.opt.lk.heuristic = a.opt.heuristic;
+    int i = 2;
+    if (a.cmd == "solve") {
+        if (argc < 3 || argv[2][0] == '-') usage_exit("solve: SOLVER_NAME is required");
+        a.solver = argv[2];
+        i = 3;
+    } else if (a.cmd != "pipeline" && a.cmd != "solvers") {
+        usage_exit("unknown sub-command");
+    }
+    for (; i < argc; ++i) {
+        std::string s = argv[i], inline_val;
+        bool has_inline = false;
+        const size_t eq = s.find('=');
+        if (s.rfind("--", 0) == 0 && eq != std::string::npos) {
+            inline_val = s.substr(eq + 1);
+            s = s.substr(0, eq);
+            has_inline = true;
+        }
+        auto val = [&]() -> std::string {
+            if (has_inline) return inline_val;
+            if (i + 1 >= argc) usage_exit((s + ": a value is required").c_str());
+            return argv[++i];
+        };
+        if (s == "-i" || s == "--input") a.file = val();
+        else if (s == "--no-seed") a.no_seed = true;
+        else if (s == "--steps") a.steps = val();
+        else if (s == "--output-format") a.output_format = val();
+        else if (s == "--optimal-tour") a.optimal_tour = val();
+        else if (s == "--distance-type") a.distance_type = val();
+        else if (s == "--epochs") a.opt.heuristic.epochs = a.opt.lk.heuristic.epochs = parse_usize(s, val());
+        else if (s == "--platoo_epochs" || s == "--platoo-epochs") a.opt.heuristic.platoo_epochs = a.opt.lk.heuristic.platoo_epochs = parse_usize(s, val());
+        else if (s == "--n_nearest" || s == "--n-nearest") a.opt.heuristic.n_nearest = a.opt.lk.heuristic.n_nearest = parse_usize(s, val());
+        else if (s == "--max-depth") a.opt.lk.max_depth = parse_usize(s, val());
+        else if (s == "-v" || s == "--verbose") a.opt.heuristic.verbose = true;
+        else if (s == "--seed") a.opt.seed = std::stoull(val());
+        else if (s == "--best-sweep") a.best = true;
+        else if (s == "--device") a.device = std::stoi(val());
+        else if (s == "--stats") a.stats = true;
+        else if (s == "--short") a.short_list = true;
+        else usage_exit(("unexpected argument " + s).c_str());
+    }
+    if (a.output_format != "text" && a.output_format != "json") usage_exit("--output-format: text or json");
+    if (a.opt.heuristic.n_nearest == 0) {  // HeuristicOptions::validate (mod.rs:677-682), through solve_with_context
+        std::fprintf(stderr, "error: n_nearest must be >= 1\n");
+        std::exit(1);
+    }
+    if (a.opt.lk.max_depth == 0) {
+        std::fprintf(stderr, "error: max_depth must be >= 1\n");
+        std::exit(1);
+    }
+    a.opt.two_opt_mode = a.best ? TL_MODE_BEST_SWEEP : TL_MODE_REF_ORDER;
+    return a;
+}
+
+std::vector<Solvers> parse_steps(const std::string &csv)
+{
+    std::vector<Solvers> v;
+    std::stringstream ss(csv);
+    for (std::string tok; std::getline(ss, tok, ',');) {
+        Solvers s;
+        std::string why;
+        if (!solver_from_str(tok, s, why)) {
+            std::fprintf(stderr, "error: %s: `%s`\n", why.c_str(), tok.c_str());
+            std::exit(1);
+        }
+        v.push_back(s);
+    }
+    return v;
+}
+
+}  // namespace
+
 int main(int argc, char **argv)
 {
     try {
-        if (argc < 3 || (std::string(argv[1]) != "solve")) {
-            std::fprintf(stderr, "usage: teeline-gpu solve 2opt|3opt|oropt|lk|nn -i file.tsp [--no-seed] [--best-sweep] [--seed S] [--stats]\n");
-            return 2;
+        Args a = parse(argc, argv);
+        if (a.cmd == "solvers") {  // `teeline solvers [--short]`, restricted to what this build runs
+            static const char *rows[][3] = {{"nearest_neighbor", "nn", "heuristic"}, {"two_opt", "2opt", "heuristic"}, {"three_opt", "3opt", "heuristic"},
+                                            {"or_opt", "or-opt", "heuristic"}, {"lin_kernighan", "lk", "heuristic"}, {"random_shuffle", "shuffle", "heuristic"}};
+            if (!a.short_list) std::printf("%-22s %-8s TYPE\n", "NAME", "ALIAS");
+            for (auto &r : rows) {
+                if (a.short_list) std::printf("%s\n", r[1]);
+                else std::printf("%-22s %-8s %s\n", r[0], r[1], r[2]);
+            }
+            return 0;
         }
-        const std::string solver = argv[2];
-        std::string file;
-        bool no_seed = false, best = false, stats = false;
-        int device = 0;
-        uint64_t seed = 1;
-        HeuristicOptions h;
-        LKOptions lk;
-        lk.heuristic = h;  // LKOptions::from_cli: heuristic = HeuristicOptions::from_cli (mod.rs:1321-1325)
-        for (int a = 3; a < argc; ++a) {
-            const std::string s = argv[a];
-            auto val = [&]() -> std::string {
-                if (a + 1 >= argc) throw std::runtime_error(s + ": missing value");
-                return argv[++a];
-            };
-            if (s == "-i" || s == "--input") file = val();
-            else if (s == "--no-seed") no_seed = true;
-            else if (s == "--best-sweep") best = true;
-            else if (s == "--stats") stats = true;
-            else if (s == "--seed") seed = std::stoull(val());
-            else if (s == "--device") device = std::stoi(val());
-            else if (s == "--epochs") h.epochs = lk.heuristic.epochs = std::stoull(val());
-            else if (s == "--platoo-epochs") h.platoo_epochs = lk.heuristic.platoo_epochs = std::stoull(val());
-            else if (s == "--n-nearest") h.n_nearest = lk.heuristic.n_nearest = std::stoull(val());
-            else if (s == "--max-depth") lk.max_depth = std::stoull(val());
-            else throw std::runtime_error("unknown argument " + s);
+        std::vector<Solvers> stages;
+        const bool json_mode = a.cmd == "solve" && a.output_format == "json";  // `pipeline` always prints text (main.rs:425,430)
+        if (a.cmd == "solve") {
+            std::string name = a.solver;
+            for (auto &ch : name) ch = (char)std::tolower((unsigned char)ch);
+            if (name == "fast") stages = {Solvers::NearestNeighbor, Solvers::TwoOpt};  // resolve_preset (main.rs:354-369)
+            else if (name == "classic" || name == "thorough") {
+                std::fprintf(stderr, "error: preset `%s` ends in simulated annealing, which this build does not accelerate\n", name.c_str());
+                return 1;
+            } else {
+                Solvers s;
+                std::string why;
+                if (!solver_from_str(name, s, why)) {
+                    std::fprintf(stderr, "error: %s: `%s`\n", why.c_str(), a.solver.c_str());
+                    return why == "unknown solver" ? 2 : 1;
+                }
+                // auto_expand_with_nn (mod.rs:129-139): deterministic local searches are seeded with a nearest-neighbour stage
+                const bool expand = s == Solvers::TwoOpt || s == Solvers::ThreeOpt || s == Solvers::LinKernighan || s == Solvers::OrOpt;
+                if (!a.no_seed && expand) stages = {Solvers::NearestNeighbor, s};
+                else stages = {s};
+            }
+        } else {
+            if (a.steps.empty()) {
+                std::fprintf(stderr, "error: pipeline: provide --steps (TOML --config files are not read by this façade)\n");
+                return 1;
+            }
+            stages = parse_steps(a.steps);
         }
-        if (h.n_nearest == 0) throw std::runtime_error("n_nearest must be >= 1");
-        std::string text;
-        tsplib::TspLibData data = file.empty() ? tsplib::read_from_string(std::string(std::istreambuf_iterator<char>(std::cin), {}))
-                                              : tsplib::read_from_file(file);
-        Context ctx(device);
+        for (const auto &w : pipeline::stage_warnings(stages)) std::fprintf(stderr, "warning: %s\n", w.c_str());
+
+        tsplib::TspLibData data;
+        if (a.file.empty()) {
+            try {
+                data = tsplib::read_from_string(std::string(std::istreambuf_iterator<char>(std::cin), {}));
+            } catch (const std::exception &e) {
+                std::fprintf(stderr, "Failed to read TSPLIB file from STDIN: \"%s\"\n", e.what());
+                return 1;
+            }
+        } else {
+            if (!std::ifstream(a.file)) {
+                std::fprintf(stderr, "File doesnt exists: \"%s\"\n", a.file.c_str());  // main.rs:715-718
+                return 1;
+            }
+            try {
+                data = tsplib::read_from_file(a.file);
+            } catch (const std::exception &e) {
+                std::fprintf(stderr, "Error in TSPLIB file: \"%s\"\n", e.what());
+                return 1;
+            }
+        }
+        if (!a.distance_type.empty()) {  // --distance-type (main.rs:461-471): euc_2d | geo
+            std::string d = a.distance_type;
+            for (auto &ch : d) ch = (char)std::tolower((unsigned char)ch);
+            if (d == "euc_2d" || d == "euc2d") data.distance_type = DistanceType::Euc2D;
+            else if (d == "geo") data.distance_type = DistanceType::Geo;
+            else {
+                std::fprintf(stderr, "error: --distance-type: unknown distance type `%s`\n", a.distance_type.c_str());
+                return 1;
+            }
+        }
+        Context ctx(a.device);
         TspProblem problem = data.problem(ctx);
-        // run_pipeline_stages (pipeline.rs:53-80): stage k+1 is warm-started with stage k's tour after validate_tour
-        std::vector<size_t> seed_route;
-        const std::vector<size_t> *init = nullptr;
-        if (solver != "nn" && !no_seed && problem.distance_type == DistanceType::Euc2D) {
-            Solution nn = nearest_neighbor::solve(ctx, problem, h, nullptr, nullptr);
-            if (!validate_tour(nn.route(), problem.cities)) throw std::runtime_error("pipeline: seed stage produced an invalid tour");
-            seed_route = nn.route();
-            init = &seed_route;
+        bool have_opt = false;
+        opt_tour::OptTour ot;
+        if (!a.optimal_tour.empty()) {
+            try {
+                ot = opt_tour::read_from_file(a.optimal_tour);
+                have_opt = true;
+            } catch (const std::exception &e) {
+                std::fprintf(stderr, "--optimal-tour: %s\n", e.what());  // main.rs:486-493: reported, then ignored
+            }
         }
-        Solution sol;
-        if (solver == "2opt") sol = two_opt::solve(ctx, problem, h, nullptr, init, best ? TL_MODE_BEST_SWEEP : TL_MODE_REF_ORDER);
-        else if (solver == "3opt") sol = three_opt::solve(ctx, problem, h, nullptr, init);
-        else if (solver == "oropt" || solver == "or_opt") sol = or_opt::solve(ctx, problem, h, nullptr, init);
-        else if (solver == "lk") sol = lin_kernighan::solve(ctx, problem, lk, nullptr, init, seed);
-        else if (solver == "nn") sol = nearest_neighbor::solve(ctx, problem, h, nullptr, nullptr);
-        else throw std::runtime_error("unknown solver `" + solver + "` (this build accelerates 2opt, 3opt, oropt, lk, nn)");
-        if (!validate_tour(sol.route(), problem.cities)) throw std::runtime_error("pipeline: solver produced an invalid tour");  // pipeline.rs:70-71
-        std::printf("%.5f %d\n", sol.total, 0);
-        for (size_t k = 0; k < sol.route().size(); ++k) std::printf(k ? " %zu" : "%zu", sol.route()[k]);
-        std::printf("\n");
-        if (stats)
-            std::fprintf(stderr, "sweeps=%llu candidates=%llu moves=%llu kernel_ms=%.3f total_ms=%.3f\n", (unsigned long long)sol.stats.sweeps,
-                         (unsigned long long)sol.stats.candidates, (unsigned long long)sol.stats.moves, sol.stats.kernel_ms, sol.stats.total_ms);
+        auto outcomes = pipeline::run_pipeline_stages(ctx, problem, stages, a.opt);
+        const Solution &tour = outcomes.back().solution;
+        if (!json_mode) std::fputs(cli::format_solution(tour, false).c_str(), stdout);
+        cli::OptimalComparison cmp;
+        const bool have_cmp = have_opt && cli::compute_optimal_comparison(ctx, tour.total, problem, ot, cmp);
+        if (json_mode) std::fputs(cli::format_solution_json(tour, false, have_cmp ? &cmp : nullptr).c_str(), stdout);
+        else if (have_cmp) std::fputs(cli::format_optimal_comparison(tour.total, cmp).c_str(), stderr);
+        if (a.stats)
+            for (const auto &o : outcomes)
+                std::fprintf(stderr, "stage %s: cost=%.5f sweeps=%llu candidates=%llu moves=%llu kernel_ms=%.3f wall_ms=%llu\n", solver_name(o.solver),
+                             o.solution.total, (unsigned long long)o.solution.stats.sweeps, (unsigned long long)o.solution.stats.candidates,
+                             (unsigned long long)o.solution.stats.moves, o.solution.stats.kernel_ms, (unsigned long long)o.duration_ms);
         return 0;
     } catch (const ReferencePanic &e) {
         std::fprintf(stderr, "thread 'main' panicked: %s\n", e.what());
