@@ -325,9 +325,9 @@ def main():
                                      "bytes": n * (n - 1) // 2 * 4}
         # the HBM-bound kernel of the path (DistanceMatrix::build): a roofline object of its own, traffic from its PMC passes
         rdm = {"bound": "hbm", "achieved": gb / (ms * 1e-3), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gb / (ms * 1e-3) / HBM_PEAK_GBPS,
-               "traffic": None, "kernel": "k_dm_build_packed_rows", "kernel_ms_avg": ms,
+               "traffic": None, "kernel": "k_dm_build_packed_blocked", "kernel_ms_avg": ms,
                "note": "4 B written per distance; a plain fill of the same 200 MB reaches 6.65 TB/s on this part (scripts/hbm_fill_probe.py), "
-                       "the build is at the VALU/HBM crossover (DESIGN.md §4.1)"}
+                       "row-blocked build: column coordinates loaded once per 4 rows (DESIGN.md §4.1)"}
         dpath = latest_profile("r*_dm_build_hbm_traffic.json")
         if dpath and n == 10000:
             try:

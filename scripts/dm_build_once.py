@@ -1,4 +1,4 @@
-"""One packed distance-matrix build at n = 10^4 (plus one warm-up) — the target of the rocprofv3 PMC passes for k_dm_build_packed_rows."""
+"""One packed distance-matrix build at n = 10^4 (plus one warm-up) — the target of the rocprofv3 PMC passes for k_dm_build_packed_blocked."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

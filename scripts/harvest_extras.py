@@ -39,7 +39,7 @@ for name in ("write", "fetch"):
 if len(vals) == 2:
     n = 10000
     json.dump({
-        "kernel": "k_dm_build_packed_rows", "n": n,
+        "kernel": "k_dm_build_packed_blocked", "n": n,
         "write_size_kb_raw": vals["write"], "fetch_size_kb_raw": vals["fetch"],
         "traffic_bytes_per_launch": (2 * vals["fetch"] + vals["write"]) * 1024,
         "algorithmic_bytes_per_launch": n * (n - 1) // 2 * 4,

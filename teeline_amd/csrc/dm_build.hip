@@ -37,6 +37,39 @@ __global__ __launch_bounds__(kDmThreads) void k_dm_build_packed_rows(const float
     }
 }
 
+// EUC_2D form of the same build: a workgroup takes kDmRows consecutive rows x (kDmThreads * kDmCols) columns.  The column
+// coordinates are loaded ONCE into registers and reused for every row of the block (the row's own point is a wave-uniform
+// scalar load), so the store loop holds no vector load at all.  tests/probes/dm_store_probe.hip takes the row kernel
+// apart at n = 10^4: the bare store pattern runs at the fill ceiling (33 us, 6.0 TB/s); the per-element coordinate load
+// costs +7.5 us (each iteration's load sits behind the previous iteration's store on the shared vmcnt counter, and 400 MB of
+// L2 -> L1 reads ride along with the 200 MB of writes); all the arithmetic of the correctly rounded distance only +3.5 us.
+// Blocking over rows removes the load term: 44.7 -> 34.6-37.5 us in the probe (4 rows x 1024 columns; 2, 3, 6, 8, 16 rows,
+// 512 / 2048 / 4096 columns, 16-byte stores and other workgroup sizes all measured, none faster).
+constexpr int kDmRows = 4, kDmCols = 4;
+__global__ __launch_bounds__(kDmThreads) void k_dm_build_packed_blocked(const float2 *__restrict__ xy, uint32_t n, float *__restrict__ out)
+{
+    const uint32_t i0 = blockIdx.x * kDmRows + 1u;  // row 0 of the strict lower triangle is empty
+    const uint32_t jb = blockIdx.y * (kDmThreads * kDmCols) + threadIdx.x;
+    const uint32_t ilast = (i0 + kDmRows - 1u < n - 1u) ? i0 + kDmRows - 1u : n - 1u;
+    if (blockIdx.y * (kDmThreads * kDmCols) >= ilast) return;  // the slab lies on or above the diagonal of every row of the block
+    float2 c[kDmCols];
+#pragma unroll
+    for (int p = 0; p < kDmCols; ++p) {
+        const uint32_t j = jb + (uint32_t)p * kDmThreads;
+        c[p] = xy[j < n ? j : n - 1u];  // clamped, never stored: no divergent load
+    }
+#pragma unroll 1
+    for (uint32_t i = i0; i <= ilast; ++i) {
+        const float2 a = xy[i];
+        float *__restrict__ row = out + (size_t)i * (i - 1u) / 2u;
+#pragma unroll
+        for (int p = 0; p < kDmCols; ++p) {
+            const uint32_t j = jb + (uint32_t)p * kDmThreads;
+            if (j < i) row[j] = dist(a, c[p]);  // cities[i].distance(cities[j]), j < i
+        }
+    }
+}
+
 // Does a caller's packed matrix hold exactly the EUC_2D distances of xy?  (The reference's DistanceMatrix does not
 // remember its DistanceType, distance_matrix.rs:86-93: a drop-in caller that only has `problem.distances` learns here
 // whether the on-the-fly coordinate kernels apply — bit for bit, NaN payloads aside — or the matrix kernels must run.)
@@ -119,7 +152,11 @@ hipError_t launch_dm_build(const float2 *xy, uint32_t n, int dist_kind, int layo
         const uint32_t per_row = kDmThreads * kDmPerThread;
         const dim3 grid(n - 1, (n - 1 + per_row - 1) / per_row);
         if (geo) hipLaunchKernelGGL(k_dm_build_packed_rows<true>, grid, dim3(kDmThreads), 0, s, xy, n, out);
-        else hipLaunchKernelGGL(k_dm_build_packed_rows<false>, grid, dim3(kDmThreads), 0, s, xy, n, out);
+        else {
+            const uint32_t cols = kDmThreads * kDmCols;
+            const dim3 gb((n - 1 + kDmRows - 1) / kDmRows, (n - 1 + cols - 1) / cols);
+            hipLaunchKernelGGL(k_dm_build_packed_blocked, gb, dim3(kDmThreads), 0, s, xy, n, out);
+        }
     } else {
         const uint32_t per = kDmThreads * kDmPerThread;
         dim3 grid(n, (n + per - 1) / per);

@@ -36,9 +36,8 @@ __device__ __forceinline__ float sqrt_rn_ref(float x) { return __builtin_sqrtf(x
 // smaller non-zero inputs take the compiler's full expansion under a wave-uniform branch.  ~9 VALU.
 // tl_selftest_sqrt compares it with sqrt_rn_ref over whole bit-pattern ranges on the device (tests/test_gpu_numerics.py
 // sweeps all 2^31 non-negative floats).
-__device__ __forceinline__ float sqrt_rn(float x)
+__device__ __forceinline__ float sqrt_rn_fast(float x)  // the fix-up alone: x = 0, +inf or x >= 2^-96 (callers check)
 {
-    if (__builtin_amdgcn_ballot_w64((x < 1.2621774e-29f) & (x != 0.0f))) return sqrt_rn_ref(x);  // 2^-96
     const float y = __builtin_amdgcn_sqrtf(x);
     const int yi = __builtin_bit_cast(int, y);
     const float yd = __builtin_bit_cast(float, yi - 1), yu = __builtin_bit_cast(float, yi + 1);
@@ -46,6 +45,12 @@ __device__ __forceinline__ float sqrt_rn(float x)
     float r = (rd <= 0.0f) ? yd : y;
     r = (ru > 0.0f) ? yu : r;
     return r;
+}
+
+__device__ __forceinline__ float sqrt_rn(float x)
+{
+    if (__builtin_amdgcn_ballot_w64((x < 1.2621774e-29f) & (x != 0.0f))) return sqrt_rn_ref(x);  // 2^-96
+    return sqrt_rn_fast(x);
 }
 
 __device__ __forceinline__ float dist(float2 p, float2 q) { return sqrt_rn(sqdist(p, q)); }
