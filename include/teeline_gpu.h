@@ -77,8 +77,12 @@ typedef enum tl_mode {
 #define TL_FLAG_LK_NO_SPLIT (1u << 3)      /* tl_lk: one lane per (t1, orientation) pair, no sub-search split               */
 #define TL_FLAG_LK_SPLIT2 (1u << 4)        /* tl_lk: two split levels (k(k+1) sub-searches per pair) instead of three       */
 #define TL_FLAG_LK_NO_SUBCHAINS (1u << 5)  /* tl_lk: the pick step walks the winning chain again instead of reading it      */
-#define TL_FLAG_KNN_4LANES (1u << 6)       /* candidate lists: four lanes per city (the form used beyond n = 32 K)          */
-#define TL_FLAG_KNN_1LANE (1u << 7)        /* candidate lists: one lane per city                                            */
+#define TL_FLAG_KNN_4LANES (1u << 6)       /* candidate lists: brute force, four lanes per city                              */
+#define TL_FLAG_KNN_1LANE (1u << 7)        /* candidate lists: brute force, one lane per city                                */
+#define TL_FLAG_KNN_BRUTE (1u << 10)       /* candidate lists: brute-force scan (sixteen lanes per city) in (distance, position)
+                                              order instead of the kd-tree walk — the same lists unless two candidates of a city
+                                              are at the same f32 distance (then the reference's order is the tree's visiting order) */
+#define TL_FLAG_LK_SMALL (1u << 9)         /* tl_lk: the LDS-resident single-workgroup form (default for small n) at every n it fits */
 /* The LDS-resident 2-opt kernel also counts the work its exact decision cascade really does (d_out_stats words 5..8: tile
  * bounds, candidates into L1 / L2 / L3).  Same results; ~8 % slower (the kernel is SGPR-bound), so bench.py uses it for one
  * untimed launch only. */
@@ -181,8 +185,10 @@ int tl_or_opt_find_best_move(tl_ctx *ctx, const float *xy, uint32_t n, const flo
                              int *found, float *delta, uint32_t *i, uint32_t *j, uint32_t *seg_len, int *reversed);
 
 /* ---- LK candidate lists: replaces lin_kernighan::build_candidates (lin_kernighan.rs:12-27) -- */
-/* out: n x min(k, n-1) u32, ascending f32 distance, ties -> lowest position (the reference's kd-tree tie
- * order is implementation-defined, kdtree.rs:63). */
+/* out: n x min(k, n-1) u32 — the k-NN buffer of the reference's kd-tree query per city (kdtree.rs:193-212, mod.rs:1839-1889):
+ * ascending f32 distance, equal distances in the tree's visiting order.  The tree is the reference's wherever its median
+ * selection is unambiguous (no points comparing Equal around a pivot, kdtree.rs:63,301-317); elsewhere the reference's tree is
+ * implementation-defined and the (coordinate value, position) order decides.  k <= 16. */
 int tl_build_candidates(tl_ctx *ctx, const float *xy, uint32_t n, uint32_t k, uint32_t *out);
 
 /* ---- NN seed: replaces nearest_neighbor::solve (nearest_neighbor.rs:8-76) ---------------------- */

@@ -12,8 +12,9 @@
  * One thing cannot be restated: partition_points uses `select_nth_unstable_by` (kdtree.rs:63), whose arrangement of
  * elements that compare Equal is an implementation detail of the Rust standard library.  The tree — and with it the
  * visiting order that breaks exact distance ties in the k-buffer — is unique exactly when no two points of a subtree
- * that straddle its median compare Equal on the split coordinate.  This file selects the median with a STABLE order
- * (Equal elements keep their current order) and reports through `*tie_free` whether that choice was ever exercised:
+ * that straddle its median compare Equal on the split coordinate.  This file's rule for that case (shared with the GPU
+ * product, teeline_amd/csrc/kdtree.hip): the points of a subtree are ordered by (exact coordinate value, position in the
+ * city array) and the element at len/2 is the pivot.  `*tie_free` reports whether the rule was ever exercised:
  * tie_free == 1 means the tree built here is the reference's tree, whatever its select implementation.
  */
 #include "tl_oracle.h"
@@ -43,7 +44,15 @@ static int cmp_coord(float a, float b)
     return a < b ? -1 : 1;
 }
 
-/* stable merge sort of positions by cmp_coord on `coord` (Equal keeps the current order) */
+/* (exact coordinate value, position) order: a total order, so the result does not depend on the incoming arrangement */
+static int before(const float *xy, uint32_t p, uint32_t q, int coord)
+{
+    const float a = xy[2 * p + coord], b = xy[2 * q + coord];
+    if (a < b) return 1;
+    if (b < a) return 0;
+    return p < q;
+}
+
 static void msort(const float *xy, uint32_t *v, uint32_t *tmp, uint32_t len, int coord)
 {
     if (len < 2) return;
@@ -52,7 +61,7 @@ static void msort(const float *xy, uint32_t *v, uint32_t *tmp, uint32_t len, int
     msort(xy, v + h, tmp, len - h, coord);
     uint32_t a = 0, b = h, w = 0;
     while (a < h && b < len) {
-        if (cmp_coord(xy[2 * v[b] + coord], xy[2 * v[a] + coord]) < 0) tmp[w++] = v[b++];
+        if (before(xy, v[b], v[a], coord)) tmp[w++] = v[b++];
         else tmp[w++] = v[a++];
     }
     while (a < h) tmp[w++] = v[a++];

@@ -6,9 +6,11 @@
  * never orders by id, so positions are an exact stand-in).
  *
  * Known, documented divergences:
- *  - candidate lists: the reference queries a kd-tree whose tie order is implementation-defined
- *    (kdtree.rs:63 select_nth_unstable_by); the oracle uses brute force, ascending distance,
- *    lowest position first on ties.  Identical whenever the k+1 nearest distances are distinct.
+ *  - candidate lists: the reference queries a kd-tree (restated in tl_oracle_kdtree.c); its tree is
+ *    implementation-defined only where select_nth_unstable_by (kdtree.rs:63) meets Equal elements around a median,
+ *    for which the oracle fixes the (coordinate value, position) order.  tlo_build_candidates below is the
+ *    brute-force scan in (distance, position) order: the same lists wherever no two candidates of a city are at
+ *    the same f32 distance; it serves the NN seed's rule and as a cross-check.
  *  - kicks: the reference draws from an unseeded thread RNG (lin_kernighan.rs:73); the oracle
  *    takes an explicit seed (splitmix64) so results are reproducible.
  */
@@ -356,7 +358,7 @@ int tlo_lin_kernighan_cand(const float *xy, const float *packed, uint32_t n, con
     uint32_t *candidate = (uint32_t *)malloc((size_t)n * sizeof(uint32_t));
     if (!cand || !candidate) { free(cand); free(candidate); return TLO_ERR_NOMEM; }
     if (cand_in) memcpy(cand, cand_in, (size_t)n * k * sizeof(uint32_t));
-    else tlo_build_candidates(xy, n, k, cand); /* :43 */
+    else tlo_build_candidates_kdtree(xy, n, k, cand, NULL); /* :43 build_candidates = kd-tree k-NN (tl_oracle_kdtree.c) */
 
     if (init) memcpy(out, init, (size_t)n * sizeof(uint32_t)); /* :45-46 */
     else tlo_nearest_neighbor(packed ? NULL : xy, packed, n, 3, out, NULL); /* :47-55 nearest_neighbor::solve(problem):

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libteeline_gpu.so")
 
-SOURCES = ["tl_api.hip", "two_opt_ref.hip", "two_opt_dm.hip", "dm_build.hip", "three_opt.hip", "lk.hip", "two_opt_best.hip", "or_opt.hip", "two_opt_large.hip"]
+SOURCES = ["tl_api.hip", "two_opt_ref.hip", "two_opt_dm.hip", "dm_build.hip", "three_opt.hip", "lk.hip", "two_opt_best.hip", "or_opt.hip", "two_opt_large.hip", "kdtree.hip"]
 HEADERS = ["tl_device.h", "tl_kernels.h", "two_opt_common.h", os.path.join(ROOT, "include", "teeline_gpu.h")]
 
 # -ffp-contract=off: the reference never fuses mul+add (src/tsp/kdtree.rs:291-295); bit-exact parity
@@ -74,5 +74,8 @@ def build_cli(force=False):
 
 
 if __name__ == "__main__":
+    if "--tune" in sys.argv:  # tuning variant: reads TL_* knobs from the environment (never the product library)
+        print(build(force=True, verbose=True, extra_flags=["-DTL_TUNE"], out=os.path.join(HERE, "libteeline_gpu_tune.so")))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_cli(force="--force" in sys.argv))

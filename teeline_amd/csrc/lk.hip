@@ -544,16 +544,44 @@ struct LkSeg {
 
 }  // namespace
 
-__global__ __launch_bounds__(kLkNT) void k_lk_solve(LkArgs G)
+// The whole ILS in ONE persistent workgroup of NT threads.  SMALL: every array the search touches — coordinates, candidate
+// lists, tour, scratch tour, rank, successor, predecessor, scan order, best tour — lives in this CU's LDS (n (36 + 4k)
+// bytes), so a node of the chain search costs LDS latencies and a move costs no kernel boundary.  Built as the candidate
+// for small instances and MEASURED SLOWER than the chip-wide scans at every size: berlin52 with the
+// CLI's options (3 327 scans) 129 ms against 80 ms, a280 517 against 349 ms, n = 1 500 933 against 58 ms
+// (scripts/timing_lk.py, 64 / 256 / 1024 threads) — what a scan costs here is the single-lane stretches (segment table of
+// apply_lk_chain, the ordered cost sum), not memory latency.  Kept as TL_FLAG_LK_SMALL, a cross-check of the state machine.
+// !SMALL: the same code on the global arrays (TL_FLAG_LK_ONE_WORKGROUP).
+template <int NT, bool SMALL>
+__global__ __launch_bounds__(NT) void k_lk_solve(LkArgs G)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lk_small_smem[];
     __shared__ uint32_t s_key, s_clen, s_nseg, s_flag;
     __shared__ uint32_t s_chain[kLkMaxChain];
     __shared__ LkSeg s_seg[2 * (kLkMaxDepth + 2)];
-    __shared__ float s_part[kLkNT];
+    __shared__ float s_part[NT];
+    constexpr uint32_t kLkNT = NT;  // shadows the file-level constant inside this kernel
     const uint32_t tid = threadIdx.x, n = G.n;
     uint32_t *tour = G.tour, *alt = G.alt, *pos = G.pos, *next = G.next, *prev = G.prev;
     uint32_t *city_ids = G.city_ids, *best = G.best;
-    const float2 *__restrict__ xy = G.xy;
+    const float2 *xy = G.xy;
+    const uint32_t *cand = G.cand;
+    if (SMALL) {
+        float2 *lxy = reinterpret_cast<float2 *>(lk_small_smem);
+        uint32_t *w = reinterpret_cast<uint32_t *>(lk_small_smem + (size_t)n * 8);
+        uint32_t *lcand = w;
+        w += (size_t)n * G.k;
+        tour = w; alt = w + n; pos = w + 2 * (size_t)n; next = w + 3 * (size_t)n; prev = w + 4 * (size_t)n;
+        city_ids = w + 5 * (size_t)n; best = w + 6 * (size_t)n;
+        for (uint32_t r = tid; r < n; r += kLkNT) {
+            lxy[r] = G.xy[r];
+            tour[r] = G.tour[r];
+        }
+        for (size_t e = tid; e < (size_t)n * G.k; e += kLkNT) lcand[e] = G.cand[e];
+        xy = lxy;
+        cand = lcand;
+        __syncthreads();
+    }
     uint64_t scans = 0, searches = 0, moves = 0, exchanged = 0;
 
     auto rebuild = [&](const uint32_t *t) {  // make_pos + flat_to_next_prev (:110-145)
@@ -595,7 +623,7 @@ __global__ __launch_bounds__(kLkNT) void k_lk_solve(LkArgs G)
         __syncthreads();
         while (true) {
             rebuild(tour);  // :470
-            LkView V{xy, G.cand, next, G.k, G.max_depth};
+            LkView V{xy, cand, next, G.k, G.max_depth};
             bool found_any = false;
             for (uint32_t base = 0; base < 2u * n; base += kLkNT) {  // find_lk_move (:345-389) in its own order
                 if (tid == 0) s_key = 0xFFFFFFFFu;
@@ -729,6 +757,8 @@ __global__ __launch_bounds__(kLkNT) void k_lk_solve(LkArgs G)
         for (uint32_t r = tid; r < n; r += kLkNT) best[r] = tour[r];
     }
     __syncthreads();
+    if (SMALL)
+        for (uint32_t r = tid; r < n; r += kLkNT) G.best[r] = best[r];
     if (tid == 0) {
         G.counters[0] = scans;
         G.counters[1] = searches;
@@ -1379,10 +1409,23 @@ hipError_t launch_nn_seed_dm(const float *dm, uint32_t n, uint32_t *path, int ld
     return hipGetLastError();
 }
 
-hipError_t launch_lk_solve(const LkArgs &G, hipStream_t s)
+size_t lk_small_lds_bytes(uint32_t n, uint32_t k) { return (size_t)n * (36u + 4u * (size_t)k) + 16u; }
+
+hipError_t launch_lk_solve(const LkArgs &G, hipStream_t s, bool small, int threads)
 {
-    hipLaunchKernelGGL(k_lk_solve, dim3(1), dim3(kLkNT), 0, s, G);
-    return hipGetLastError();
+    if (!small) {
+        hipLaunchKernelGGL((k_lk_solve<kLkNT, false>), dim3(1), dim3(kLkNT), 0, s, G);
+        return hipGetLastError();
+    }
+    const size_t lds = lk_small_lds_bytes(G.n, G.k);
+    auto go = [&](auto kern, int nt) -> hipError_t {
+        hipError_t e = allow_max_lds(reinterpret_cast<const void *>(kern));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(1), dim3(nt), lds, s, G);
+        return hipGetLastError();
+    };
+    (void)threads;  // 64 / 256 / 1024 threads measured (scripts/timing_lk.py): 256 is the best of the three up to n ~ 300
+    return go(k_lk_solve<256, true>, 256);
 }
 
 }  // namespace tl

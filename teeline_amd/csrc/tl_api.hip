@@ -30,7 +30,7 @@ struct tl_ctx {
     int cus = 0, lds_bytes = 0;
     std::string arch;
     std::string err;
-    DevBuf xy, dm, init, out_pos, out_cost, out_stats, misc, work, dmfull;
+    DevBuf xy, dm, init, out_pos, out_cost, out_stats, misc, work, dmfull, kd;
     uint32_t dm_n = 0;
     int dm_layout = -1;
 };
@@ -38,6 +38,8 @@ struct tl_ctx {
 static thread_local std::string g_create_err;  // tl_last_error(NULL): the calling thread's last tl_create failure
 
 static int knn_form(const tl_ctx *c);
+// lin_kernighan cut-over (measured): the LDS-resident single workgroup never wins -> 0
+static constexpr uint32_t kLkSmallMaxN = 0, kLkSmallWave64MaxN = 0, kLkSmall256MaxN = 0;
 
 static int fail(tl_ctx *c, int code, const char *fmt, ...)
 {
@@ -133,7 +135,7 @@ extern "C" void tl_destroy(tl_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->xy, &c->dm, &c->init, &c->out_pos, &c->out_cost, &c->out_stats, &c->misc, &c->work, &c->dmfull})
+    for (DevBuf *b : {&c->xy, &c->dm, &c->init, &c->out_pos, &c->out_cost, &c->out_stats, &c->misc, &c->work, &c->dmfull, &c->kd})
         if (b->p) (void)hipFree(b->p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1013,7 +1015,28 @@ extern "C" int tl_or_opt(tl_ctx *c, const float *xy, uint32_t n, const float *dm
 }
 
 static bool max_depth_ge2_split(uint32_t) { return true; }
-static int knn_form(const tl_ctx *c) { return (c->flags & TL_FLAG_KNN_1LANE) ? 1 : (c->flags & TL_FLAG_KNN_4LANES) ? 4 : 0; }  // the split scan handles every max_depth >= 1
+static int knn_form(const tl_ctx *c) { return (c->flags & TL_FLAG_KNN_1LANE) ? 1 : (c->flags & TL_FLAG_KNN_4LANES) ? 4 : 0; }
+
+// lin_kernighan::build_candidates (lin_kernighan.rs:12-27) into d_cand (n x k): the reference's kd-tree k-NN — tree built on
+// the host from the caller's coordinates, queried on the device (kdtree.hip) — or, under the TL_FLAG_KNN_* flags, the
+// brute-force scan in (distance, position) order (identical lists wherever no two candidates of a city tie in f32 distance).
+// d_xy must already hold xy (enqueued on c->stream).
+static int build_candidates_dev(tl_ctx *c, const float *xy_host, const float2 *d_xy, uint32_t n, uint32_t k, uint32_t *d_cand)
+{
+    if (k == 0) return TL_OK;
+    if (c->flags & (TL_FLAG_KNN_BRUTE | TL_FLAG_KNN_4LANES | TL_FLAG_KNN_1LANE)) {
+        HIPCHK(c, launch_knn(d_xy, n, k, d_cand, c->stream, knn_form(c)));
+        return TL_OK;
+    }
+    std::vector<KdNode> nodes;
+    kdtree_build_host(xy_host, n, nodes);
+    int rc;
+    if ((rc = ensure(c, c->kd, nodes.size() * sizeof(KdNode)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->kd.p, nodes.data(), nodes.size() * sizeof(KdNode), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_knn_kdtree((const KdNode *)c->kd.p, d_xy, n, k, d_cand, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // `nodes` (pageable host memory) goes out of scope
+    return TL_OK;
+}  // the split scan handles every max_depth >= 1
 
 // ------------------------------------------------------------------------------------------------
 // candidate lists, NN seed, Lin-Kernighan
@@ -1029,7 +1052,7 @@ extern "C" int tl_build_candidates(tl_ctx *c, const float *xy, uint32_t n, uint3
     int rc;
     if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->misc, (size_t)n * k * 4))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, launch_knn((const float2 *)c->xy.p, n, k, (uint32_t *)c->misc.p, c->stream, knn_form(c)));
+    if ((rc = build_candidates_dev(c, xy, (const float2 *)c->xy.p, n, k, (uint32_t *)c->misc.p))) return rc;
     HIPCHK(c, hipMemcpyAsync(out, c->misc.p, (size_t)n * k * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return TL_OK;
@@ -1144,7 +1167,20 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const float *dm_pac
                  o_chains = o_state + 256;
     // default: scans spread over all CUs; TL_FLAG_LK_ONE_WORKGROUP runs the whole ILS in one persistent workgroup instead
     // (kept as a cross-check of the state machine)
-    const bool multi_cu = !(c->flags & TL_FLAG_LK_ONE_WORKGROUP);
+    // An LDS-resident single-workgroup form (k_lk_solve<NT, true>) exists for small instances; measured on MI355X it loses to
+    // the chip-wide scans at every size (scripts/timing_lk.py), so the cut-over kLkSmallMaxN is 0 and the
+    // form only runs under TL_FLAG_LK_SMALL (a cross-check).
+    const uint32_t k_small = o.n_nearest > n - 1 ? n - 1 : o.n_nearest;
+    uint32_t small_max_n = kLkSmallMaxN;
+    int small_nt = n <= kLkSmallWave64MaxN ? 64 : (n <= kLkSmall256MaxN ? 256 : 1024);
+#ifdef TL_TUNE  // tuning builds only (python -m teeline_amd.build --tune): the product library never reads the environment
+    if (const char *e = getenv("TL_LK_SMALL_MAX_N")) small_max_n = (uint32_t)atoi(e);
+    if (const char *e = getenv("TL_LK_SMALL_NT")) small_nt = atoi(e);
+#endif
+    const uint32_t variant_flags = TL_FLAG_LK_ONE_WORKGROUP | TL_FLAG_LK_NO_SPLIT | TL_FLAG_LK_SPLIT2 | TL_FLAG_LK_NO_SUBCHAINS;
+    const bool lk_small = ((c->flags & TL_FLAG_LK_SMALL) || (!(c->flags & variant_flags) && n <= small_max_n)) &&
+                          lk_small_lds_bytes(n, k_small) + 4096 <= (size_t)c->lds_bytes;
+    const bool multi_cu = !(c->flags & TL_FLAG_LK_ONE_WORKGROUP) && !lk_small;
     const size_t o_pairmin = o_chains + (multi_cu ? up((size_t)2 * n * lk_chain_slot_words() * 4) : 0);
     const bool split_scan = multi_cu && max_depth_ge2_split(o.max_depth) && !(c->flags & TL_FLAG_LK_NO_SPLIT);
     // every successful sub-search keeps its chain (64 B) so that the pick step does not walk the winner again; sized for
@@ -1178,7 +1214,7 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const float *dm_pac
         // lin_kernighan.rs:47-55: nearest_neighbor::solve with HeuristicOptions::default() (n_nearest = 3)
         if ((rc = nn_seed_dev(c, (const float2 *)c->xy.p, n, 3, (uint32_t *)(w + o_tour)))) return rc;
     }
-    if (k) HIPCHK(c, launch_knn((const float2 *)c->xy.p, n, k, (uint32_t *)(w + o_cand), c->stream, knn_form(c)));  // :43 build_candidates
+    if ((rc = build_candidates_dev(c, xy, (const float2 *)c->xy.p, n, k, (uint32_t *)(w + o_cand)))) return rc;  // :43 build_candidates
     HIPCHK(c, hipMemsetAsync(w + o_cnt, 0, 64, c->stream));
     LkArgs G{};
     G.xy = (const float2 *)c->xy.p;
@@ -1206,7 +1242,7 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const float *dm_pac
     if (split_scan) HIPCHK(c, hipMemsetAsync(G.pairmin, 0xFF, (size_t)2 * n * 4, c->stream));
     uint64_t cnt[4] = {0, 0, 0, 0};
     if (!multi_cu) {
-        HIPCHK(c, launch_lk_solve(G, c->stream));
+        HIPCHK(c, launch_lk_solve(G, c->stream, lk_small, small_nt));
     } else {
         HIPCHK(c, launch_lk_begin(G, c->stream));
         LkState hs{};

@@ -176,10 +176,25 @@ struct LkArgs {
 hipError_t launch_knn(const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, hipStream_t s, int form = 0);
 hipError_t launch_nn_seed(const float2 *xy, uint32_t n, const uint32_t *cand, uint32_t k, uint32_t *path, int lds_bytes, hipStream_t s);
 hipError_t launch_nn_seed_dm(const float *dm, uint32_t n, uint32_t *path, int lds_bytes, hipStream_t s);
-hipError_t launch_lk_solve(const LkArgs &G, hipStream_t s);
+// small: the LDS-resident form (n (36 + 4k) bytes of LDS, lk_small_lds_bytes) with `threads` in {64, 256, 1024}
+hipError_t launch_lk_solve(const LkArgs &G, hipStream_t s, bool small = false, int threads = 1024);
+size_t lk_small_lds_bytes(uint32_t n, uint32_t k);
 hipError_t launch_lk_begin(const LkArgs &G, hipStream_t s);
 hipError_t launch_lk_round(const LkArgs &G, hipStream_t s);
 size_t lk_chain_slot_words();
+
+// kdtree.hip — build_candidates through the reference's kd-tree (kdtree.rs)
+struct KdNode {
+    float x, y;           // the node's point
+    int32_t left, right;  // node indices, -1 = None
+    uint32_t pos;         // its position in the city array (= KDPoint.id of build_candidates' cities)
+    uint32_t coord;       // depth % 2
+};
+}  // namespace tl
+#include <vector>
+namespace tl {
+bool kdtree_build_host(const float *xy, uint32_t n, std::vector<KdNode> &nodes);  // returns tie_free
+hipError_t launch_knn_kdtree(const KdNode *nodes, const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, hipStream_t s);
 
 // dm_build.hip
 hipError_t launch_dm_build(const float2 *xy, uint32_t n, int dist, int layout, float *out, hipStream_t s);

@@ -31,16 +31,21 @@ def test_candidate_lists(ctx, k, tsplib_dir):
     import teeline_amd as TA
     sets = [T.parse_tsplib(os.path.join(tsplib_dir, "berlin52.tsp"))["xy"], O.synth_xy(1000, seed=3), lattice(9, 1),
             O.synth_xy(4, seed=2)]
+    sets.append(T.parse_tsplib(os.path.join(tsplib_dir, "a280.tsp"))["xy"])       # lattice: most rows hold distance ties
+    sets.append(np.concatenate([lattice(6, 2), lattice(6, 2)[:9]]).astype(np.float32))  # duplicates
+    sets.append(np.array([[0, 0], [0, 0], [0, 0]], np.float32))                     # test_kdtree_duplicate_coordinates
     for xy in sets:
+        # the reference's lists: kd-tree k-NN buffer per city (kdtree.rs:193-212), equal distances in visiting order
         got = TA.lin_kernighan.build_candidates(prob(xy), k, ctx=ctx)
-        want = O.build_candidates(xy, k)
+        want, _ = O.build_candidates_kdtree(xy, k)
         assert got.shape == want.shape and np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("flag", ["TL_FLAG_KNN_4LANES", "TL_FLAG_KNN_1LANE"])
+@pytest.mark.parametrize("flag", ["TL_FLAG_KNN_BRUTE", "TL_FLAG_KNN_4LANES", "TL_FLAG_KNN_1LANE"])
 def test_candidate_list_builders_agree(flag):
-    # default: sixteen lanes per city; TL_FLAG_KNN_4LANES: the four-lane form used beyond n = 32 K; TL_FLAG_KNN_1LANE: one
-    # lane per city — all must give the oracle's lists (ascending f32 distance, ties -> lowest position), duplicates included
+    # the brute-force builders (TL_FLAG_KNN_BRUTE: sixteen lanes per city; _4LANES; _1LANE) scan in position order: the
+    # oracle's scan lists (ascending f32 distance, ties -> lowest position), duplicates included — and the kd-tree walk's
+    # lists wherever no distances tie
     import teeline_amd as TA
     dup = np.concatenate([lattice(7, 3), lattice(7, 3)[:20]]).astype(np.float32)
     with TA.Context(0, getattr(TA, flag)) as c2:
@@ -48,6 +53,8 @@ def test_candidate_list_builders_agree(flag):
             for k in (1, 4, 7, 16):
                 got = TA.lin_kernighan.build_candidates(prob(xy), k, ctx=c2)
                 assert np.array_equal(got, O.build_candidates(xy, k))
+        rnd = O.synth_xy(3000, seed=4)
+        assert np.array_equal(TA.lin_kernighan.build_candidates(prob(rnd), 5, ctx=c2), O.build_candidates_kdtree(rnd, 5)[0])
 
 
 def test_nearest_neighbor_seed(ctx, tsplib_dir):
@@ -150,7 +157,7 @@ def test_lk_variants_are_identical(tsplib_dir):
     sq = np.array([[0, 0], [1, 1], [1, 0], [0, 1]], np.float32)
     tri = np.array([[0, 0], [1, 0], [0.5, 1]], np.float32)
     import teeline_amd as TA
-    for flag in (TA.TL_FLAG_LK_NO_SPLIT, TA.TL_FLAG_LK_ONE_WORKGROUP, TA.TL_FLAG_LK_NO_SUBCHAINS, TA.TL_FLAG_LK_SPLIT2):
+    for flag in (TA.TL_FLAG_LK_NO_SPLIT, TA.TL_FLAG_LK_ONE_WORKGROUP, TA.TL_FLAG_LK_NO_SUBCHAINS, TA.TL_FLAG_LK_SPLIT2, TA.TL_FLAG_LK_SMALL):
         with TA.Context(0, flag) as ctx:
             for seed in (1, 2):
                 assert_same(gpu_lk(ctx, xy, seed=seed), O.lin_kernighan(xy, seed=seed))
