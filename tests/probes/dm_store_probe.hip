@@ -115,6 +115,38 @@ static float run_blocked_x4(const float2 *xy, uint32_t n, float *out)
     return time_us_fn([&] { hipLaunchKernelGGL((k_rows_blocked_x4<R, THREADS>), grid, dim3(THREADS), 0, 0, xy, n, out); });
 }
 
+// blocked, with the column slab on blockIdx.x (consecutive workgroups write adjacent 4 KB pieces of the same rows)
+template <int R, int P, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_rows_blocked_swapped(const float2 *__restrict__ xy, uint32_t n, float *__restrict__ out)
+{
+    const uint32_t i0 = blockIdx.y * R + 1u;
+    const uint32_t jb = blockIdx.x * (THREADS * P) + threadIdx.x;
+    const uint32_t ilast = (i0 + R - 1u < n - 1u) ? i0 + R - 1u : n - 1u;
+    if (blockIdx.x * (THREADS * P) >= ilast) return;
+    float2 c[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const uint32_t j = jb + (uint32_t)p * THREADS;
+        c[p] = xy[j < n ? j : n - 1u];
+    }
+#pragma unroll 1
+    for (uint32_t i = i0; i <= ilast; ++i) {
+        const float2 a = xy[i];
+        float *__restrict__ row = out + (size_t)i * (i - 1u) / 2u;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const uint32_t j = jb + (uint32_t)p * THREADS;
+            if (j < i) row[j] = dist(a, c[p]);
+        }
+    }
+}
+template <int R, int P, int THREADS>
+static float run_blocked_swapped(const float2 *xy, uint32_t n, float *out)
+{
+    const dim3 grid((n - 1 + THREADS * P - 1) / (THREADS * P), (n - 1 + R - 1) / R);
+    return time_us_fn([&] { hipLaunchKernelGGL((k_rows_blocked_swapped<R, P, THREADS>), grid, dim3(THREADS), 0, 0, xy, n, out); });
+}
+
 template <int R, int P, int THREADS>
 static float run_blocked(const float2 *xy, uint32_t n, float *out)
 {
@@ -182,6 +214,12 @@ int main()
     line("rows 256x40: full (one workgroup per row)", run_rows<4, 40, 256>(xy, n, out));
     line("rows 1024x10: full (one workgroup per row)", run_rows<4, 10, 1024>(xy, n, out));
     line("rows 512x8: full", run_rows<4, 8, 512>(xy, n, out));
+    line("swapped R=4 P=4 T=256", run_blocked_swapped<4, 4, 256>(xy, n, out));
+    line("swapped R=8 P=4 T=256", run_blocked_swapped<8, 4, 256>(xy, n, out));
+    line("swapped R=4 P=2 T=256", run_blocked_swapped<4, 2, 256>(xy, n, out));
+    line("swapped R=4 P=8 T=256", run_blocked_swapped<4, 8, 256>(xy, n, out));
+    line("blocked R=4  P=4 T=256 (ref)", run_blocked<4, 4, 256>(xy, n, out));
+    line("swapped R=4 P=4 T=256 (again)", run_blocked_swapped<4, 4, 256>(xy, n, out));
     line("blocked R=2  P=4 T=256", run_blocked<2, 4, 256>(xy, n, out));
     line("blocked R=2  P=8 T=256", run_blocked<2, 8, 256>(xy, n, out));
     line("blocked R=3  P=4 T=256", run_blocked<3, 4, 256>(xy, n, out));

@@ -31,6 +31,23 @@ with TA.Context(0) as ctx:
         if not ok:
             fails += 1
             print(f"LK MISMATCH seed={seed} n={n} kind={kind} k={k} depth={depth} epochs={epochs}: gpu {float(sol.total)!r} {sol.stats} vs oracle {float(cost)!r} {st}", flush=True)
+        # candidate lists: the kd-tree walk against the oracle's restated kd-tree (lattices and clusters hold distance ties)
+        kc = int(rng.integers(1, 17))
+        got = TA.lin_kernighan.build_candidates(TA.TspProblem(np.arange(n), xy), kc, ctx=ctx)
+        want, _ = O.build_candidates_kdtree(xy, kc)
+        runs += 1
+        if not np.array_equal(got, want):
+            fails += 1
+            print(f"KNN MISMATCH seed={seed} n={n} kind={kind} k={kc}: {int((got != want).any(axis=1).sum())} rows", flush=True)
+        if n <= 400 and seed % 3 == 0:  # NN seed over a matrix (GEO / EXPLICIT problems)
+            packed = O.dm_build_packed(xy)
+            pm = TA.TspProblem(np.arange(n), xy, TA.distance_matrix.DistanceMatrix(n, packed, np.arange(n), "explicit"))
+            nnm = TA.nearest_neighbor.solve(pm, TA.HeuristicOptions(n_nearest=3), ctx=ctx)
+            rc, r3, c3 = O.nearest_neighbor(None, packed, n, 3)
+            runs += 1
+            if list(nnm.route()) != r3.tolist() or np.float32(nnm.total).tobytes() != np.float32(c3).tobytes():
+                fails += 1
+                print(f"NN-DM MISMATCH seed={seed} n={n} kind={kind}", flush=True)
         kk = int(rng.integers(0, 9))
         nn = TA.nearest_neighbor.solve(TA.TspProblem(np.arange(n), xy), TA.HeuristicOptions(n_nearest=max(kk, 1)), ctx=ctx)
         rc, r2, c2 = O.nearest_neighbor(xy, None, n, max(kk, 1))
