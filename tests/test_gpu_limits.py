@@ -1,0 +1,187 @@
+"""Size limits and degenerate inputs of every entry point (-m gpu): the largest n each kernel form takes, one past it
+(TL_ERR_UNSUPPORTED, never a HIP error or a wrong answer), and the empty / tiny inputs the reference special-cases.
+Where the oracle would need minutes, size-independent properties stand in: valid tour, endpoints of the open path fixed,
+fixed point of one more reference sweep, cost == tour_length, reported delta == cost difference."""
+import numpy as np
+import pytest
+
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def len64(xy, tour):
+    p = np.asarray(xy, dtype=np.float64)[np.asarray(tour, dtype=np.int64)]
+    d = p - np.roll(p, -1, axis=0)
+    return float(np.sqrt((d * d).sum(axis=1)).sum())
+
+
+def prob(xy, packed=None):
+    import teeline_amd as TA
+    n = len(xy)
+    dm = None if packed is None else TA.distance_matrix.DistanceMatrix(n, packed, np.arange(n), "explicit")
+    return TA.TspProblem(np.arange(n), xy, dm)
+
+
+def test_two_opt_size_limits(ctx):
+    import teeline_amd as TA
+    nmax = ctx.two_opt_lds_max_n()
+    assert 15000 <= nmax <= 16384
+    # the LDS kernel at its limit and the HBM-resident form one city later: both from the NN seed, checked as fixed points
+    for n in (nmax, nmax + 1):
+        xy = O.synth_xy(n, seed=11)
+        rc, nn, cnn = O.nearest_neighbor(xy, None, n, 3)
+        sol = TA.two_opt.solve(prob(xy), None, None, [int(v) for v in nn], ctx=ctx)
+        route = np.asarray(sol.route(), dtype=np.uint32)
+        assert O.validate_tour(route) and route[0] == nn[0] and route[-1] == nn[-1] and sol.total < cnn
+        rc, again, c2, st2 = O.two_opt(xy, None, n, init=route, max_candidates=1)   # one reference sweep: nothing left to improve
+        assert st2["moves"] == 0 and np.float32(c2).tobytes() == np.float32(sol.total).tobytes()
+        assert sol.stats["candidates"] == sol.stats["sweeps"] * ((n - 3) * (n - 2) // 2)
+    # packed (i, j) keys: 65 535 cities is the last size (next test), 65 536 is refused before anything is launched
+    with pytest.raises(TA.TeelineGpuError) as e:
+        TA.two_opt.solve(prob(O.synth_xy(65536, seed=13)), None, None, None, ctx=ctx)
+    assert e.value.code == TA._capi.TL_ERR_UNSUPPORTED
+    # multi-start / population are LDS-only
+    with pytest.raises(TA.TeelineGpuError) as e:
+        TA.two_opt.multistart(prob(O.synth_xy(nmax + 1, seed=11)), 2, seed=1, ctx=ctx)
+    assert e.value.code == TA._capi.TL_ERR_UNSUPPORTED
+
+
+def test_two_opt_largest_instance_from_a_good_tour(ctx):
+    # n = 65 535 through the HBM-resident path from a space-filling start (strips of the NN seed are too slow on the CPU
+    # oracle at this size): the result must be a valid tour, not longer than the start, and a fixed point of the reference sweep
+    import teeline_amd as TA
+    n = 65535
+    xy = O.synth_xy(n, seed=12)
+    order = np.lexsort((np.where((xy[:, 0] // 25).astype(np.int64) % 2 == 0, xy[:, 1], -xy[:, 1]), (xy[:, 0] // 25).astype(np.int64))).astype(np.uint32)
+    start_cost = O.tour_length(xy, None, order)
+    sol = TA.two_opt.solve(prob(xy), None, None, [int(v) for v in order], ctx=ctx)
+    route = np.asarray(sol.route(), dtype=np.uint32)
+    assert O.validate_tour(route) and route[0] == order[0] and route[-1] == order[-1] and sol.total <= start_cost
+    assert np.float32(sol.total).tobytes() == O.tour_length(xy, None, route).tobytes()
+    rc, again, c2, st2 = O.two_opt(xy, None, n, init=route, max_candidates=1)
+    assert st2["moves"] == 0
+
+
+def test_matrix_form_size_limit(ctx):
+    import teeline_amd as TA
+    n = 19000  # 8 B of LDS per city: below the ~19 900 limit; 1.4 GB full matrix in the workspace
+    xy = O.synth_xy(n, seed=3)
+    packed = TA.distance_matrix.build(np.arange(n), xy, ctx=ctx).items
+    rc, nn, cnn = O.nearest_neighbor(xy, None, n, 3)
+    sol = TA.two_opt.solve(prob(xy, packed), None, None, [int(v) for v in nn], ctx=ctx)
+    ref = TA.two_opt.solve(prob(xy), None, None, [int(v) for v in nn], ctx=ctx)      # the coordinate form is the cross-check
+    assert sol.route() == ref.route() and sol.total == ref.total and sol.stats["moves"] == ref.stats["moves"]
+    with pytest.raises(TA.TeelineGpuError) as e:
+        big = 21000
+        xyb = O.synth_xy(big, seed=4)
+        TA.two_opt.solve(prob(xyb, TA.distance_matrix.build(np.arange(big), xyb, ctx=ctx).items), None, None, None, ctx=ctx)
+    assert e.value.code == TA._capi.TL_ERR_UNSUPPORTED
+
+
+def test_three_opt_and_or_opt_limits(ctx):
+    import teeline_amd as TA
+    # 3-opt: the pick kernel stages the tour in LDS (4 B per city): n <= (160 KB - 2 KB) / 4; one past it is refused up front
+    lds = ctx.device_info()["lds_bytes"]
+    n3 = (lds - 2048) // 4
+    with pytest.raises(TA.TeelineGpuError) as e:
+        TA.three_opt.find_best_move(prob(O.synth_xy(n3 + 1, seed=5)), np.arange(n3 + 1), ctx=ctx)
+    assert e.value.code == TA._capi.TL_ERR_UNSUPPORTED
+    # a large scan the oracle cannot afford: the reported savings must be the cost difference of the applied move
+    n = 6000
+    xy = O.synth_xy(n, seed=6)
+    rc, nn, cnn = O.nearest_neighbor(xy, None, n, 3)
+    mv = TA.three_opt.find_best_move(prob(xy), nn, ctx=ctx)
+    assert mv is not None
+    rc, after = O.apply_3opt(nn, *mv[:4])
+    assert rc == 0 and O.validate_tour(after)
+    assert abs(len64(xy, nn) - len64(xy, after) - float(mv[4])) < 0.01 and mv[4] > 0
+    # Or-opt: the packed loop-order key 6 n^2 < 2^32 -> n <= 26 754
+    with pytest.raises(TA.TeelineGpuError) as e:
+        TA.or_opt.find_best_move(prob(O.synth_xy(26755, seed=7)), np.arange(26755), ctx=ctx)
+    assert e.value.code == TA._capi.TL_ERR_UNSUPPORTED
+    n = 26754
+    xy = O.synth_xy(n, seed=8)
+    rc, nn, cnn = O.nearest_neighbor(xy, None, n, 3)
+    mv = TA.or_opt.find_best_move(prob(xy), nn, ctx=ctx)
+    assert mv is not None and mv[0] < -1e-3
+    rc, after = O.apply_relocation(nn, mv[1], mv[3], mv[2], mv[4])
+    assert rc == 0 and O.validate_tour(after)
+    assert abs(len64(xy, after) - len64(xy, nn) - float(mv[0])) < 0.01
+
+
+def test_candidate_lists_and_nn_seed_at_large_n(ctx):
+    import teeline_amd as TA
+    n = 150000
+    xy = O.synth_xy(n, seed=9)
+    got = TA.lin_kernighan.build_candidates(prob(xy), 8, ctx=ctx)
+    want, _ = O.build_candidates_kdtree(xy, 8)
+    assert np.array_equal(got, want)
+    k16 = TA.lin_kernighan.build_candidates(prob(xy[:5000]), 16, ctx=ctx)
+    assert np.array_equal(k16, O.build_candidates_kdtree(xy[:5000], 16)[0])
+    with pytest.raises(TA.TeelineGpuError) as e:
+        TA.lin_kernighan.build_candidates(prob(xy[:100]), 17, ctx=ctx)
+    assert e.value.code == TA._capi.TL_ERR_UNSUPPORTED
+    n2 = 40000
+    sol = TA.nearest_neighbor.solve(prob(xy[:n2]), ctx=ctx)
+    rc, route, c = O.nearest_neighbor(xy[:n2], None, n2, 3)
+    assert list(sol.route()) == route.tolist() and np.float32(sol.total).tobytes() == np.float32(c).tobytes()
+    with pytest.raises(TA.TeelineGpuError) as e:   # visited flags live in one CU's LDS
+        TA.nearest_neighbor.solve(prob(O.synth_xy(170000, seed=10)), ctx=ctx)
+    assert e.value.code == TA._capi.TL_ERR_UNSUPPORTED
+
+
+def test_lk_at_a_size_beyond_the_oracle(ctx):
+    # n = 40 000, one epoch: the oracle would need ~20 min; properties only
+    import teeline_amd as TA
+    n = 40000
+    xy = O.synth_xy(n, seed=14)
+    h = TA.HeuristicOptions(epochs=1, platoo_epochs=1, n_nearest=5)
+    sol = TA.lin_kernighan.solve(prob(xy), TA.LKOptions(h, 5), None, None, ctx=ctx, seed=3)
+    route = np.asarray(sol.route(), dtype=np.uint32)
+    rc, nn, cnn = O.nearest_neighbor(xy, None, n, 3)
+    assert O.validate_tour(route) and sol.total < cnn and sol.stats["moves"] > 0
+    assert np.float32(sol.total).tobytes() == O.tour_length(xy, None, route).tobytes()
+    # the result of an lk_pass is LK-optimal for its own candidate lists: one more pass of the oracle finds nothing ... from
+    # the tour the LAST pass ended in, which is `route` only if the kick was rejected; so only when no kick improved
+    with pytest.raises(TA.TeelineGpuError):
+        TA.lin_kernighan.solve(prob(xy[:100]), TA.LKOptions(h, 7), None, None, ctx=ctx)   # max_depth > 6
+
+
+def test_empty_and_tiny_inputs_of_every_entry_point(ctx):
+    import teeline_amd as TA
+    one = np.array([[3.0, 4.0]], np.float32)
+    two = np.array([[0, 0], [3, 4]], np.float32)
+    three = np.array([[0, 0], [3, 4], [6, 0]], np.float32)
+    # two_opt: n < 3 underflows in the reference (two_opt.rs:17,29) -> ReferencePanics; n = 3: identity, one empty sweep
+    for xy in (one, two):
+        with pytest.raises(TA.ReferencePanics):
+            TA.two_opt.solve(prob(xy), None, None, None, ctx=ctx)
+    s = TA.two_opt.solve(prob(three), None, None, [2, 0, 1], ctx=ctx)
+    assert s.route() == [2, 0, 1] and s.stats["sweeps"] == 1 and s.stats["candidates"] == 0 and s.total == np.float32(16.0)
+    # three_opt / or_opt: n < 4 returns the cities order whatever the seed (three_opt.rs:25-28, or_opt.rs:31-34)
+    for mod in (TA.three_opt, TA.or_opt):
+        for xy in (one, two, three):
+            s = mod.solve(prob(xy), None, None, list(range(len(xy)))[::-1], ctx=ctx)
+            assert s.route() == list(range(len(xy)))
+        assert mod.find_best_move(prob(three), [0, 1, 2], ctx=ctx) is None
+    # nearest_neighbor: one city is its own tour; lin_kernighan: fewer than 4 cities -> the seed untouched (lin_kernighan.rs:57-59)
+    assert TA.nearest_neighbor.solve(prob(one), ctx=ctx).route() == [0]
+    assert TA.nearest_neighbor.solve(prob(two), ctx=ctx).route() == [0, 1]
+    for xy in (one, two, three):
+        s = TA.lin_kernighan.solve(prob(xy), None, None, None, ctx=ctx)
+        rc, r, c, st = O.lin_kernighan(xy)
+        assert s.route() == r.tolist() and np.float32(s.total).tobytes() == np.float32(c).tobytes()
+    # distance matrix: at least two points (distance_matrix.rs:124-126); tour_length of fewer than two cities is 0 (:236-238)
+    with pytest.raises(ValueError):
+        TA.distance_matrix.build([0], one, ctx=ctx)
+    dm = TA.distance_matrix.build([0, 1], two, ctx=ctx)
+    assert dm.items.tolist() == [5.0] and dm.tour_length([0], ctx=ctx) == 0.0 and dm.tour_length([0, 1], ctx=ctx) == np.float32(10.0)
+    # candidate lists: k clamps to n - 1 (lin_kernighan.rs:14); a single city has none
+    assert TA.lin_kernighan.build_candidates(prob(two), 5, ctx=ctx).tolist() == [[1], [0]]
+    assert TA.lin_kernighan.build_candidates(prob(one), 5, ctx=ctx).shape == (1, 0)
+    # multi-start: at least one restart; a population needs valid permutations
+    with pytest.raises(TA.TeelineGpuError):
+        TA.two_opt.multistart(prob(O.synth_xy(50, seed=1)), 0, ctx=ctx)
+    with pytest.raises(TA.TeelineGpuError):
+        TA.two_opt.solve_population(prob(O.synth_xy(5, seed=1)), [[0, 1, 2, 3, 3]], ctx=ctx)
