@@ -147,6 +147,52 @@ static float run_blocked_swapped(const float2 *xy, uint32_t n, float *out)
     return time_us_fn([&] { hipLaunchKernelGGL((k_rows_blocked_swapped<R, P, THREADS>), grid, dim3(THREADS), 0, 0, xy, n, out); });
 }
 
+// blocked, launched over the (row block, column slab) pairs of the lower triangle only (no workgroup that exits at once):
+// linear id -> slab by a short scalar walk over the slabs (<= n / (THREADS * P) steps)
+template <int R, int P, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_rows_blocked_tri(const float2 *__restrict__ xy, uint32_t n, float *__restrict__ out, uint32_t nrb)
+{
+    uint32_t id = blockIdx.x, slab = 0;
+    for (;;) {  // slab s holds the row blocks rb with (rb + 1) * R > s * THREADS * P, i.e. rb >= first(s)
+        const uint32_t first = (slab * (THREADS * P)) / R;
+        const uint32_t cnt = nrb - (first < nrb ? first : nrb);
+        if (id < cnt) break;
+        id -= cnt;
+        ++slab;
+    }
+    const uint32_t rb = (slab * (THREADS * P)) / R + id;
+    const uint32_t i0 = rb * R + 1u;
+    const uint32_t jb = slab * (THREADS * P) + threadIdx.x;
+    const uint32_t ilast = (i0 + R - 1u < n - 1u) ? i0 + R - 1u : n - 1u;
+    float2 c[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const uint32_t j = jb + (uint32_t)p * THREADS;
+        c[p] = xy[j < n ? j : n - 1u];
+    }
+#pragma unroll 1
+    for (uint32_t i = i0; i <= ilast; ++i) {
+        const float2 a = xy[i];
+        float *__restrict__ row = out + (size_t)i * (i - 1u) / 2u;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const uint32_t j = jb + (uint32_t)p * THREADS;
+            if (j < i) row[j] = dist(a, c[p]);
+        }
+    }
+}
+template <int R, int P, int THREADS>
+static float run_blocked_tri(const float2 *xy, uint32_t n, float *out)
+{
+    const uint32_t nrb = (n - 1 + R - 1) / R, nslab = (n - 1 + THREADS * P - 1) / (THREADS * P);
+    uint32_t total = 0;
+    for (uint32_t s = 0; s < nslab; ++s) {
+        const uint32_t first = (s * (THREADS * P)) / R;
+        total += nrb - (first < nrb ? first : nrb);
+    }
+    return time_us_fn([&] { hipLaunchKernelGGL((k_rows_blocked_tri<R, P, THREADS>), dim3(total), dim3(THREADS), 0, 0, xy, n, out, nrb); });
+}
+
 template <int R, int P, int THREADS>
 static float run_blocked(const float2 *xy, uint32_t n, float *out)
 {
@@ -214,6 +260,11 @@ int main()
     line("rows 256x40: full (one workgroup per row)", run_rows<4, 40, 256>(xy, n, out));
     line("rows 1024x10: full (one workgroup per row)", run_rows<4, 10, 1024>(xy, n, out));
     line("rows 512x8: full", run_rows<4, 8, 512>(xy, n, out));
+    line("tri R=4 P=4 T=256", run_blocked_tri<4, 4, 256>(xy, n, out));
+    line("tri R=8 P=4 T=256", run_blocked_tri<8, 4, 256>(xy, n, out));
+    line("tri R=4 P=2 T=256", run_blocked_tri<4, 2, 256>(xy, n, out));
+    line("tri R=4 P=4 T=256 (again)", run_blocked_tri<4, 4, 256>(xy, n, out));
+    line("blocked R=4  P=4 T=256 (ref0)", run_blocked<4, 4, 256>(xy, n, out));
     line("swapped R=4 P=4 T=256", run_blocked_swapped<4, 4, 256>(xy, n, out));
     line("swapped R=8 P=4 T=256", run_blocked_swapped<8, 4, 256>(xy, n, out));
     line("swapped R=4 P=2 T=256", run_blocked_swapped<4, 2, 256>(xy, n, out));
