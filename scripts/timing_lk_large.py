@@ -14,7 +14,7 @@ for flag, name in ((0, "kd-tree walk (default)"), (TA.TL_FLAG_KNN_BRUTE, "brute 
             t = time.perf_counter()
             TA.lin_kernighan.build_candidates(p, 5, ctx=ctx)
             best = min(best, (time.perf_counter() - t) * 1e3)
-        print(f"build_candidates n={n} k=5, {name}: {best:.2f} ms per call (host tree build + upload + kernel + download)")
+        print(f"build_candidates n={n} k=5, {name}: {best:.2f} ms per call (tree build + walk + download)")
 with TA.Context(0) as ctx:
     for _ in range(2):
         t = time.perf_counter()

@@ -8,18 +8,20 @@
 // k = 5) a scan in position order returns different lists, and Lin-Kernighan walks its candidates in list order: different
 // tours.  So the product walks the same tree in the same order.
 //
-//   host  : tree build — median split by coord = depth % 2 over points ordered by (exact coordinate value, position); where
-//           no two points straddling a median compare Equal (kdtree.rs:301-317) this is the reference's tree whatever
-//           its select_nth_unstable_by (kdtree.rs:63) does, elsewhere the reference's tree is implementation-defined and
-//           this rule (the CPU oracle under oracle/ states the same one) is the specification.  O(n log n): two index
-//           lists presorted by x and by y, split stably at every node.
+//   build : median split by coord = depth % 2 over points ordered by (exact coordinate value, position); where no two points
+//           straddling a median compare Equal (kdtree.rs:301-317) this is the reference's tree whatever its
+//           select_nth_unstable_by (kdtree.rs:63) does, elsewhere the reference's tree is implementation-defined and this rule
+//           (the CPU oracle under oracle/ states the same one) is the specification.  On the device, level by level: two
+//           index lists presorted by (x, position) and (y, position) (64-bit radix sort), and per level every segment of the
+//           list sorted by the level's coordinate yields its pivot (the element at len / 2) while the other list is split
+//           stably into left | pivot | right with one prefix sum over "goes left" flags.  A node's index is its pivot's
+//           final place in the lists, so children are the midpoints of the two sub-ranges.
 //   device: one lane per city runs KDNode::nearest with an explicit stack (node, stage) in LDS: the node itself, the
 //           near branch, and — decided only AFTER the near branch has returned, with the radius it left — the far branch
 //           iff search_radius() > |split|.  Distances are the reference's correctly rounded f32 (tl::dist).
 #include "tl_kernels.h"
 
-#include <algorithm>
-#include <vector>
+#include <hipcub/hipcub.hpp>
 
 #pragma clang fp contract(off)
 
@@ -37,83 +39,167 @@ __host__ __device__ __forceinline__ int cmp_coord(float a, float b)
     return a < b ? -1 : 1;
 }
 
-struct Builder {
-    const float *xy;
-    std::vector<KdNode> &nodes;
-    std::vector<uint32_t> sorted[2];  // the subtree's points in [lo, hi) of both lists: by (x, position) and by (y, position)
-    std::vector<uint32_t> tmp;
-    std::vector<unsigned char> side;
-    bool tie_free = true;
-
-    int32_t build(uint32_t lo, uint32_t hi, uint32_t depth)
-    {
-        if (lo >= hi) return -1;  // kdtree.rs:37-39
-        const int32_t me = (int32_t)nodes.size();
-        nodes.push_back(KdNode{});
-        const uint32_t len = hi - lo, c = depth & 1u;
-        KdNode nd{};
-        nd.coord = c;
-        nd.left = nd.right = -1;
-        if (len == 1) {  // :41-43 leaf
-            nd.pos = sorted[0][lo];
-        } else {
-            std::vector<uint32_t> &S = sorted[c], &O = sorted[c ^ 1u];
-            const uint32_t mid = lo + len / 2u;  // :61 pivot_idx = len / 2
-            const uint32_t pivot = S[mid];
-            const float pv = xy[2 * pivot + c];
-            if (cmp_coord(xy[2 * S[mid - 1] + c], pv) == 0) tie_free = false;
-            if (mid + 1 < hi && cmp_coord(xy[2 * S[mid + 1] + c], pv) == 0) tie_free = false;
-            for (uint32_t t = lo; t < mid; ++t) side[S[t]] = 0;
-            side[pivot] = 1;
-            for (uint32_t t = mid + 1; t < hi; ++t) side[S[t]] = 2;
-            uint32_t wl = lo, wr = mid + 1;  // the other list, split stably into [lo, mid) | pivot | (mid, hi)
-            for (uint32_t t = lo; t < hi; ++t) {
-                const uint32_t p = O[t];
-                if (side[p] == 0) tmp[wl++] = p;
-                else if (side[p] == 2) tmp[wr++] = p;
-            }
-            tmp[mid] = pivot;
-            std::copy(tmp.begin() + lo, tmp.begin() + hi, O.begin() + lo);
-            nd.pos = pivot;  // :67
-            nd.left = build(lo, mid, depth + 1);       // :70 points before the pivot
-            nd.right = build(mid + 1, hi, depth + 1);  // :68 split_off(pivot_idx + 1)
-        }
-        nd.x = xy[2 * nd.pos];
-        nd.y = xy[2 * nd.pos + 1];
-        nodes[me] = nd;
-        return me;
-    }
+// ---------------------------------------------------------------------------------------------- device tree build
+// Workspace layout (u32 words unless noted), n elements each: S[0] (by x), S[1] (by y), Onew, seg_lo[2], seg_hi[2] (double
+// buffered per-position segment bounds, hi == lo: position finished), side (per POINT), flag, scan; u64: keys in / out.
+struct KdBuildWs {
+    unsigned long long *keys_in, *keys_out;
+    uint32_t *S[2], *Onew, *seg_lo[2], *seg_hi[2], *side, *flag, *scan, *pivpos;
 };
+
+__global__ __launch_bounds__(256) void k_kd_keys(const float2 *__restrict__ xy, uint32_t n, int coord, unsigned long long *__restrict__ keys)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float v = (coord ? xy[i].y : xy[i].x) + 0.0f;  // -0.0 -> +0.0: the order is the float order (a < b), ties by position
+    const uint32_t b = __builtin_bit_cast(uint32_t, v);
+    const uint32_t sortable = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    keys[i] = ((unsigned long long)sortable << 32) | i;
+}
+
+__global__ __launch_bounds__(256) void k_kd_unpack(const unsigned long long *__restrict__ keys, uint32_t n, uint32_t *__restrict__ S, uint32_t *__restrict__ seg_lo,
+                                                   uint32_t *__restrict__ seg_hi)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    S[i] = (uint32_t)(keys[i] & 0xFFFFFFFFull);
+    if (seg_lo) {  // level 0: one segment [0, n)
+        seg_lo[i] = 0u;
+        seg_hi[i] = n;
+    }
+}
+
+// level step 1 — over the positions of the list sorted by this level's coordinate: every segment's element at len / 2 is
+// its pivot (kdtree.rs:61-67) and becomes node `mid`; every point learns its side
+__global__ __launch_bounds__(256) void k_kd_pivots(const float2 *__restrict__ xy, uint32_t n, uint32_t coord, const uint32_t *__restrict__ Sc,
+                                                   const uint32_t *__restrict__ seg_lo, const uint32_t *__restrict__ seg_hi, uint32_t *__restrict__ side,
+                                                   KdNode *__restrict__ nodes)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t lo = seg_lo[t], hi = seg_hi[t];
+    if (hi <= lo) return;  // finished (a pivot of an earlier level)
+    const uint32_t mid = lo + (hi - lo) / 2u;
+    const uint32_t p = Sc[t];
+    side[p] = t < mid ? 0u : (t == mid ? 1u : 2u);
+    if (t == mid) {
+        KdNode nd;
+        nd.x = xy[p].x;
+        nd.y = xy[p].y;
+        nd.pos = p;
+        nd.coord = coord;
+        nd.left = mid > lo ? (int32_t)(lo + (mid - lo) / 2u) : -1;                  // :70 points before the pivot
+        nd.right = hi > mid + 1u ? (int32_t)(mid + 1u + (hi - mid - 1u) / 2u) : -1;  // :68 split_off(pivot_idx + 1)
+        nodes[mid] = nd;
+    }
+}
+
+// level step 2 — over the positions of the OTHER list: "goes left" flags for the prefix sum, and where the pivot sits
+__global__ __launch_bounds__(256) void k_kd_flags(uint32_t n, const uint32_t *__restrict__ O, const uint32_t *__restrict__ seg_lo,
+                                                  const uint32_t *__restrict__ seg_hi, const uint32_t *__restrict__ side, uint32_t *__restrict__ flag,
+                                                  uint32_t *__restrict__ pivpos)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t lo = seg_lo[t], hi = seg_hi[t];
+    uint32_t f = 0u;
+    if (hi > lo) {
+        const uint32_t sd = side[O[t]];
+        f = sd == 0u ? 1u : 0u;
+        if (sd == 1u) pivpos[lo] = t;
+    }
+    flag[t] = f;
+}
+
+// level step 3 — the other list, split stably into [lo, mid) | pivot | (mid, hi), and the next level's segment bounds
+__global__ __launch_bounds__(256) void k_kd_split(uint32_t n, const uint32_t *__restrict__ O, const uint32_t *__restrict__ seg_lo, const uint32_t *__restrict__ seg_hi,
+                                                  const uint32_t *__restrict__ side, const uint32_t *__restrict__ scan, const uint32_t *__restrict__ pivpos,
+                                                  uint32_t *__restrict__ Onew, uint32_t *__restrict__ nlo, uint32_t *__restrict__ nhi)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t lo = seg_lo[t], hi = seg_hi[t];
+    const uint32_t p = O[t];
+    if (hi <= lo) {  // finished positions keep their point and stay finished
+        Onew[t] = p;
+        nlo[t] = t;
+        nhi[t] = t;
+        return;
+    }
+    const uint32_t mid = lo + (hi - lo) / 2u;
+    const uint32_t lrank = scan[t] - scan[lo];  // "goes left" elements of the segment before t
+    const uint32_t sd = side[p];
+    uint32_t dst;
+    if (sd == 0u) dst = lo + lrank;
+    else if (sd == 1u) dst = mid;
+    else dst = mid + 1u + ((t - lo) - lrank - (pivpos[lo] < t ? 1u : 0u));
+    Onew[dst] = p;
+    // bounds of the NEXT level, written for position t itself (both lists share the ranges): left part, pivot, right part
+    if (t < mid) { nlo[t] = lo; nhi[t] = mid; }
+    else if (t == mid) { nlo[t] = t; nhi[t] = t; }
+    else { nlo[t] = mid + 1u; nhi[t] = hi; }
+}
 
 }  // namespace
 
-// kdtree::from_cities (kdtree.rs:19-34): node 0 is the root (n >= 1).  Returns tie_free (see the header comment).
-bool kdtree_build_host(const float *xy, uint32_t n, std::vector<KdNode> &nodes)
+size_t kdtree_build_ws_bytes(uint32_t n, size_t *cub_bytes_out)
 {
-    nodes.clear();
-    nodes.reserve(n);
-    Builder b{xy, nodes, {}, {}, {}};
+    size_t sort_b = 0, scan_b = 0;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, sort_b, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (int)n, 0, 64, nullptr);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_b, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, nullptr);
+    const size_t cub_b = ((sort_b > scan_b ? sort_b : scan_b) + 255) & ~(size_t)255;
+    if (cub_bytes_out) *cub_bytes_out = cub_b;
+    const size_t np = ((size_t)n + 63) & ~(size_t)63;
+    return cub_b + np * 8 * 2 + np * 4 * 12 + 256;
+}
+
+// kdtree::from_cities (kdtree.rs:19-34) on the device.  `ws` has kdtree_build_ws_bytes(n) bytes, `nodes` n entries; the root
+// is node n / 2.  Everything is enqueued on `s`; nothing is waited for.
+hipError_t kdtree_build_dev(const float2 *xy, uint32_t n, void *ws, KdNode *nodes, hipStream_t s)
+{
+    size_t cub_b = 0;
+    (void)kdtree_build_ws_bytes(n, &cub_b);
+    const size_t np = ((size_t)n + 63) & ~(size_t)63;
+    unsigned char *w = (unsigned char *)ws;
+    void *cub_tmp = w;
+    w += cub_b;
+    KdBuildWs B;
+    B.keys_in = (unsigned long long *)w; w += np * 8;
+    B.keys_out = (unsigned long long *)w; w += np * 8;
+    uint32_t **slots[] = {&B.S[0], &B.S[1], &B.Onew, &B.seg_lo[0], &B.seg_lo[1], &B.seg_hi[0], &B.seg_hi[1], &B.side, &B.flag, &B.scan, &B.pivpos};
+    for (uint32_t **sl : slots) { *sl = (uint32_t *)w; w += np * 4; }
+    const dim3 grid((n + 255u) / 256u), blk(256);
+    hipError_t e;
     for (int c = 0; c < 2; ++c) {
-        b.sorted[c].resize(n);
-        for (uint32_t i = 0; i < n; ++i) b.sorted[c][i] = i;
-        std::sort(b.sorted[c].begin(), b.sorted[c].end(), [&](uint32_t p, uint32_t q) {
-            const float a = xy[2 * p + c], d = xy[2 * q + c];
-            if (a < d) return true;
-            if (d < a) return false;
-            return p < q;
-        });
+        hipLaunchKernelGGL(k_kd_keys, grid, blk, 0, s, xy, n, c, B.keys_in);
+        size_t tb = cub_b;
+        if ((e = hipcub::DeviceRadixSort::SortKeys(cub_tmp, tb, B.keys_in, B.keys_out, (int)n, 0, 64, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_kd_unpack, grid, blk, 0, s, B.keys_out, n, B.S[c], c == 0 ? B.seg_lo[0] : (uint32_t *)nullptr, c == 0 ? B.seg_hi[0] : (uint32_t *)nullptr);
     }
-    b.tmp.resize(n);
-    b.side.resize(n);
-    b.build(0, n, 0);
-    return b.tie_free;
+    uint32_t levels = 1;  // height of a median-split tree: the smallest h with 2^h > n
+    while ((1ull << levels) <= (unsigned long long)n) ++levels;
+    int cur = 0;
+    for (uint32_t d = 0; d < levels; ++d) {
+        const uint32_t c = d & 1u;
+        uint32_t *Sc = B.S[c], *O = B.S[c ^ 1u];
+        hipLaunchKernelGGL(k_kd_pivots, grid, blk, 0, s, xy, n, c, Sc, B.seg_lo[cur], B.seg_hi[cur], B.side, nodes);
+        hipLaunchKernelGGL(k_kd_flags, grid, blk, 0, s, n, O, B.seg_lo[cur], B.seg_hi[cur], B.side, B.flag, B.pivpos);
+        size_t tb = cub_b;
+        if ((e = hipcub::DeviceScan::ExclusiveSum(cub_tmp, tb, B.flag, B.scan, (int)n, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_kd_split, grid, blk, 0, s, n, O, B.seg_lo[cur], B.seg_hi[cur], B.side, B.scan, B.pivpos, B.Onew, B.seg_lo[cur ^ 1], B.seg_hi[cur ^ 1]);
+        // the split list replaces the other list (pointer swap: the next level reads it as Sc)
+        B.S[c ^ 1u] = B.Onew;
+        B.Onew = O;
+        cur ^= 1;
+    }
+    return hipGetLastError();
 }
 
 namespace {
 
 template <int KMAX>
 __global__ __launch_bounds__(256) void k_knn_kdtree(const KdNode *__restrict__ nodes, const float2 *__restrict__ xy, uint32_t n, uint32_t k,
-                                                    uint32_t *__restrict__ cand)
+                                                    uint32_t *__restrict__ cand, uint32_t root)
 {
     __shared__ uint32_t stk[kKdStack][256];  // [level][lane]: conflict-free, 40 KB
     const uint32_t tid = threadIdx.x, c = blockIdx.x * 256u + tid;
@@ -128,7 +214,7 @@ __global__ __launch_bounds__(256) void k_knn_kdtree(const KdNode *__restrict__ n
     }
     float radius = __builtin_inff();  // search_radius(): INFINITY until the buffer holds k, then the k-th kept distance
     int sp = 0;
-    stk[0][tid] = 0u;  // (root << 1) | stage 0
+    stk[0][tid] = root << 1;  // (root << 1) | stage 0
     while (sp >= 0) {
         const uint32_t e = stk[sp][tid];
         const KdNode nd = nodes[e >> 1];
@@ -180,10 +266,10 @@ __global__ __launch_bounds__(256) void k_knn_kdtree(const KdNode *__restrict__ n
 
 hipError_t launch_knn_kdtree(const KdNode *nodes, const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, hipStream_t s)
 {
-    const uint32_t grid = (n + 255u) / 256u;
-    if (k <= 4) hipLaunchKernelGGL(k_knn_kdtree<4>, dim3(grid), dim3(256), 0, s, nodes, xy, n, k, cand);
-    else if (k <= 8) hipLaunchKernelGGL(k_knn_kdtree<8>, dim3(grid), dim3(256), 0, s, nodes, xy, n, k, cand);
-    else hipLaunchKernelGGL(k_knn_kdtree<16>, dim3(grid), dim3(256), 0, s, nodes, xy, n, k, cand);
+    const uint32_t grid = (n + 255u) / 256u, root = n / 2u;  // the level-0 segment [0, n) has its pivot at n / 2
+    if (k <= 4) hipLaunchKernelGGL(k_knn_kdtree<4>, dim3(grid), dim3(256), 0, s, nodes, xy, n, k, cand, root);
+    else if (k <= 8) hipLaunchKernelGGL(k_knn_kdtree<8>, dim3(grid), dim3(256), 0, s, nodes, xy, n, k, cand, root);
+    else hipLaunchKernelGGL(k_knn_kdtree<16>, dim3(grid), dim3(256), 0, s, nodes, xy, n, k, cand, root);
     return hipGetLastError();
 }
 

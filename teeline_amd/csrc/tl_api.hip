@@ -1017,8 +1017,8 @@ extern "C" int tl_or_opt(tl_ctx *c, const float *xy, uint32_t n, const float *dm
 static bool max_depth_ge2_split(uint32_t) { return true; }
 static int knn_form(const tl_ctx *c) { return (c->flags & TL_FLAG_KNN_1LANE) ? 1 : (c->flags & TL_FLAG_KNN_4LANES) ? 4 : 0; }
 
-// lin_kernighan::build_candidates (lin_kernighan.rs:12-27) into d_cand (n x k): the reference's kd-tree k-NN — tree built on
-// the host from the caller's coordinates, queried on the device (kdtree.hip) — or, under the TL_FLAG_KNN_* flags, the
+// lin_kernighan::build_candidates (lin_kernighan.rs:12-27) into d_cand (n x k): the reference's kd-tree k-NN — tree built and
+// queried on the device (kdtree.hip) — or, under the TL_FLAG_KNN_* flags, the
 // brute-force scan in (distance, position) order (identical lists wherever no two candidates of a city tie in f32 distance).
 // d_xy must already hold xy (enqueued on c->stream).
 static int build_candidates_dev(tl_ctx *c, const float *xy_host, const float2 *d_xy, uint32_t n, uint32_t k, uint32_t *d_cand)
@@ -1028,13 +1028,13 @@ static int build_candidates_dev(tl_ctx *c, const float *xy_host, const float2 *d
         HIPCHK(c, launch_knn(d_xy, n, k, d_cand, c->stream, knn_form(c)));
         return TL_OK;
     }
-    std::vector<KdNode> nodes;
-    kdtree_build_host(xy_host, n, nodes);
+    (void)xy_host;
     int rc;
-    if ((rc = ensure(c, c->kd, nodes.size() * sizeof(KdNode)))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->kd.p, nodes.data(), nodes.size() * sizeof(KdNode), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, launch_knn_kdtree((const KdNode *)c->kd.p, d_xy, n, k, d_cand, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // `nodes` (pageable host memory) goes out of scope
+    const size_t nodes_b = (((size_t)n * sizeof(KdNode)) + 255) & ~(size_t)255;
+    if ((rc = ensure(c, c->kd, nodes_b + kdtree_build_ws_bytes(n, nullptr)))) return rc;
+    KdNode *nodes = (KdNode *)c->kd.p;
+    HIPCHK(c, kdtree_build_dev(d_xy, n, (unsigned char *)c->kd.p + nodes_b, nodes, c->stream));
+    HIPCHK(c, launch_knn_kdtree(nodes, d_xy, n, k, d_cand, c->stream));
     return TL_OK;
 }  // the split scan handles every max_depth >= 1
 

@@ -190,10 +190,8 @@ struct KdNode {
     uint32_t pos;         // its position in the city array (= KDPoint.id of build_candidates' cities)
     uint32_t coord;       // depth % 2
 };
-}  // namespace tl
-#include <vector>
-namespace tl {
-bool kdtree_build_host(const float *xy, uint32_t n, std::vector<KdNode> &nodes);  // returns tie_free
+size_t kdtree_build_ws_bytes(uint32_t n, size_t *cub_bytes_out);
+hipError_t kdtree_build_dev(const float2 *xy, uint32_t n, void *ws, KdNode *nodes, hipStream_t s);  // root = node n / 2
 hipError_t launch_knn_kdtree(const KdNode *nodes, const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, hipStream_t s);
 
 // dm_build.hip
