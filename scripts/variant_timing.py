@@ -15,6 +15,10 @@ ms = []
 for _ in range(4):
     ctx.check(ctx.lib.tl_two_opt_batch_dev(ctx.handle, d_xy.data_ptr(), n, None, 12345, 0, R, 0, d_pos.data_ptr(), d_cost.data_ptr(), d_st.data_ptr(), C.c_void_p(s.cuda_stream)))
     torch.cuda.synchronize(); ms.append(ctx.last_kernel_ms())
+crc = int(d_pos.to(torch.int64).sum().item()) ^ int(d_cost.view(torch.int32).to(torch.int64).sum().item())
+if crc != 298053045692 or int(d_st[:, 3].max().item()) != 0:  # the committed kernel's tours (sweep-bounded run: a wrong variant cannot hang)
+    print(f"{os.path.basename(os.environ.get('TEELINE_GPU_LIB','default')):20s} WRONG RESULTS check {crc} status {int(d_st[:, 3].max().item())}")
+    sys.exit(0)
 prob = TA.TspProblem(np.arange(n), xy)
 nn = TA.nearest_neighbor.solve(prob, ctx=ctx)
 a = min(TA.two_opt.solve(prob, None, None, nn.route(), ctx=ctx).stats["kernel_ms"] for _ in range(3))

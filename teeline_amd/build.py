@@ -56,6 +56,18 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
     return LIB_OUT
 
 
+JITTER_LIB = os.path.join(HERE, "libteeline_gpu_jitter.so")
+
+
+def build_jitter(force=False):
+    """The race-stress build of the same sources (-DTL_JITTER: waves leave every workgroup barrier far apart, tl_device.h).
+    Test infrastructure (tests/test_gpu_race_stress.py loads it in a child process); never the product library."""
+    build()
+    if not force and os.path.exists(JITTER_LIB) and os.path.getmtime(JITTER_LIB) >= os.path.getmtime(LIB):
+        return JITTER_LIB
+    return build(extra_flags=["-DTL_JITTER"], out=JITTER_LIB)
+
+
 CLI = os.path.join(HERE, "teeline-gpu")
 CLI_SRC = os.path.join(HERE, "host_cpp", "teeline_gpu_cli.cpp")
 CLI_HDR = os.path.join(HERE, "host_cpp", "teeline_gpu.hpp")
@@ -79,3 +91,4 @@ if __name__ == "__main__":
         sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_cli(force="--force" in sys.argv))
+    print(build_jitter(force="--force" in sys.argv))

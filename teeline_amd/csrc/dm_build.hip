@@ -132,12 +132,12 @@ __global__ __launch_bounds__(1024) void k_tour_length(const float2 *__restrict__
     for (uint32_t base = 0; base + 1 < n; base += 1024) {
         const uint32_t k = base + tid;
         scratch[tid] = (k + 1 < n) ? D(perm[k], perm[k + 1]) : 0.0f;
-        __syncthreads();
+        TL_SYNC();
         if (tid == 0) {
             const uint32_t cnt = (n - 1 - base) < 1024u ? (n - 1 - base) : 1024u;
             for (uint32_t q = 0; q < cnt; ++q) total += scratch[q];
         }
-        __syncthreads();
+        TL_SYNC();
     }
     if (tid == 0) *out_cost = total;
 }

@@ -54,9 +54,9 @@ __global__ __launch_bounds__(256) void k_knn(const float2 *__restrict__ xy, uint
     for (int t = 0; t < KMAX; ++t) { bd[t] = __builtin_inff(); bp[t] = 0xFFFFFFFFu; }
     float radius = __builtin_inff(), rlim = __builtin_inff();
     for (uint32_t base = 0; base < n; base += 256u) {
-        __syncthreads();
+        TL_SYNC();
         if (base + threadIdx.x < n) tile[threadIdx.x] = xy[base + threadIdx.x];
-        __syncthreads();
+        TL_SYNC();
         const uint32_t lim = (n - base) < 256u ? (n - base) : 256u;
         for (uint32_t t = 0; t < lim; ++t) {
             const uint32_t p = base + t;
@@ -175,9 +175,9 @@ __global__ __launch_bounds__(256) void k_knn_quad(const float2 *__restrict__ xy,
     for (int t = 0; t < KMAX; ++t) { bd[t] = __builtin_inff(); bp[t] = 0xFFFFFFFFu; }
     float radius = __builtin_inff(), rlim = __builtin_inff();
     for (uint32_t base = 0; base < n; base += 256u) {
-        __syncthreads();
+        TL_SYNC();
         if (base + threadIdx.x < n) tile[threadIdx.x] = xy[base + threadIdx.x];
-        __syncthreads();
+        TL_SYNC();
         const uint32_t lim = (n - base) < 256u ? (n - base) : 256u;
         for (uint32_t t = q; t < ((lim + G - 1u) & ~(G - 1u)); t += G) {  // the group walks together (wave-uniform trip count)
             const uint32_t p = base + t;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(kLkNT) void k_nn_seed(const float2 *__restrict__ xy
         const uint32_t p = tid + (uint32_t)m * kLkNT;
         rxy[m] = (regs && p < n) ? xy[p] : make_float2(0.f, 0.f);
     }
-    __syncthreads();
+    TL_SYNC();
     if (tid == 0) {
         path[0] = 0;  // :28 start = cities[0]
         visited[0] = 1;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kLkNT) void k_nn_seed(const float2 *__restrict__ xy
         s_minsq = 0xFFFFFFFFu;
         s_minpos = 0xFFFFFFFFu;
     }
-    __syncthreads();
+    TL_SYNC();
     while (true) {
         if (tid < 64u) {
             // the walk (:44-49), wave 0: lane t looks at the t-th nearest of the current city, the first lane whose city is
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(kLkNT) void k_nn_seed(const float2 *__restrict__ xy
                 s_cur = cur;
             }
         }
-        __syncthreads();
+        TL_SYNC();
         if (s_len >= n) break;
         // :50-63 fallback: globally nearest unvisited; ties -> lowest position (the reference iterates a HashSet).
         // sqrt is monotone, so the nearest city has the smallest squared distance: pass 1 reduces min sq (u32 bits order
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(kLkNT) void k_nn_seed(const float2 *__restrict__ xy
             }
             msq = wave_min_u32(msq);
             if (lane == 0 && msq != 0xFFFFFFFFu) atomicMin(&s_minsq, msq);
-            __syncthreads();
+            TL_SYNC();
             const uint32_t gsq = s_minsq;
             const float dmin = sqrt_rn(__builtin_bit_cast(float, gsq));
             const uint32_t limb = __builtin_bit_cast(uint32_t, __builtin_bit_cast(float, gsq) * 1.000001f);
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(kLkNT) void k_nn_seed(const float2 *__restrict__ xy
             }
             msq = wave_min_u32(msq);
             if (lane == 0 && msq != 0xFFFFFFFFu) atomicMin(&s_minsq, msq);
-            __syncthreads();
+            TL_SYNC();
             const uint32_t gsq = s_minsq;
             const float dmin = sqrt_rn(__builtin_bit_cast(float, gsq));
             // squares that can still round to dmin lie within a few ulps of the minimum; everything else is farther
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(kLkNT) void k_nn_seed(const float2 *__restrict__ xy
         }
         mpos = wave_min_u32(mpos);
         if (lane == 0 && mpos != 0xFFFFFFFFu) atomicMin(&s_minpos, mpos);
-        __syncthreads();
+        TL_SYNC();
     }
 }
 
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(NT) void k_lk_solve(LkArgs G)
         for (size_t e = tid; e < (size_t)n * G.k; e += kLkNT) lcand[e] = G.cand[e];
         xy = lxy;
         cand = lcand;
-        __syncthreads();
+        TL_SYNC();
     }
     uint64_t scans = 0, searches = 0, moves = 0, exchanged = 0;
 
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(NT) void k_lk_solve(LkArgs G)
             next[c] = t[r + 1u == n ? 0u : r + 1u];
             prev[c] = t[r == 0u ? n - 1u : r - 1u];
         }
-        __syncthreads();
+        TL_SYNC();
     };
 
     // tour_distance (:118-122): (0..n).map(d(t[i], t[(i+1)%n])).sum() — sequential f32 from 0, closing edge last
@@ -603,31 +603,31 @@ __global__ __launch_bounds__(NT) void k_lk_solve(LkArgs G)
                 const uint32_t a = t[r], b = t[r + 1u == n ? 0u : r + 1u];
                 s_part[tid] = a == b ? 0.0f : dist(xy[a], xy[b]);
             }
-            __syncthreads();
+            TL_SYNC();
             if (tid == 0) {
                 const uint32_t cnt = (n - base) < (uint32_t)kLkNT ? (n - base) : (uint32_t)kLkNT;
                 for (uint32_t q = 0; q < cnt; ++q) total += s_part[q];
             }
-            __syncthreads();
+            TL_SYNC();
         }
         if (tid == 0) s_part[0] = total;
-        __syncthreads();
+        TL_SYNC();
         const float r = s_part[0];
-        __syncthreads();
+        TL_SYNC();
         return r;
     };
 
     // lk_pass (:454-481) on `tour` (which must be G.tour); returns nothing, leaves the improved tour in G.tour
     auto lk_pass = [&]() {
         for (uint32_t r = tid; r < n; r += kLkNT) city_ids[r] = tour[r];  // :466 fixed for the whole pass
-        __syncthreads();
+        TL_SYNC();
         while (true) {
             rebuild(tour);  // :470
             LkView V{xy, cand, next, G.k, G.max_depth};
             bool found_any = false;
             for (uint32_t base = 0; base < 2u * n; base += kLkNT) {  // find_lk_move (:345-389) in its own order
                 if (tid == 0) s_key = 0xFFFFFFFFu;
-                __syncthreads();
+                TL_SYNC();
                 const uint32_t idx = base + tid;
                 uint32_t chain[kLkMaxChain];
                 uint32_t clen = 0;
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(NT) void k_lk_solve(LkArgs G)
                     if (lk_chain<0, uint32_t>(V, chain, clen, p1, t2, p2, g0)) ok = chain_valid(chain, clen, tour, pos, n);
                 }
                 if (ok) atomicMin(&s_key, idx);
-                __syncthreads();
+                TL_SYNC();
                 const uint32_t key = s_key;
                 if (key != 0xFFFFFFFFu) {
                     if (idx == key) {
@@ -651,10 +651,10 @@ __global__ __launch_bounds__(NT) void k_lk_solve(LkArgs G)
                     }
                     searches += (uint64_t)key + 1u;
                     found_any = true;
-                    __syncthreads();
+                    TL_SYNC();
                     break;
                 }
-                __syncthreads();
+                TL_SYNC();
             }
             ++scans;
             if (!found_any) {
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(NT) void k_lk_solve(LkArgs G)
                 }
                 s_nseg = nseg;
             }
-            __syncthreads();
+            TL_SYNC();
             const uint32_t nseg = s_nseg;
             for (uint32_t sidx = 0; sidx < nseg; ++sidx) {
                 const LkSeg sg = s_seg[sidx];
@@ -706,11 +706,11 @@ __global__ __launch_bounds__(NT) void k_lk_solve(LkArgs G)
                     alt[sg.dst + t] = tour[sp];
                 }
             }
-            __syncthreads();
+            TL_SYNC();
             for (uint32_t r = tid; r < n; r += kLkNT) tour[r] = alt[r];
             ++moves;
             exchanged += (uint64_t)(s_clen / 2u);
-            __syncthreads();
+            TL_SYNC();
         }
     };
 
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(NT) void k_lk_solve(LkArgs G)
     if (n >= 4) {
         lk_pass();                                                   // :61-68
         for (uint32_t r = tid; r < n; r += kLkNT) best[r] = tour[r];
-        __syncthreads();
+        TL_SYNC();
         float best_dist = tour_distance(best);                       // :70
         uint32_t platoo = 0;
         uint64_t draws = 0;
@@ -741,12 +741,12 @@ __global__ __launch_bounds__(NT) void k_lk_solve(LkArgs G)
                     tour[w] = best[src];
                 }
             }
-            __syncthreads();
+            TL_SYNC();
             lk_pass();
             const float dcur = tour_distance(tour);
             if (dcur < best_dist) {                                  // :86
                 for (uint32_t r = tid; r < n; r += kLkNT) best[r] = tour[r];
-                __syncthreads();
+                TL_SYNC();
                 best_dist = dcur;
                 platoo = 0;
             } else {
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(NT) void k_lk_solve(LkArgs G)
     } else {
         for (uint32_t r = tid; r < n; r += kLkNT) best[r] = tour[r];
     }
-    __syncthreads();
+    TL_SYNC();
     if (SMALL)
         for (uint32_t r = tid; r < n; r += kLkNT) G.best[r] = best[r];
     if (tid == 0) {
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(256) void k_lk_scan(LkArgs G)
             xyL[c] = G.xy[c];
             nextL[c] = (uint16_t)G.next[c];
         }
-        __syncthreads();
+        TL_SYNC();
     }
     if (idx >= 2u * n || idx >= S->window) return;
     uint32_t chain[kLkMaxChain];
@@ -1062,23 +1062,23 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
                 const uint32_t a = t[r], b = t[r + 1u == n ? 0u : r + 1u];
                 s_part[tid] = a == b ? 0.0f : dist(xy[a], xy[b]);
             }
-            __syncthreads();
+            TL_SYNC();
             if (tid == 0) {
                 const uint32_t cnt = (n - base) < (uint32_t)kLkNT ? (n - base) : (uint32_t)kLkNT;
                 for (uint32_t q = 0; q < cnt; ++q) total += s_part[q];
             }
-            __syncthreads();
+            TL_SYNC();
         }
         if (tid == 0) s_part[0] = total;
-        __syncthreads();
+        TL_SYNC();
         const float r = s_part[0];
-        __syncthreads();
+        TL_SYNC();
         return r;
     };
 
     const uint32_t key = S->key;
     if (tid == 0) S->applied = 0u;  // set again below if this round applies a move (k_lk_rebuild runs after every control)
-    __syncthreads();
+    TL_SYNC();
     if (key != 0xFFFFFFFFu) {
         // ---- apply_lk_chain (:397-450), then rescan (lk_pass loop :468-478)
         const uint32_t *slot = G.chains + (size_t)key * (kLkMaxChain + 2);
@@ -1110,7 +1110,7 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
             }
             s_nseg = nseg;
         }
-        __syncthreads();
+        TL_SYNC();
         const uint32_t nseg = s_nseg;
         for (uint32_t sidx = 0; sidx < nseg; ++sidx) {
             const LkSeg sg = s_seg[sidx];
@@ -1123,7 +1123,7 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
         // the new tour is in `alt`: copy it back and rebuild rank / successor / predecessor — here for small tours, in
         // k_lk_rebuild on all CUs for large ones (3n scattered stores are slow from one CU)
         if (n < kLkRebuildSplitN) {
-            __syncthreads();
+            TL_SYNC();
             for (uint32_t r = tid; r < n; r += kLkNT) {
                 const uint32_t c = alt[r];
                 tour[r] = c;
@@ -1148,7 +1148,7 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
         return;
     }
     if (S->window < 2u * n) {  // nothing inside the prefix: the same find_lk_move goes on over all pairs
-        __syncthreads();
+        TL_SYNC();
         if (tid == 0) S->window = 2u * n;
         return;
     }
@@ -1160,7 +1160,7 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
     bool kick = false;
     if (S->stage == 0) {                       // initial pass done (:61-70)
         for (uint32_t r = tid; r < n; r += kLkNT) best[r] = tour[r];
-        __syncthreads();
+        TL_SYNC();
         const float bd = tour_distance(best);
         if (tid == 0) {
             S->best_dist = bd;
@@ -1172,13 +1172,13 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
     } else {                                    // an epoch's pass done (:85-96)
         const float dcur = tour_distance(tour);
         const bool better = dcur < S->best_dist;
-        __syncthreads();
+        TL_SYNC();
         bool stop = false;
         if (better) {
             for (uint32_t r = tid; r < n; r += kLkNT) best[r] = tour[r];
         }
         uint32_t platoo = S->platoo, epoch = S->epoch;
-        __syncthreads();
+        TL_SYNC();
         if (better) platoo = 0;
         else if (++platoo >= G.platoo_epochs) stop = true;
         ++epoch;
@@ -1189,7 +1189,7 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
         }
         kick = !stop && epoch < G.epochs;
     }
-    __syncthreads();
+    TL_SYNC();
     if (!kick) {
         if (tid == 0) S->finished = 1;
         return;
@@ -1211,10 +1211,10 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
             else src = w;
             tour[w] = best[src];
         }
-        __syncthreads();
+        TL_SYNC();
         if (tid == 0) S->draws = draws + 3;
     }
-    __syncthreads();
+    TL_SYNC();
     for (uint32_t r = tid; r < n; r += kLkNT) G.city_ids[r] = tour[r];
     rebuild();
     if (tid == 0) {
@@ -1369,7 +1369,7 @@ __global__ __launch_bounds__(kLkNT) void k_nn_seed_dm(const float *__restrict__ 
     for (uint32_t p = tid; p < n; p += kLkNT) visited[p] = p == 0u;  // :28-30 starts at cities[0]
     if (tid < 2) s_best[tid] = ~0ull;
     if (tid == 0) path[0] = 0u;
-    __syncthreads();
+    TL_SYNC();
     uint32_t cur = 0;
     for (uint32_t step = 1; step < n; ++step) {
         unsigned long long best = ~0ull;
@@ -1388,14 +1388,14 @@ __global__ __launch_bounds__(kLkNT) void k_nn_seed_dm(const float *__restrict__ 
         }
         unsigned long long *slot = &s_best[step & 1u];
         if ((tid & 63u) == 0u) atomicMin(slot, best);
-        __syncthreads();
+        TL_SYNC();
         cur = (uint32_t)(*slot & 0xFFFFFFFFull);
         if (tid == 0) {
             path[step] = cur;
             visited[cur] = 1;
             s_best[(step + 1u) & 1u] = ~0ull;
         }
-        __syncthreads();
+        TL_SYNC();
     }
 }
 

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(kOrWaves * 64) void k_or_scan(OrOptArgs A, uint32_t
     }
     best = wave_min_u64(best);
     if (lane == 0) s_key[wave] = best;
-    __syncthreads();
+    TL_SYNC();
     if (threadIdx.x == 0) {
         unsigned long long k = s_key[0];
         for (int w = 1; w < kOrWaves; ++w) k = s_key[w] < k ? s_key[w] : k;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(1024) void k_or_pick(OrOptArgs A, uint32_t nblocks,
     }
     best = wave_min_u64(best);
     if (lane == 0) s_key[wave] = best;
-    __syncthreads();
+    TL_SYNC();
     best = s_key[0];
     for (int w = 1; w < 16; ++w) best = s_key[w] < best ? s_key[w] : best;
     const bool found = best != kNoKey64;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(1024) void k_or_pick(OrOptArgs A, uint32_t nblocks,
     if (!found || !apply) return;
     uint32_t *path = A.perm;
     for (uint32_t t = tid; t < n; t += 1024u) old[t] = path[t];
-    __syncthreads();
+    TL_SYNC();
     const uint32_t insert_at = (j >= i + seg_len) ? (j - seg_len + 1u) : (j + 1u);  // index in the drained tour
     for (uint32_t t = tid; t < n; t += 1024u) {
         uint32_t src;

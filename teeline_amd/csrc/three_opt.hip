@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kT3) void k_three_opt_scan(ThreeOptArgs A)
         }
         s_i = lo;
     }
-    __syncthreads();
+    TL_SYNC();
     const uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_i);  // provably wave-uniform: scalar loads for the (i, j) terms
     const uint32_t jlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(i + 1u + (blockIdx.x - A.chunk_prefix[i]) * A.jc));
     uint32_t jhi = jlo + A.jc;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kT3) void k_three_opt_scan(ThreeOptArgs A)
         if (better(os, oij, okc, bs, bij, bkc)) { bs = os; bij = oij; bkc = okc; }
     }
     if ((tid & 63u) == 0u) { r_s[tid >> 6] = bs; r_ij[tid >> 6] = bij; r_kc[tid >> 6] = bkc; }
-    __syncthreads();
+    TL_SYNC();
     if (tid == 0) {
         for (int w = 1; w < kT3 / 64; ++w)
             if (better(r_s[w], r_ij[w], r_kc[w], bs, bij, bkc)) { bs = r_s[w]; bij = r_ij[w]; bkc = r_kc[w]; }
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(1024) void k_three_opt_pick(ThreeOptArgs A, uint32_
         if (better(os, oij, okc, bs, bij, bkc)) { bs = os; bij = oij; bkc = okc; }
     }
     if ((tid & 63u) == 0u) { r_s[tid >> 6] = bs; r_ij[tid >> 6] = bij; r_kc[tid >> 6] = bkc; }
-    __syncthreads();
+    TL_SYNC();
     bs = r_s[0]; bij = r_ij[0]; bkc = r_kc[0];
     for (int w = 1; w < 16; ++w)
         if (better(r_s[w], r_ij[w], r_kc[w], bs, bij, bkc)) { bs = r_s[w]; bij = r_ij[w]; bkc = r_kc[w]; }
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(1024) void k_three_opt_pick(ThreeOptArgs A, uint32_
     uint32_t *path = A.perm;
     const uint32_t l1 = j - i, l2 = k - j, L = l1 + l2;  // seg1 = path[i+1..=j], seg2 = path[j+1..=k]
     for (uint32_t t = tid; t < L; t += 1024u) tmp[t] = path[i + 1u + t];
-    __syncthreads();
+    TL_SYNC();
     for (uint32_t t = tid; t < L; t += 1024u) {
         uint32_t src;  // index into tmp (0..l1-1 = seg1, l1.. = seg2)
         switch (kase) {

@@ -16,6 +16,11 @@
 
 using namespace tl;
 
+#ifndef TL_MAX_SWEEPS
+#define TL_MAX_SWEEPS (1u << 20)  // status 1 beyond (never reached by a descent: every move shortens the tour); tuning variants
+                                  // are built with a small cap so that a wrong experimental kernel ends instead of hanging the GPU
+#endif
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -88,7 +93,11 @@ static bool is_permutation(const uint32_t *p, uint32_t n)  // validate_tour, src
 
 // ------------------------------------------------------------------------------------------------
 extern "C" int tl_abi_version(void) { return TL_ABI_VERSION; }
+#ifdef TL_JITTER
+extern "C" const char *tl_version(void) { return "teeline-gpu 0.1 (gfx950) +jitter"; }  // race-stress build (tl_device.h)
+#else
 extern "C" const char *tl_version(void) { return "teeline-gpu 0.1 (gfx950)"; }
+#endif
 
 extern "C" const char *tl_last_error(const tl_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -299,7 +308,7 @@ static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uin
     A.seed = seed;
     A.first = first;
     A.n = n;
-    A.max_sweeps = 1u << 20;
+    A.max_sweeps = TL_MAX_SWEEPS;
     A.init_mode = init_mode;
     // every size / mode check comes before the first event record: a rejected call must leave the event pair of the
     // previous kernel sequence intact
@@ -390,7 +399,7 @@ static int two_opt_ref_large(tl_ctx *c, const float *xy, uint32_t n, const uint3
     A.n = n;
     A.n_pad = n_pad;
     A.ntile_cap = ntile_cap;
-    A.max_sweeps = 1u << 20;
+    A.max_sweeps = TL_MAX_SWEEPS;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     HIPCHK(c, launch_large_two_opt_init(A, c->stream));
     LargeTwoOptState hs{};

@@ -94,6 +94,33 @@ __device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t k)
     return z ^ (z >> 31);
 }
 
+// Workgroup barrier.  The race-stress build (-DTL_JITTER, libteeline_gpu_jitter.so, tests/test_gpu_race_stress.py) parks
+// pseudo-randomly chosen waves for 3-30 us right after every barrier, so that waves leave it far apart: an exchange through
+// LDS that is only safe because the waves happen to run in step shows up as a result that differs from the oracle's.
+// (Found this way: the LDS 2-opt kernel's "some key is posted -> skip round 2" test, two_opt_ref.hip.)
+#ifdef TL_JITTER
+__device__ __forceinline__ void jitter(uint32_t salt)
+{
+    uint32_t h = (uint32_t)__builtin_amdgcn_s_memtime() ^ (salt * 0x9E3779B1u) ^ ((threadIdx.x >> 6) * 0x85EBCA6Bu) ^
+                 (blockIdx.x * 0xC2B2AE35u);
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    h ^= h >> 12;
+    h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
+    if ((h & 7u) == 0u) {
+        const uint32_t reps = (h >> 3) & 7u;
+        for (uint32_t k = 0; k <= reps; ++k) __builtin_amdgcn_s_sleep(127);  // 127 x 64 clocks
+    }
+}
+#define TL_SYNC()           \
+    do {                    \
+        __syncthreads();    \
+        tl::jitter(__LINE__); \
+    } while (0)
+#else
+#define TL_SYNC() __syncthreads()
+#endif
+
 __device__ __forceinline__ float readlane_f(float v, int l)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));

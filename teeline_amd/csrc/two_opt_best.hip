@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kBsWaves * 64) void k_bs_scan(BestSweepArgs A)
     }
     best = wave_min_u64(best);
     if (lane == 0) s_key[wave] = best;
-    __syncthreads();
+    TL_SYNC();
     if (threadIdx.x == 0) {
         unsigned long long k = s_key[0];
         for (int w = 1; w < kBsWaves; ++w) k = s_key[w] < k ? s_key[w] : k;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(1024) void k_bs_apply(BestSweepArgs A, uint32_t nbl
     }
     best = wave_min_u64(best);
     if (lane == 0) s_key[wave] = best;
-    __syncthreads();
+    TL_SYNC();
     best = s_key[0];
     for (int w = 1; w < 16; ++w) best = s_key[w] < best ? s_key[w] : best;
     if (best == kNoKey64) {
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(1024) void k_bs_apply(BestSweepArgs A, uint32_t nbl
         perm[lo + t] = v;
         perm[hi - t] = u;
     }
-    __syncthreads();
+    TL_SYNC();
     for (uint32_t t = ((lo - 1u) >> 6) + (uint32_t)wave; t <= (hi >> 6); t += 16u) build_tile_meta(P, n, t, lane, A.tbox, A.tmsq);
     if (tid == 0) {
         A.counters[0] += 1;                       // sweeps

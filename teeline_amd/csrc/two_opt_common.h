@@ -64,7 +64,10 @@ __device__ __forceinline__ float box_lb(float px, float py, float4 box)
 #define TL_DENSE_LEAD 4
 #endif
 static constexpr uint32_t kDenseLead = TL_DENSE_LEAD;  // waves active in round 1 of a dense step
-static constexpr uint32_t kMaxChainHits = 16;  // hits one wave may chain inside its tile before handing back
+#ifndef TL_MAX_CHAIN
+#define TL_MAX_CHAIN 16
+#endif
+static constexpr uint32_t kMaxChainHits = TL_MAX_CHAIN;  // hits one wave may chain inside its tile before handing back
 
 // Work the cascade really does, counted per wave with wave-uniform (SALU) adds: candidates (lanes) that entered L1, that
 // survived L1 into L2, that needed the exact L3, and tile bounds evaluated by L0 (lanes = tiles).  bench.py reports them
@@ -149,40 +152,75 @@ __device__ __forceinline__ bool tile_first_hit(const float2 *P, uint32_t n, uint
     return true;
 }
 
-// Dense mode: ALL improving moves of the reference's scan inside this tile, chained without leaving the wave.  After a hit
+// Dense mode: the improving moves of the reference's scan from this tile on, chained without leaving the wave.  After a hit
 // at lane l the row's b becomes the old P[j] (two_opt.rs:50 reverses p[i+1..=j], so p[i+1] := p[j]) and positions > j
-// are untouched, hence the lanes > l are simply decided again against the new b.  Hits are recorded in `hl`
-// (hl[0] = count, hl[1] = column at which the scan resumes, hl[2..] = hit columns); the first one is posted to the key
-// slot.  Only the list of the wave that owns the globally first hit is used afterwards.  Returns the number of hits.
+// are untouched, hence the lanes > l are simply decided again against the new b.  When the tile is exhausted and the wave
+// owns the row's first hit, it walks on alone through the next tiles for as long as hits keep coming (at most
+// kChainTiles tiles without one): early in a descent moves are a few candidates apart, and a further tile costs this wave
+// ~500 cycles where handing back costs the workgroup a whole step (two barriers and the step's accounting, ~3.6k).
+// Measured on the 256-restart batch (n = 10^4): 0 / 1 / 2 / 4 / 8 / 16 tiles -> 43.5k / 37.2k / 35.4k / 33.5k / 31.6k /
+// 29.6k steps per descent and 128.1 / 123.2 / 123.2 / 127.3 / 133.2 / 143.6 ms (the chance of a hit in the next tile falls
+// from ~18 % over the first two to ~5 % and ~3 % further out); choosing the count from the recent gap between moves, or
+// requesting the next tile's coordinates ahead, measured no better.
+// Hits are recorded in `hl` (hl[0] = count, hl[1] = column at which the scan resumes, hl[2..] = hit columns); the first
+// one is posted to the key slot.  Only the list of the wave that owns the globally first hit is used afterwards.
+// Returns the number of hits.
+#ifndef TL_CHAIN_TILES
+#define TL_CHAIN_TILES 2
+#endif
+static constexpr uint32_t kChainTiles = TL_CHAIN_TILES;
 template <bool PRUNE, typename TC>
 __device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint32_t i, uint32_t tb, uint32_t jmin,
                                                float ax, float ay, float bx, float by, float sqab,
                                                uint32_t *hl, uint32_t *keyslot, int lane, TC &tc)
 {
-    const uint32_t j = tb + (uint32_t)lane;
-    const float2 c = P[j], e = P[j + 1u];
+    uint32_t j = tb + (uint32_t)lane;
+    float2 c = P[j], e = P[j + 1u];
     uint64_t m = tile_mask_core<PRUNE>(c, e, j, n, jmin, ax, ay, bx, by, sqab, tc);
     if (m == 0) return 0;  // the common case: no chain state was ever set up
-    uint32_t from = jmin, nh = 0, hitv = 0;  // lane h of hitv holds the h-th hit column
+    uint32_t from = jmin, nh = 0, hitv = 0, mykey = 0;  // lane h of hitv holds the h-th hit column
+    bool capped = false;
     for (;;) {
         const int l = __builtin_ffsll((long long)m) - 1;
         const uint32_t jh = tb + (uint32_t)l;
         hitv = ((uint32_t)lane == nh) ? jh : hitv;
-        if (nh == 0 && lane == 0) atomicMin(keyslot, (i << 16) | jh);  // post at once: it stops the other waves' scans
+        if (nh == 0) {
+            mykey = (i << 16) | jh;
+            if (lane == 0) atomicMin(keyslot, mykey);  // post at once: it stops the other waves' scans
+        }
         ++nh;
         from = jh + 1u;
-        if (nh >= kMaxChainHits || l == 63 || from > n - 2u) break;
+        if (nh >= kMaxChainHits) {
+            capped = true;
+            break;
+        }
+        if (from > n - 2u) break;
         bx = readlane_f(c.x, l);  // new p[i+1] = old p[j]
         by = readlane_f(c.y, l);
         const float dx = ax - bx, dy = ay - by;
         sqab = dx * dx + dy * dy;
-        m = tile_mask_core<PRUNE>(c, e, j, n, from, ax, ay, bx, by, sqab, tc);
-        if (m == 0) break;
+        m = (l == 63) ? 0ull : tile_mask_core<PRUNE>(c, e, j, n, from, ax, ay, bx, by, sqab, tc);
+        uint32_t idle = 0;
+        bool stop = false;
+        while (m == 0) {  // tile exhausted: the next one, alone
+            // (a wave that does not own the first hit any more stops: its list will not be read)
+            if (idle >= kChainTiles || tb + 64u > n - 2u || (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot) != mykey) {
+                stop = true;
+                break;
+            }
+            ++idle;
+            tb += 64u;
+            j += 64u;
+            c = P[j];
+            e = P[j + 1u];
+            m = tile_mask_core<PRUNE>(c, e, j, n, from, ax, ay, bx, by, sqab, tc);
+        }
+        if (stop) break;
     }
     if ((uint32_t)lane < nh) hl[2u + (uint32_t)lane] = hitv;
     if (lane == 0) {
         hl[0] = nh;
-        hl[1] = (nh >= kMaxChainHits) ? from : (tb + 64u);  // tile exhausted unless the chain was cut short
+        hl[1] = capped ? from : (tb + 64u);  // every tile up to tb is exhausted unless the chain was cut short
     }
     return nh;
 }

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void k_dm_expand_full(const float *__restrict_
         tile[rr][lx] = v;
         if (r < n && c < n && c <= r) full[(size_t)r * n + c] = v;
     }
-    __syncthreads();
+    TL_SYNC();
     for (uint32_t rr = ly; rr < 64u; rr += 4u) {
         // mirrored element: full[c'][r'] with c' = tc*64 + rr (row of the upper part), r' = tr*64 + lx
         const uint32_t cu = tc * 64u + rr, ru = tr * 64u + lx;
@@ -79,9 +79,9 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
     }
     if (tid == 0) perm[n] = 0;
     if (tid < 4) keys[tid] = kNoKey;
-    __syncthreads();
+    TL_SYNC();
     for (uint32_t k = tid; k + 1u < n; k += kDmNT) edge[k] = dm[(size_t)perm[k] * n + perm[k + 1u]];
-    __syncthreads();
+    TL_SYNC();
 
     const uint32_t nrows = n - 3;
     uint32_t i0 = 0, j0 = 2, step = 0, sweeps = 1, status = 0;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
                 }
             }
         }
-        __syncthreads();
+        TL_SYNC();
         const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)keys[slot]);
         if (key == kNoKey) {
             i0 += R;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
                 edge[lo - 1u] = hv[2u * ww];
                 edge[hi] = hv[2u * ww + 1u];
             }
-            __syncthreads();
+            TL_SYNC();
             improved = true;
             ++moves;
             reversed += (uint64_t)(js - is);

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(1024) void k_rl_apply(LargeTwoOptArgs A)
     const uint32_t tid = threadIdx.x, n = A.n, nrows = n - 3u;
     const int lane = tid & 63, wave = tid >> 6;
     const uint32_t key = S->key, i0 = S->i0, R = S->rows;
-    __syncthreads();
+    TL_SYNC();
     uint32_t ni0, nj0, nrowsstep = R;
     bool improved = S->improved != 0u;
     if (key == kNoKey) {
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(1024) void k_rl_apply(LargeTwoOptArgs A)
             perm[lo + t] = v;
             perm[hi - t] = u;
         }
-        __syncthreads();
+        TL_SYNC();
         for (uint32_t t = ((lo - 1u) >> 6) + (uint32_t)wave; t <= (hi >> 6); t += 16u) build_tile_meta(P, n, t, lane, A.tbox, A.tmsq);
         improved = true;
         ni0 = is;

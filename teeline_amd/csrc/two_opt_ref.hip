@@ -142,7 +142,7 @@ __device__ __forceinline__ uint32_t flush_deferred(float2 *P, uint16_t *perm, ui
             }
         }
     }
-    __syncthreads();
+    TL_SYNC();
     if (wfirst <= ghi) {
 #pragma unroll
         for (int q = 0; q < kFlushSlots; ++q) {
@@ -155,7 +155,7 @@ __device__ __forceinline__ uint32_t flush_deferred(float2 *P, uint16_t *perm, ui
             }
         }
     }
-    __syncthreads();
+    TL_SYNC();
     return have ? g - (lo - 1u) : 0u;
 }
 
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         // entry >= n would index xy out of bounds, so the descent is refused (status 2, cost NaN, tour untouched)
         const uint32_t *__restrict__ src = A.init + (size_t)d * n;
         if (tid == 0) ctl->bad_init = 0u;
-        __syncthreads();
+        TL_SYNC();
         bool bad = false;
         for (uint32_t k = tid; k < n; k += NT) {
             const uint32_t v = src[k];
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             perm[k] = (uint16_t)v;
         }
         if (bad) ctl->bad_init = 1u;
-        __syncthreads();
+        TL_SYNC();
         if (ctl->bad_init) {
             if (tid == 0) {
                 A.out_cost[d] = __builtin_nanf("");
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             const uint64_t kth = (uint64_t)(n - 1 - i);  // i = n-1 is draw 0
             draws[i] = (uint16_t)(splitmix64_at(s, kth) % ((uint64_t)i + 1));
         }
-        __syncthreads();
+        TL_SYNC();
         if (tid == 0) {
             for (uint32_t i = n - 1; i >= 1; --i) {
                 const uint32_t j = draws[i];
@@ -245,11 +245,11 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         tbox[k] = make_float4(inf, inf, -inf, -inf);  // empty box: never live
         tmsq[k] = -1.0f;
     }
-    __syncthreads();
+    TL_SYNC();
     for (uint32_t k = tid; k < npad; k += NT) P[k] = (k < n) ? xy[perm[k]] : make_float2(0.f, 0.f);
-    __syncthreads();
+    TL_SYNC();
     for (uint32_t t = (uint32_t)wave; t < ntile; t += NW) build_tile_meta(P, n, t, lane, tbox, tmsq);
-    __syncthreads();
+    TL_SYNC();
 
     // ---------------------------------------------------------------- descent
     const uint32_t nrows = n - 3;  // rows i in [0, n-3); j in [i+2, n-2]
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 for (uint32_t t = dirty_lo + (uint32_t)wave; t <= dirty_hi; t += NW) build_tile_meta(P, n, t, lane, tbox, tmsq);
                 dirty_lo = 0xFFFFFFFFu;
                 dirty_hi = 0;
-                __syncthreads();
+                TL_SYNC();
             }
             // ---- pruned mode: wave w owns rows w, w+16, ... of the block.  L0 (lanes = tiles) yields the live-tile
             // mask of the row in SGPRs, L1 (lanes = j) runs on those tiles right away — no exchange between waves,
@@ -418,20 +418,21 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #endif
                 dense_tile<PRUNE>(P, n, i, t << 6, j0, ax, ay, bx, by, sqab, queues + ((t & 15u) | hpar) * kQCap, keyslot, lane, tc);
             }
-            __syncthreads();
-            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot) == kNoKey) {
-                for (uint32_t t = t0 + kDenseLead + (uint32_t)wave; t <= last_tile; t += NW) {
-                    const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot);
-                    if ((kb & 0xFFFFu) < (t << 6)) break;  // an earlier column already improves (kNoKey reads as column 65535)
+            TL_SYNC();
+            // Round 2.  A wave stops only at a hit in a column BEFORE its tile (a lead-round hit stops everybody at once).  A
+            // hit that another wave has just posted further right must not stop it: this tile may hold an earlier one (a
+            // blanket "some key is posted -> skip round 2" test here was a race between waves leaving the barrier).
+            for (uint32_t t = t0 + kDenseLead + (uint32_t)wave; t <= last_tile; t += NW) {
+                const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot);
+                if ((kb & 0xFFFFu) < (t << 6)) break;  // an earlier column already improves (kNoKey reads as column 65535)
 #ifdef TL_PROFILE
-                    ++livetiles;
+                ++livetiles;
 #endif
-                    if (dense_tile<PRUNE>(P, n, i, t << 6, j0, ax, ay, bx, by, sqab, queues + ((t & 15u) | hpar) * kQCap, keyslot, lane, tc)) break;
-                }
+                if (dense_tile<PRUNE>(P, n, i, t << 6, j0, ax, ay, bx, by, sqab, queues + ((t & 15u) | hpar) * kQCap, keyslot, lane, tc)) break;
             }
         }
         TL_STAMP(2);
-        __syncthreads();
+        TL_SYNC();
         TL_STAMP(3);
         const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->keys[slot]);
 #ifdef TL_PROFILE2
@@ -452,9 +453,9 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             // in `pendv` until the row ends (flush_deferred); the scan goes on at `resume` with b = the old p[hit].
             const uint32_t js = key & 0xFFFFu;
             const uint32_t *hl = queues + ((((js >> 6) & 15u) | hpar) * kQCap);
-            static_assert(kMaxChainHits == 16, "hl[2 + (hsel & 15)]");
-            const uint32_t hsel = (uint32_t)lane - np;  // lanes np .. np+nh-1 take the new hits (hl[] has kQCap words: any read is in range)
-            const uint32_t hval = hl[2u + (hsel & 15u)];
+            static_assert(2u + kMaxChainHits <= kQCap, "a hit list fits its slot");
+            const uint32_t hsel = (uint32_t)lane - np;  // lanes np .. np+nh-1 take the new hits
+            const uint32_t hval = hl[2u + (hsel < kMaxChainHits ? hsel : 0u)];
             const uint32_t nh = (uint32_t)__builtin_amdgcn_readfirstlane((int)hl[0]);
             const uint32_t resume = (uint32_t)__builtin_amdgcn_readfirstlane((int)hl[1]);
             pendv = hsel < nh ? hval : pendv;
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                         perm[hi - t2] = u2;
                     }
                 }
-                __syncthreads();
+                TL_SYNC();
                 ++moves;
                 reversed += (uint64_t)(hi - is);
                 // (for a hit in a later row of the block hi - j0 wraps to a huge value: the estimate then keeps the pruned block
@@ -566,11 +567,11 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     }
     float total = 0.0f;
     if (n >= 2) total = dist(P[n - 1], P[0]);
-    __syncthreads();
+    TL_SYNC();
     for (uint32_t base = 0; base + 1 < n; base += NT) {
         const uint32_t k = base + tid;
         scratch[tid] = (k + 1 < n) ? dist(P[k], P[k + 1]) : 0.0f;
-        __syncthreads();
+        TL_SYNC();
         if (tid == 0) {
             const uint32_t cnt = (n - 1 - base) < (uint32_t)NT ? (n - 1 - base) : (uint32_t)NT;
             const float4 *s4 = reinterpret_cast<const float4 *>(scratch);
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             }
             for (; qd < cnt; ++qd) total += scratch[qd];
         }
-        __syncthreads();
+        TL_SYNC();
     }
     // `reversed` of the deferred (dense-mode) reversals: per-lane shares of wave 0, summed
     if (wave == 0) {
