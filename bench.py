@@ -245,7 +245,8 @@ def main():
             assert torch.equal(d_pos2, d_pos) and torch.equal(d_cost2, d_cost), "the counting kernel variant gave other tours"
             w = d_stats2.cpu().numpy().astype(np.uint64)
             work = {"l0_tile_bounds": int(w[:, 5].sum()), "l1_candidates": int(w[:, 6].sum()),
-                    "l2_candidates": int(w[:, 7].sum()), "l3_candidates": int(w[:, 8].sum())}
+                    "l2_candidates": int(w[:, 7].sum()), "l3_candidates": int(w[:, 8].sum()),
+                    "pruned_rows": int(w[:, 11].sum()), "pruned_row_tile_passes": int(w[:, 12].sum())}
     ticks = st_host[:, 10].astype(np.float64)
     clock_hz = float(np.mean(st_host[:, 9].astype(np.float64) / np.maximum(ticks, 1.0))) * REFCLK_HZ if ticks.min() > 0 else 0.0
 

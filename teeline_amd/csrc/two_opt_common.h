@@ -74,13 +74,14 @@ static constexpr uint32_t kMaxChainHits = TL_MAX_CHAIN;  // hits one wave may ch
 // as "candidates touched" next to the algorithmic candidate count.
 struct TileCounts {
     uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+    uint32_t prow = 0, ptile = 0;  // pruned mode: rows bounded by L0, tile passes those rows ran (live tiles)
 };
 // The timed kernels carry NoCounts: the four live SGPR counters cost the LDS descent kernel 8 % (it is SGPR-bound: 22 -> 44
 // spilled SGPRs), so counting is a separate instantiation that bench.py launches once, untimed (TL_FLAG_COUNT_WORK).
 struct NoCounts {
     struct Sink {
         __device__ __forceinline__ void operator+=(uint32_t) {}
-    } l0, l1, l2, l3;
+    } l0, l1, l2, l3, prow, ptile;
 };
 
 // The improving columns of row (a, b) inside one 64-wide j tile (lane l holds c = P[tb+l], e = P[tb+l+1]) as a lane mask,

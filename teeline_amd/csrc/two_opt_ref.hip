@@ -58,7 +58,7 @@ constexpr int kMaxGroups = 4;         // 64-tile groups: n_pad <= 4 * 64 * 64 = 
 
 struct Ctl {                     // kCtlBytes of LDS
     uint32_t keys[4];
-    unsigned long long cnt[4];  // cascade work of the descent (TileCounts summed over the waves; counting instantiation)
+    unsigned long long cnt[6];  // cascade work of the descent (TileCounts summed over the waves; counting instantiation)
     unsigned long long clk0, rt0;  // s_memtime / s_memrealtime at the start of the descent (kept here, not in SGPRs)
     uint32_t bad_init;
 };
@@ -232,10 +232,8 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             }
         }
     }
-    if (tid < 4) {
-        ctl->keys[tid] = kNoKey;
-        ctl->cnt[tid] = 0ull;
-    }
+    if (tid < 4) ctl->keys[tid] = kNoKey;
+    if (tid < 6) ctl->cnt[tid] = 0ull;
     if (tid == 0) {
         ctl->clk0 = __builtin_amdgcn_s_memtime();
         ctl->rt0 = __builtin_amdgcn_s_memrealtime();
@@ -368,6 +366,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 const uint32_t jmin = (r == 0) ? j0 : (i + 2u);
                 const uint32_t tmin = jmin >> 6;
                 bool row_hit = false;
+                tc.prow += 1u;
 #pragma unroll
                 for (int gI = 0; gI < kMaxGroups; ++gI) {
                     if (gI < G && (((uint32_t)gI + 1u) << 6) > tmin) {  // groups wholly before the row's first column: nothing to test
@@ -381,6 +380,7 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                         while (m != 0 && hm == 0) {  // later tiles of this row are later columns
                             t = ((uint32_t)gI << 6) + (uint32_t)(__builtin_ffsll((long long)m) - 1);
                             m &= m - 1;
+                            tc.ptile += 1u;
 #ifdef TL_PROFILE
                             ++livetiles;
 #endif
@@ -563,6 +563,8 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             atomicAdd(&ctl->cnt[1], (unsigned long long)tc.l1);
             atomicAdd(&ctl->cnt[2], (unsigned long long)tc.l2);
             atomicAdd(&ctl->cnt[3], (unsigned long long)tc.l3);
+            atomicAdd(&ctl->cnt[4], (unsigned long long)tc.prow);
+            atomicAdd(&ctl->cnt[5], (unsigned long long)tc.ptile);
         }
     }
     float total = 0.0f;
@@ -612,6 +614,8 @@ __global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         st[6] = ctl->cnt[1];
         st[7] = ctl->cnt[2];
         st[8] = ctl->cnt[3];
+        st[11] = ctl->cnt[4];  // pruned mode: rows bounded by L0 and the tile passes they ran
+        st[12] = ctl->cnt[5];
         st[9] = __builtin_amdgcn_s_memtime() - ctl->clk0;
         st[10] = __builtin_amdgcn_s_memrealtime() - ctl->rt0;
 #endif
