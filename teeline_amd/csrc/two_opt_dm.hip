@@ -27,6 +27,10 @@ constexpr int kDmNT = 1024;
 #define TL_DM_TILES 4
 #endif
 constexpr int kDmTiles = TL_DM_TILES;  // 64-column tiles whose gathers are in flight together (wide mode)
+#ifndef TL_DM_CHAIN
+#define TL_DM_CHAIN 16
+#endif
+constexpr uint32_t kDmChain = TL_DM_CHAIN;  // improving moves one wave may chain inside its tile of a dense row
 }
 
 // packed strict lower triangle (idx(r > c) = r(r-1)/2 + c) -> full symmetric row-major n x n, zero diagonal
@@ -65,8 +69,14 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
     uint32_t *perm = reinterpret_cast<uint32_t *>(smem);            // n + 1 (pad)
     float *edge = reinterpret_cast<float *>(perm + nq);             // edge[j] = D[perm[j]][perm[j+1]], j < n-1
     uint32_t *keys = reinterpret_cast<uint32_t *>(edge + nq);       // 4 slots
-    float *hv = reinterpret_cast<float *>(keys + 4);                // per wave: D[a][c], D[b][e] of its first improving lane
-    float *rowbuf = hv + 2 * (kDmNT / 64);                          // STAGE: per wave two matrix rows of nq floats
+    // per wave: the improving moves it chained in its tile — column, D[a][c] and D[b][e] of the hit lane (the two new boundary
+    // edges of that reversal) — their count and the column at which the scan resumes
+    uint32_t *hl_j = keys + 4;                                      // [NW][kDmChain]
+    float *hl_a = reinterpret_cast<float *>(hl_j + (kDmNT / 64) * kDmChain);
+    float *hl_b = hl_a + (kDmNT / 64) * kDmChain;
+    uint32_t *hcnt = reinterpret_cast<uint32_t *>(hl_b + (kDmNT / 64) * kDmChain);  // [NW]
+    uint32_t *hres = hcnt + (kDmNT / 64);                           // [NW]
+    float *rowbuf = reinterpret_cast<float *>(hres + (kDmNT / 64)); // STAGE: per wave two matrix rows of nq floats
     const float *__restrict__ dm = A.dm_full;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t d = blockIdx.x;
@@ -157,8 +167,11 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
                             const uint32_t l = (uint32_t)(__builtin_ffsll((long long)m) - 1);
                             if (lane == l) {
                                 atomicMin(&keys[slot], (i << 16) | j);
-                                hv[2u * wave] = dac[u];
-                                hv[2u * wave + 1u] = dbe[u];
+                                hl_j[wave * kDmChain] = j;
+                                hl_a[wave * kDmChain] = dac[u];
+                                hl_b[wave * kDmChain] = dbe[u];
+                                hcnt[wave] = 1u;
+                                hres[wave] = j + 1u;
                             }
                             done = true;
                         }
@@ -177,17 +190,38 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
                 const uint32_t j = jb + lane;
                 const uint32_t jj = j <= n - 2u ? j : n - 2u;
                 const uint32_t c = perm[jj], e = perm[jj + 1u];
-                const float dac = rowa[c], dbe = rowb[e];
-                const float cur = dab + edge[jj];
-                const float neu = dac + dbe;
-                const bool imp = (j >= j0) & (j <= n - 2u) & (neu < cur);
-                const uint64_t m = __builtin_amdgcn_ballot_w64(imp);
+                const float dac = rowa[c], dce = edge[jj];
+                float dbe = rowb[e];
+                float dabc = dab;
+                bool imp = (j >= j0) & (j <= n - 2u) & (dac + dbe < dabc + dce);
+                uint64_t m = __builtin_amdgcn_ballot_w64(imp);
                 if (m) {
-                    const uint32_t l = (uint32_t)(__builtin_ffsll((long long)m) - 1);
-                    if (lane == l) {
-                        atomicMin(&keys[slot], (i << 16) | j);
-                        hv[2u * wave] = dac;
-                        hv[2u * wave + 1u] = dbe;
+                    // Chain every improving move of the reference's scan inside this tile: after a hit at lane l the row's b is
+                    // the old perm[j] (two_opt.rs:50 reverses p[i+1..=j]), positions > j are untouched, so the lanes > l are
+                    // decided again with D[b'][e] gathered from the new b's matrix row and D[a][b'] = the hit lane's D[a][c].
+                    // The reversals themselves wait until the step's barrier (they all start at i+1).
+                    uint32_t nh = 0, jh = 0;
+                    for (;;) {
+                        const uint32_t l = (uint32_t)(__builtin_ffsll((long long)m) - 1);
+                        jh = jb + l;
+                        if (lane == l) {
+                            if (nh == 0) atomicMin(&keys[slot], (i << 16) | jh);
+                            hl_j[wave * kDmChain + nh] = jh;
+                            hl_a[wave * kDmChain + nh] = dac;
+                            hl_b[wave * kDmChain + nh] = dbe;
+                        }
+                        ++nh;
+                        if (nh >= kDmChain || l == 63u || jh + 1u > n - 2u) break;
+                        const uint32_t bn = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)l);
+                        dabc = readlane_f(dac, (int)l);
+                        dbe = dm[(size_t)bn * n + e];
+                        imp = (j > jh) & (j <= n - 2u) & (dac + dbe < dabc + dce);
+                        m = __builtin_amdgcn_ballot_w64(imp);
+                        if (!m) break;
+                    }
+                    if (lane == 0) {
+                        hcnt[wave] = nh;
+                        hres[wave] = nh >= kDmChain ? jh + 1u : jb + 64u;  // the tile is exhausted unless the chain was cut short
                     }
                     break;
                 }
@@ -203,33 +237,38 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
             const uint32_t is = key >> 16, js = key & 0xFFFFu;
             gap_rows = (gap_rows + since_rows + (is - i0) + 1u) >> 1;  // running estimate of the rows between moves
             since_rows = 0;
-            const uint32_t lo = is + 1u, hi = js;  // swap_2opt(path, i+1, j), two_opt.rs:69-79
             // the wave that posted the winning key: its row in a wide block, its tile of the row in a dense one
             const uint32_t ww = wide ? is - i0 : ((js - jbase) >> 6) & (NWv - 1u);
-            const uint32_t half = (hi - lo + 1u) >> 1;
-            for (uint32_t t = tid; t < half; t += kDmNT) {
-                const uint32_t u = perm[lo + t], v = perm[hi - t];
-                perm[lo + t] = v;
-                perm[hi - t] = u;
+            const uint32_t nh = (uint32_t)__builtin_amdgcn_readfirstlane((int)hcnt[ww]);
+            const uint32_t resume = (uint32_t)__builtin_amdgcn_readfirstlane((int)hres[ww]);
+            const uint32_t lo = is + 1u;
+            for (uint32_t h = 0; h < nh; ++h) {  // swap_2opt(path, i+1, j), two_opt.rs:69-79, in the order the reference applies them
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hl_j[ww * kDmChain + h]);
+                const uint32_t half = (hi - lo + 1u) >> 1;
+                for (uint32_t t = tid; t < half; t += kDmNT) {
+                    const uint32_t u = perm[lo + t], v = perm[hi - t];
+                    perm[lo + t] = v;
+                    perm[hi - t] = u;
+                }
+                // edges inside the segment keep their lengths in reversed order (the matrix is symmetric); the two boundary
+                // edges become (a, c) and (b, e)
+                const uint32_t ehalf = (hi - lo) >> 1;
+                for (uint32_t t = tid; t < ehalf; t += kDmNT) {
+                    const float x = edge[lo + t], y = edge[hi - 1u - t];
+                    edge[lo + t] = y;
+                    edge[hi - 1u - t] = x;
+                }
+                if (tid == 0) {
+                    edge[lo - 1u] = hl_a[ww * kDmChain + h];
+                    edge[hi] = hl_b[ww * kDmChain + h];
+                }
+                reversed += (uint64_t)(hi - is);
+                TL_SYNC();
             }
-            // edges inside the segment keep their lengths in reversed order (the matrix is symmetric); the two boundary
-            // edges become (a, c) and (b, e)
-            const uint32_t ehalf = (hi - lo) >> 1;
-            for (uint32_t t = tid; t < ehalf; t += kDmNT) {
-                const float x = edge[lo + t], y = edge[hi - 1u - t];
-                edge[lo + t] = y;
-                edge[hi - 1u - t] = x;
-            }
-            if (tid == 0) {
-                edge[lo - 1u] = hv[2u * ww];
-                edge[hi] = hv[2u * ww + 1u];
-            }
-            TL_SYNC();
             improved = true;
-            ++moves;
-            reversed += (uint64_t)(js - is);
+            moves += nh;
             i0 = is;
-            j0 = js + 1u;
+            j0 = resume;
             if (j0 > n - 2u) {
                 ++i0;
                 j0 = i0 + 2u;
@@ -260,7 +299,11 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
         uint64_t *st = A.out_stats + (size_t)d * TL_STATS_STRIDE;
         st[0] = sweeps;
         st[1] = moves;
+#ifdef TL_DM_REPORT_STEPS
+        st[2] = step;  // tuning builds: steps instead of reversed elements
+#else
         st[2] = reversed;
+#endif
         st[3] = status;
         st[4] = step;
     }
@@ -268,7 +311,7 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
 
 size_t two_opt_ref_dm_lds_bytes(uint32_t n)
 {
-    return (size_t)((n + 1u + 3u) & ~3u) * 8 + 16 + (size_t)(kDmNT / 64) * 8;
+    return (size_t)((n + 1u + 3u) & ~3u) * 8 + 16 + (size_t)(kDmNT / 64) * (kDmChain * 12 + 8);
 }
 static size_t two_opt_ref_dm_stage_bytes(uint32_t n) { return (size_t)((n + 1u + 3u) & ~3u) * 4 * 2 * (kDmNT / 64); }
 
