@@ -978,6 +978,14 @@ __global__ __launch_bounds__(1024) void k_lk_scan_sub(LkArgs G)
         else { q1 = sub / k1; s1 = sub % k1; s2 = 0u; }
     }
     if (idx >= G.state->window) return;  // prefix window (k_lk_control)
+    // fused pick (one workgroup = one pair): the pair's first chain in DFS order = the lowest sub-search index that found one;
+    // its lane still holds the chain, validates it and posts the pair (what k_lk_scan_pick does from pairmin / subchains)
+    __shared__ uint32_t s_minsub;
+    const bool fused = BLOCK3D && G.fused_pick != 0u;
+    if (fused) {
+        if (sub == 0u) s_minsub = 0xFFFFFFFFu;
+        TL_SYNC();
+    }
     const uint32_t t1 = G.city_ids[idx >> 1];
     const uint32_t t2 = (idx & 1u) ? G.prev[t1] : G.next[t1];
     const float2 p1 = G.xy[t1], p2 = G.xy[t2];
@@ -989,6 +997,17 @@ __global__ __launch_bounds__(1024) void k_lk_scan_sub(LkArgs G)
     LkView V{G.xy, G.cand, G.next, G.k, G.max_depth};
     const bool got = G.split_levels == 3u ? lk_subsearch3<uint32_t>(V, chain, clen, p1, t2, p2, g0, q1, s1, s2)
                                           : lk_subsearch<uint32_t>(V, chain, clen, p1, t1, t2, p2, g0, q1, s1);
+    if (fused) {
+        if (got) atomicMin(&s_minsub, sub);
+        TL_SYNC();
+        if (got && s_minsub == sub && chain_valid(chain, clen, G.tour, G.pos, n)) {
+            uint32_t *slot = G.chains + (size_t)idx * (kLkMaxChain + 2);
+            slot[0] = clen;
+            for (uint32_t t = 0; t < clen; ++t) slot[1 + t] = chain[t];
+            atomicMin(&G.state->key, idx);
+        }
+        return;
+    }
     if (got) {
         if (G.subchains) {  // keep the chain: the pick step reads the winner's instead of walking it again
             uint32_t *slot = G.subchains + g * kLkSubSlot;
@@ -1281,7 +1300,7 @@ hipError_t launch_lk_round(const LkArgs &G, hipStream_t s)
         } else {
             hipLaunchKernelGGL(k_lk_scan_sub<false>, dim3((uint32_t)((lanes + 255u) / 256u)), dim3(256), 0, s, G);
         }
-        hipLaunchKernelGGL(k_lk_scan_pick, dim3((2u * G.n + 255u) / 256u), dim3(256), 0, s, G);
+        if (!(G.fused_pick && per_pair <= 1024u)) hipLaunchKernelGGL(k_lk_scan_pick, dim3((2u * G.n + 255u) / 256u), dim3(256), 0, s, G);
     } else {
         const size_t lds = (size_t)G.n * 10;
         if (G.n < 65536u && lds <= (size_t)G.lds_budget) {

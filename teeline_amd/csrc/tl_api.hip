@@ -1186,7 +1186,7 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const float *dm_pac
     if (const char *e = getenv("TL_LK_SMALL_MAX_N")) small_max_n = (uint32_t)atoi(e);
     if (const char *e = getenv("TL_LK_SMALL_NT")) small_nt = atoi(e);
 #endif
-    const uint32_t variant_flags = TL_FLAG_LK_ONE_WORKGROUP | TL_FLAG_LK_NO_SPLIT | TL_FLAG_LK_SPLIT2 | TL_FLAG_LK_NO_SUBCHAINS;
+    const uint32_t variant_flags = TL_FLAG_LK_ONE_WORKGROUP | TL_FLAG_LK_NO_SPLIT | TL_FLAG_LK_SPLIT2 | TL_FLAG_LK_NO_SUBCHAINS | TL_FLAG_LK_SEPARATE_PICK;
     const bool lk_small = ((c->flags & TL_FLAG_LK_SMALL) || (!(c->flags & variant_flags) && n <= small_max_n)) &&
                           lk_small_lds_bytes(n, k_small) + 4096 <= (size_t)c->lds_bytes;
     const bool multi_cu = !(c->flags & TL_FLAG_LK_ONE_WORKGROUP) && !lk_small;
@@ -1198,7 +1198,10 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const float *dm_pac
     // kept chains fit 4 GB, else two
     const uint32_t levels = (split_scan && !(c->flags & TL_FLAG_LK_SPLIT2) && (size_t)2 * n * k * (k + 1) * (k + 1) * 64 <= ((size_t)4 << 30)) ? 3u : 2u;
     const size_t sub_b = split_scan ? (size_t)2 * n * k * (k + 1) * (levels == 3u ? k + 1 : 1) * 64 : 0;
-    const bool keep_sub = split_scan && sub_b <= ((size_t)4 << 30) && !(c->flags & TL_FLAG_LK_NO_SUBCHAINS);
+    // one workgroup per pair (k(k+1)^2 or k(k+1) <= 1024 threads): the scan picks and validates the pair's first chain itself
+    const bool fused_pick = split_scan && (size_t)k * (k + 1) * (levels == 3u ? k + 1 : 1) <= 1024 &&
+                            !(c->flags & (TL_FLAG_LK_SEPARATE_PICK | TL_FLAG_LK_NO_SUBCHAINS));
+    const bool keep_sub = split_scan && !fused_pick && sub_b <= ((size_t)4 << 30) && !(c->flags & TL_FLAG_LK_NO_SUBCHAINS);
     const size_t o_sub = o_pairmin + (split_scan ? up((size_t)2 * n * 4) : 0);
     const size_t total = o_sub + (keep_sub ? up(sub_b) : 0);
     if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->work, total)) || (rc = ensure(c, c->out_cost, 4))) return rc;
@@ -1248,6 +1251,7 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const float *dm_pac
     G.pairmin = split_scan ? (uint32_t *)(w + o_pairmin) : nullptr;
     G.subchains = keep_sub ? (uint32_t *)(w + o_sub) : nullptr;
     G.split_levels = levels;
+    G.fused_pick = fused_pick ? 1u : 0u;
     if (split_scan) HIPCHK(c, hipMemsetAsync(G.pairmin, 0xFF, (size_t)2 * n * 4, c->stream));
     uint64_t cnt[4] = {0, 0, 0, 0};
     if (!multi_cu) {

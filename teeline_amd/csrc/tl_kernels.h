@@ -171,6 +171,8 @@ struct LkArgs {
     uint32_t n, k, max_depth, epochs, platoo_epochs;
     uint32_t lds_budget;    // LDS bytes a scan workgroup may use for its xy/next copies
     uint32_t split_levels;  // split scan: 2 = k(k+1) sub-searches per pair, 3 = k(k+1)^2
+    uint32_t fused_pick;    // split scan, one workgroup per pair: the workgroup picks its first chain and validates it itself
+                            // (no k_lk_scan_pick launch, no pairmin / subchains traffic)
 };
 // form: 0 = default (16 lanes per city up to n = 32 K, 4 beyond), 4 = four lanes per city, 1 = one lane per city
 hipError_t launch_knn(const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, hipStream_t s, int form = 0);

@@ -149,7 +149,8 @@ def test_lk_wide_candidate_lists(ctx):
 
 def test_lk_variants_are_identical(tsplib_dir):
     # default = scans spread over all CUs, each pair's chain search split into k*(k+1)^2 sub-searches (TL_FLAG_LK_SPLIT2: k*(k+1)), device-side control
-    # state machine, kept sub-search chains.  The unsplit scan, the single persistent workgroup and the pick step that walks the
+    # state machine, the pair's first chain picked and validated by the scan workgroup itself (TL_FLAG_LK_SEPARATE_PICK: by a kernel of
+    # its own, from kept sub-search chains).  The unsplit scan, the single persistent workgroup and the pick step that walks the
     # winning chain again must reproduce the same results (= the oracle's).
     xy = T.parse_tsplib(os.path.join(tsplib_dir, "berlin52.tsp"))["xy"]
     lat = lattice(10, 2)
@@ -157,7 +158,8 @@ def test_lk_variants_are_identical(tsplib_dir):
     sq = np.array([[0, 0], [1, 1], [1, 0], [0, 1]], np.float32)
     tri = np.array([[0, 0], [1, 0], [0.5, 1]], np.float32)
     import teeline_amd as TA
-    for flag in (TA.TL_FLAG_LK_NO_SPLIT, TA.TL_FLAG_LK_ONE_WORKGROUP, TA.TL_FLAG_LK_NO_SUBCHAINS, TA.TL_FLAG_LK_SPLIT2, TA.TL_FLAG_LK_SMALL):
+    for flag in (TA.TL_FLAG_LK_NO_SPLIT, TA.TL_FLAG_LK_ONE_WORKGROUP, TA.TL_FLAG_LK_NO_SUBCHAINS, TA.TL_FLAG_LK_SPLIT2, TA.TL_FLAG_LK_SMALL,
+                 TA.TL_FLAG_LK_SEPARATE_PICK, TA.TL_FLAG_LK_SEPARATE_PICK | TA.TL_FLAG_LK_SPLIT2):
         with TA.Context(0, flag) as ctx:
             for seed in (1, 2):
                 assert_same(gpu_lk(ctx, xy, seed=seed), O.lin_kernighan(xy, seed=seed))
