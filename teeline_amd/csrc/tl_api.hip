@@ -1186,7 +1186,7 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const float *dm_pac
     if (const char *e = getenv("TL_LK_SMALL_MAX_N")) small_max_n = (uint32_t)atoi(e);
     if (const char *e = getenv("TL_LK_SMALL_NT")) small_nt = atoi(e);
 #endif
-    const uint32_t variant_flags = TL_FLAG_LK_ONE_WORKGROUP | TL_FLAG_LK_NO_SPLIT | TL_FLAG_LK_SPLIT2 | TL_FLAG_LK_NO_SUBCHAINS | TL_FLAG_LK_SEPARATE_PICK;
+    const uint32_t variant_flags = TL_FLAG_LK_ONE_WORKGROUP | TL_FLAG_LK_NO_SPLIT | TL_FLAG_LK_SPLIT2 | TL_FLAG_LK_NO_SUBCHAINS | TL_FLAG_LK_SEPARATE_PICK | TL_FLAG_LK_NO_GRAPH;
     const bool lk_small = ((c->flags & TL_FLAG_LK_SMALL) || (!(c->flags & variant_flags) && n <= small_max_n)) &&
                           lk_small_lds_bytes(n, k_small) + 4096 <= (size_t)c->lds_bytes;
     const bool multi_cu = !(c->flags & TL_FLAG_LK_ONE_WORKGROUP) && !lk_small;
@@ -1259,12 +1259,41 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const float *dm_pac
     } else {
         HIPCHK(c, launch_lk_begin(G, c->stream));
         LkState hs{};
+        // 64 rounds per poll of `finished` (the kernels are no-ops once it is set).  The first batch is enqueued launch by
+        // launch; a search that is still running after it replays the same 64 rounds as ONE hipGraph launch per poll — a round
+        // is 2-3 short kernels (tens of microseconds), and the host's per-launch cost and the gaps between separately
+        // enqueued kernels are a visible part of it.
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t gexec = nullptr;
+        bool first = true, graph_ok = !(c->flags & TL_FLAG_LK_NO_GRAPH);
+        int rc_loop = TL_OK;
         for (;;) {
-            for (int r = 0; r < 64; ++r) HIPCHK(c, launch_lk_round(G, c->stream));  // kernels no-op once finished
-            HIPCHK(c, hipMemcpyAsync(&hs, G.state, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (!first && graph_ok && !gexec) {
+                graph_ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                if (graph_ok) {
+                    hipError_t le = hipSuccess;
+                    for (int r = 0; r < 64 && le == hipSuccess; ++r) le = launch_lk_round(G, c->stream);
+                    const hipError_t ce = hipStreamEndCapture(c->stream, &graph);
+                    graph_ok = le == hipSuccess && ce == hipSuccess && graph &&
+                               hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) == hipSuccess;
+                    if (!graph_ok) (void)hipGetLastError();  // separately enqueued launches from here on
+                }
+            }
+            hipError_t e = hipSuccess;
+            if (gexec) e = hipGraphLaunch(gexec, c->stream);
+            else for (int r = 0; r < 64 && e == hipSuccess; ++r) e = launch_lk_round(G, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&hs, G.state, sizeof(hs), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) {
+                rc_loop = fail(c, TL_ERR_HIP, "tl_lk: %s", hipGetErrorString(e));
+                break;
+            }
+            first = false;
             if (hs.finished) break;
         }
+        if (gexec) (void)hipGraphExecDestroy(gexec);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (rc_loop != TL_OK) return rc_loop;
         cnt[0] = hs.scans;
         cnt[1] = hs.searches;
         cnt[2] = hs.moves;

@@ -159,7 +159,7 @@ def test_lk_variants_are_identical(tsplib_dir):
     tri = np.array([[0, 0], [1, 0], [0.5, 1]], np.float32)
     import teeline_amd as TA
     for flag in (TA.TL_FLAG_LK_NO_SPLIT, TA.TL_FLAG_LK_ONE_WORKGROUP, TA.TL_FLAG_LK_NO_SUBCHAINS, TA.TL_FLAG_LK_SPLIT2, TA.TL_FLAG_LK_SMALL,
-                 TA.TL_FLAG_LK_SEPARATE_PICK, TA.TL_FLAG_LK_SEPARATE_PICK | TA.TL_FLAG_LK_SPLIT2):
+                 TA.TL_FLAG_LK_SEPARATE_PICK, TA.TL_FLAG_LK_SEPARATE_PICK | TA.TL_FLAG_LK_SPLIT2, TA.TL_FLAG_LK_NO_GRAPH):
         with TA.Context(0, flag) as ctx:
             for seed in (1, 2):
                 assert_same(gpu_lk(ctx, xy, seed=seed), O.lin_kernighan(xy, seed=seed))
