@@ -393,6 +393,7 @@ __host__ __device__ __forceinline__ uint32_t lk_subs(const LkArgs &G)  // sub-se
 
 constexpr int kLkMaxDepth = 6;                       // compile-time recursion bound (default max_depth = 5)
 constexpr int kLkMaxChain = 2 * kLkMaxDepth + 2;
+constexpr uint32_t kLkTailCap = 48, kLkTailWords = 10;  // parked depth-3 walks of one scan workgroup (k_lk_scan_sub)
 constexpr uint32_t kLkSubSlot = 16;                 // u32 words per kept sub-search chain (len + kLkMaxChain cities, 64-byte slots)
 static_assert(kLkMaxChain + 1 <= 16, "sub-chain slot");
 
@@ -937,6 +938,87 @@ __device__ bool lk_subsearch3(const LkViewT<NextT> &V, uint32_t (&chain)[kLkMaxC
     return lk_chain<3, NextT>(V, chain, clen, p1, t_open, p_open, gain);
 }
 
+// lk_subsearch3 cut in two for the fused scan (k_lk_scan_sub): the FRONT walks the three split levels and stops where the
+// sequential walk lk_chain<3> would begin — 0: no chain, 1: chain (clen set), 2: a walk is pending at depth 3 with
+// (chain[0..8), t_open = chain[7], p_open, gain), its depth-3 closing test already failed.
+template <typename NextT>
+__device__ int lk_subsearch3_front(const LkViewT<NextT> &V, uint32_t (&chain)[kLkMaxChain], uint32_t &clen, const float2 p1, const uint32_t t2,
+                                   const float2 p2, const float g0, const uint32_t q1, const uint32_t s1, const uint32_t s2, float2 &p_open_out,
+                                   float &gain_out)
+{
+    uint32_t t_open = t2;
+    float2 p_open = p2;
+    float gain = g0;
+    if (0u >= V.max_depth) return 0;
+    if (!lk_branch<0, NextT>(V, chain, t_open, p_open, gain, q1)) return 0;
+    {
+        const float close_gain = gain - dist(p_open, p1);
+        if (s1 == 0u) {
+            if (s2 == 0u && close_gain > kLkEps) {
+                clen = 4;
+                return 1;
+            }
+            return 0;
+        }
+        if (close_gain > kLkEps) return 0;
+        if (1u >= V.max_depth) return 0;
+    }
+    if (!lk_branch<1, NextT>(V, chain, t_open, p_open, gain, s1 - 1u)) return 0;
+    {
+        const float close_gain = gain - dist(p_open, p1);
+        if (s2 == 0u) {
+            if (close_gain > kLkEps) {
+                clen = 6;
+                return 1;
+            }
+            return 0;
+        }
+        if (close_gain > kLkEps) return 0;
+        if (2u >= V.max_depth) return 0;
+    }
+    if (!lk_branch<2, NextT>(V, chain, t_open, p_open, gain, s2 - 1u)) return 0;
+    // lk_chain<3>'s head (:280-288)
+    if (gain - dist(p_open, p1) > kLkEps) {
+        clen = 8;
+        return 1;
+    }
+    if (3u >= V.max_depth) return 0;
+    p_open_out = p_open;
+    gain_out = gain;
+    return 2;
+}
+
+// One (q3, s4) branch of a pending depth-3 walk: candidate q3 of t_open at depth 3; at depth 4 the closing test (s4 = 0) or
+// candidate s4 - 1, below which lk_chain<5> is a closing test (and, only for max_depth = 6, one more candidate loop).
+// Lexicographic order of (q3, s4) is the DFS order of lk_chain<3>, for the reasons given at lk_subsearch.
+template <typename NextT>
+__device__ bool lk_tail_branch(const LkViewT<NextT> &V, uint32_t (&chain)[kLkMaxChain], uint32_t &clen, const float2 p1, float2 p_open, float gain,
+                               const uint32_t q3, const uint32_t s4)
+{
+    uint32_t t_open = chain[7];
+    if (!lk_branch<3, NextT>(V, chain, t_open, p_open, gain, q3)) return false;
+    const float close_gain = gain - dist(p_open, p1);
+    if (s4 == 0u) {
+        if (close_gain > kLkEps) {
+            clen = 10;
+            return true;
+        }
+        return false;
+    }
+    if (close_gain > kLkEps) return false;  // the sequential walk returned at s4 = 0
+    if (4u >= V.max_depth) return false;
+    if (!lk_branch<4, NextT>(V, chain, t_open, p_open, gain, s4 - 1u)) return false;
+    return lk_chain<5, NextT>(V, chain, clen, p1, t_open, p_open, gain);
+}
+
+// the rest of lk_chain<3> for a walk whose head (closing test, depth limit) the front has already passed: the head is
+// repeated (it fails again) — only used when the workgroup's queue of parked walks is full
+template <typename NextT>
+__device__ bool lk_chain_from3(const LkViewT<NextT> &V, uint32_t (&chain)[kLkMaxChain], uint32_t &clen, const float2 p1, const float2 p_open, const float gain)
+{
+    return lk_chain<3, NextT>(V, chain, clen, p1, chain[7], p_open, gain);
+}
+
 // the sub-search `sub` of pair (t1, t2) under the launch's split depth
 __device__ __forceinline__ bool lk_run_sub(const LkArgs &G, uint32_t (&chain)[kLkMaxChain], uint32_t &clen, const float2 p1, const uint32_t t1,
                                            const uint32_t t2, const float2 p2, const float g0, const uint32_t sub)
@@ -980,10 +1062,14 @@ __global__ __launch_bounds__(1024) void k_lk_scan_sub(LkArgs G)
     if (idx >= G.state->window) return;  // prefix window (k_lk_control)
     // fused pick (one workgroup = one pair): the pair's first chain in DFS order = the lowest sub-search index that found one;
     // its lane still holds the chain, validates it and posts the pair (what k_lk_scan_pick does from pairmin / subchains)
-    __shared__ uint32_t s_minsub;
+    __shared__ uint32_t s_minkey, s_qn;
+    __shared__ uint32_t s_q[kLkTailCap][kLkTailWords];
     const bool fused = BLOCK3D && G.fused_pick != 0u;
     if (fused) {
-        if (sub == 0u) s_minsub = 0xFFFFFFFFu;
+        if (sub == 0u) {
+            s_minkey = 0xFFFFFFFFu;
+            s_qn = 0u;
+        }
         TL_SYNC();
     }
     const uint32_t t1 = G.city_ids[idx >> 1];
@@ -995,12 +1081,68 @@ __global__ __launch_bounds__(1024) void k_lk_scan_sub(LkArgs G)
     chain[1] = t2;
     const float g0 = t1 == t2 ? 0.0f : dist(p1, p2);
     LkView V{G.xy, G.cand, G.next, G.k, G.max_depth};
+    if (fused && G.split_levels == 3u) {
+        // Deferred tails.  What a scan waits for is the few lanes whose walk survives the three split levels and goes on
+        // alone through up to k + k^2 candidates, three dependent look-ups each (measured: 58 us per scan, 23 us with
+        // those walks cut off).  So a surviving lane parks its state in LDS and the workgroup — most of whose lanes failed
+        // their first test long ago — deals the next two levels out again: lane = (parked walk, candidate q3 at depth 3,
+        // closing test or candidate at depth 4).  The order key (sub, q3, s4) is the walk's DFS order, so the smallest
+        // key with a chain is the reference's first chain.
+        const uint32_t nthr = blockDim.x * blockDim.y * blockDim.z, k1 = G.k + 1u, per = G.k * k1;
+        uint32_t mykey = 0xFFFFFFFFu;
+        float2 p_open;
+        float gain;
+        const int st = lk_subsearch3_front<uint32_t>(V, chain, clen, p1, t2, p2, g0, q1, s1, s2, p_open, gain);
+        if (st == 1) mykey = sub * (per + 1u);
+        if (st == 2) {
+            const uint32_t slot = atomicAdd(&s_qn, 1u);
+            if (slot < kLkTailCap) {
+#pragma unroll
+                for (int t = 0; t < 6; ++t) s_q[slot][t] = chain[2 + t];
+                s_q[slot][6] = __float_as_uint(gain);
+                s_q[slot][7] = sub;
+                s_q[slot][8] = __float_as_uint(p_open.x);
+                s_q[slot][9] = __float_as_uint(p_open.y);
+            } else if (lk_chain_from3<uint32_t>(V, chain, clen, p1, p_open, gain)) {  // queue full: walk on alone
+                mykey = sub * (per + 1u);
+            }
+        }
+        TL_SYNC();
+        const uint32_t nq = s_qn < kLkTailCap ? s_qn : kLkTailCap;
+        for (uint32_t w = sub; w < nq * per; w += nthr) {
+            const uint32_t e = w / per, r = w - e * per, q3 = r / k1, s4 = r - q3 * k1;
+            const uint32_t key = s_q[e][7] * (per + 1u) + 1u + r;
+            if (key >= mykey) continue;  // this lane already holds an earlier chain
+            uint32_t c2[kLkMaxChain];
+            uint32_t l2 = 0;
+            c2[0] = t1;
+            c2[1] = t2;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) c2[2 + t] = s_q[e][t];
+            const float2 po = make_float2(__uint_as_float(s_q[e][8]), __uint_as_float(s_q[e][9]));
+            if (lk_tail_branch<uint32_t>(V, c2, l2, p1, po, __uint_as_float(s_q[e][6]), q3, s4)) {
+                mykey = key;
+                clen = l2;
+#pragma unroll
+                for (int t = 0; t < kLkMaxChain; ++t) chain[t] = c2[t];
+            }
+        }
+        if (mykey != 0xFFFFFFFFu) atomicMin(&s_minkey, mykey);
+        TL_SYNC();
+        if (mykey != 0xFFFFFFFFu && s_minkey == mykey && chain_valid(chain, clen, G.tour, G.pos, n)) {
+            uint32_t *slot = G.chains + (size_t)idx * (kLkMaxChain + 2);
+            slot[0] = clen;
+            for (uint32_t t = 0; t < clen; ++t) slot[1 + t] = chain[t];
+            atomicMin(&G.state->key, idx);
+        }
+        return;
+    }
     const bool got = G.split_levels == 3u ? lk_subsearch3<uint32_t>(V, chain, clen, p1, t2, p2, g0, q1, s1, s2)
                                           : lk_subsearch<uint32_t>(V, chain, clen, p1, t1, t2, p2, g0, q1, s1);
     if (fused) {
-        if (got) atomicMin(&s_minsub, sub);
+        if (got) atomicMin(&s_minkey, sub);
         TL_SYNC();
-        if (got && s_minsub == sub && chain_valid(chain, clen, G.tour, G.pos, n)) {
+        if (got && s_minkey == sub && chain_valid(chain, clen, G.tour, G.pos, n)) {
             uint32_t *slot = G.chains + (size_t)idx * (kLkMaxChain + 2);
             slot[0] = clen;
             for (uint32_t t = 0; t < clen; ++t) slot[1 + t] = chain[t];
