@@ -393,6 +393,7 @@ __host__ __device__ __forceinline__ uint32_t lk_subs(const LkArgs &G)  // sub-se
 
 constexpr int kLkMaxDepth = 6;                       // compile-time recursion bound (default max_depth = 5)
 constexpr int kLkMaxChain = 2 * kLkMaxDepth + 2;
+constexpr uint32_t kLkSlot = 32;  // u32 words per pair in LkArgs::chains: length, the chain's cities, (chip-wide step) their tour positions
 constexpr uint32_t kLkTailCap = 48, kLkTailWords = 10;  // parked depth-3 walks of one scan workgroup (k_lk_scan_sub)
 constexpr uint32_t kLkSubSlot = 16;                 // u32 words per kept sub-search chain (len + kLkMaxChain cities, 64-byte slots)
 static_assert(kLkMaxChain + 1 <= 16, "sub-chain slot");
@@ -814,7 +815,7 @@ __global__ __launch_bounds__(256) void k_lk_scan(LkArgs G)
         found = lk_chain<0, uint32_t>(V, chain, clen, p1, t2, p2, g0);
     }
     if (found && chain_valid(chain, clen, G.tour, G.pos, n)) {
-        uint32_t *slot = G.chains + (size_t)idx * (kLkMaxChain + 2);
+        uint32_t *slot = G.chains + (size_t)idx * kLkSlot;
         slot[0] = clen;
         for (uint32_t t = 0; t < clen; ++t) slot[1 + t] = chain[t];
         atomicMin(&S->key, idx);
@@ -1033,7 +1034,7 @@ __device__ __forceinline__ bool lk_run_sub(const LkArgs &G, uint32_t (&chain)[kL
 // k(k+1)^2 > 1024) recovers them with a 64-bit and three 32-bit divisions per lane, which is most of what a lane that fails
 // its first test executes.
 template <bool BLOCK3D>
-__global__ __launch_bounds__(1024) void k_lk_scan_sub(LkArgs G)
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lk_scan_sub(LkArgs G)
 {
     if (G.state->finished) return;
     const uint32_t n = G.n, subs = lk_subs(G);
@@ -1069,6 +1070,8 @@ __global__ __launch_bounds__(1024) void k_lk_scan_sub(LkArgs G)
         if (sub == 0u) {
             s_minkey = 0xFFFFFFFFu;
             s_qn = 0u;
+            // chip-wide step: which of the two tour buffers is current changes hands here — no kernel reads it during a scan
+            if (G.chip_step && idx == 0u) G.state->flip = G.state->flip_next;
         }
         TL_SYNC();
     }
@@ -1130,10 +1133,17 @@ __global__ __launch_bounds__(1024) void k_lk_scan_sub(LkArgs G)
         if (mykey != 0xFFFFFFFFu) atomicMin(&s_minkey, mykey);
         TL_SYNC();
         if (mykey != 0xFFFFFFFFu && s_minkey == mykey && chain_valid(chain, clen, G.tour, G.pos, n)) {
-            uint32_t *slot = G.chains + (size_t)idx * (kLkMaxChain + 2);
+            uint32_t *slot = G.chains + (size_t)idx * kLkSlot;
             slot[0] = clen;
             for (uint32_t t = 0; t < clen; ++t) slot[1 + t] = chain[t];
-            atomicMin(&G.state->key, idx);
+            if (G.chip_step) {  // the step kernel rebuilds pos[] while other workgroups still build their segment tables
+                // (a loop over the slot's own words: a register array here costs every lane of the scan 19 VGPRs of occupancy)
+#pragma unroll 1
+                for (uint32_t t = 0; t < kLkMaxChain; ++t) slot[1 + kLkMaxChain + t] = t < clen ? G.pos[slot[1 + t]] : 0xFFFFFFFFu;
+                atomicMin(&G.state->key2[G.parity], idx);
+            } else {
+                atomicMin(&G.state->key, idx);
+            }
         }
         return;
     }
@@ -1143,7 +1153,7 @@ __global__ __launch_bounds__(1024) void k_lk_scan_sub(LkArgs G)
         if (got) atomicMin(&s_minkey, sub);
         TL_SYNC();
         if (got && s_minkey == sub && chain_valid(chain, clen, G.tour, G.pos, n)) {
-            uint32_t *slot = G.chains + (size_t)idx * (kLkMaxChain + 2);
+            uint32_t *slot = G.chains + (size_t)idx * kLkSlot;
             slot[0] = clen;
             for (uint32_t t = 0; t < clen; ++t) slot[1 + t] = chain[t];
             atomicMin(&G.state->key, idx);
@@ -1189,13 +1199,20 @@ __global__ __launch_bounds__(256) void k_lk_scan_pick(LkArgs G)
         have = lk_run_sub(G, chain, clen, p1, t1, t2, p2, g0, sub);
     }
     if (have && chain_valid(chain, clen, G.tour, G.pos, n)) {
-        uint32_t *slot = G.chains + (size_t)idx * (kLkMaxChain + 2);
+        uint32_t *slot = G.chains + (size_t)idx * kLkSlot;
         slot[0] = clen;
         for (uint32_t t = 0; t < clen; ++t) slot[1 + t] = chain[t];
         atomicMin(&S->key, idx);
     }
 }
 
+// The state machine behind a scan.  CHIP (n >= kLkRebuildSplitN with the fused scan): one launch of ceil(n / 1024) workgroups
+// does what k_lk_control + k_lk_rebuild do in two — every workgroup builds the move's segment table for itself (from the chain
+// and the tour positions the scan left in the pair's slot) and writes its slice of the new tour into the OTHER tour buffer
+// together with rank / successor / predecessor; workgroup 0 also keeps the counters, and runs the pass-end logic alone when the
+// scan found nothing.  What other workgroups of the same launch read is never written in it: the scan's key is double-buffered
+// by the round's parity (a launch argument) and the current-buffer flag changes hands in the next scan.
+template <bool CHIP>
 __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
 {
     __shared__ uint32_t s_nseg;
@@ -1205,6 +1222,10 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
     if (S->finished) return;
     const uint32_t tid = threadIdx.x, n = G.n;
     uint32_t *tour = G.tour, *alt = G.alt, *pos = G.pos, *next = G.next, *prev = G.prev, *best = G.best;
+    if (CHIP && S->flip) {
+        tour = G.alt;
+        alt = G.tour;
+    }
     const float2 *__restrict__ xy = G.xy;
 
     auto rebuild = [&]() {
@@ -1237,18 +1258,23 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
         return r;
     };
 
-    const uint32_t key = S->key;
-    if (tid == 0) S->applied = 0u;  // set again below if this round applies a move (k_lk_rebuild runs after every control)
+    const uint32_t key = CHIP ? S->key2[G.parity] : S->key;
+    if (!CHIP && tid == 0) S->applied = 0u;  // set again below if this round applies a move (k_lk_rebuild runs after every control)
     TL_SYNC();
     if (key != 0xFFFFFFFFu) {
         // ---- apply_lk_chain (:397-450), then rescan (lk_pass loop :468-478)
-        const uint32_t *slot = G.chains + (size_t)key * (kLkMaxChain + 2);
+        const uint32_t *slot = G.chains + (size_t)key * kLkSlot;
         const uint32_t clen = slot[0];
         if (tid == 0) {
             uint32_t chain[kLkMaxChain];
             for (uint32_t t = 0; t < clen; ++t) chain[t] = slot[1 + t];
             uint32_t cpos[kLkMaxChain];
-            chain_positions(chain, clen, pos, cpos);
+            if (CHIP) {
+#pragma unroll
+                for (int t = 0; t < kLkMaxChain; ++t) cpos[t] = slot[1 + kLkMaxChain + t];
+            } else {
+                chain_positions(chain, clen, pos, cpos);
+            }
             Arcs A;
             arcs_build(cpos, clen, n, A);
             bool first_removed = false;
@@ -1273,6 +1299,36 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
         }
         TL_SYNC();
         const uint32_t nseg = s_nseg;
+        if (CHIP) {
+            // this workgroup's slice of the new tour: the city at new position d comes from old position src(d)
+            auto city_at = [&](uint32_t d) -> uint32_t {
+                uint32_t sidx = 0;
+                while (sidx + 1u < nseg && d >= s_seg[sidx + 1u].dst) ++sidx;  // segments are in dst order
+                const LkSeg sg = s_seg[sidx];
+                const uint32_t t = d - sg.dst;
+                uint32_t sp = sg.dir > 0 ? sg.src + t : sg.src + n - t;
+                if (sp >= n) sp -= n;
+                return tour[sp];
+            };
+            for (uint32_t r = blockIdx.x * kLkNT + tid; r < n; r += gridDim.x * kLkNT) {
+                const uint32_t c = city_at(r), cn = city_at(r + 1u == n ? 0u : r + 1u), cp = city_at(r == 0u ? n - 1u : r - 1u);
+                alt[r] = c;
+                pos[c] = r;
+                next[c] = cn;
+                prev[c] = cp;
+            }
+            if (blockIdx.x == 0 && tid == 0) {
+                S->scans += 1;
+                S->searches += (uint64_t)key + 1u;
+                S->moves += 1;
+                S->exchanged += clen / 2u;
+                S->key2[G.parity ^ 1u] = 0xFFFFFFFFu;  // the next scan's key
+                const uint32_t w = key + kLkWindowMargin;
+                S->window = w < 2u * n ? w : 2u * n;
+                S->flip_next = S->flip ^ 1u;
+            }
+            return;
+        }
         for (uint32_t sidx = 0; sidx < nseg; ++sidx) {
             const LkSeg sg = s_seg[sidx];
             for (uint32_t t = tid; t < sg.len; t += kLkNT) {
@@ -1307,6 +1363,13 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
             S->window = w < 2u * n ? w : 2u * n;
         }
         return;
+    }
+    if (CHIP) {  // no move: workgroup 0 is the state machine
+        if (blockIdx.x != 0) return;
+        if (tid == 0) {
+            S->key2[G.parity ^ 1u] = 0xFFFFFFFFu;
+            S->flip_next = S->flip;
+        }
     }
     if (S->window < 2u * n) {  // nothing inside the prefix: the same find_lk_move goes on over all pairs
         TL_SYNC();
@@ -1413,6 +1476,8 @@ __global__ __launch_bounds__(kLkNT) void k_lk_begin(LkArgs G)
     if (tid == 0) {
         LkState *S = G.state;
         S->key = 0xFFFFFFFFu;
+        S->key2[0] = S->key2[1] = 0xFFFFFFFFu;
+        S->flip = S->flip_next = 0u;
         S->finished = n < 4 ? 1u : 0u;  // :57-59
         S->stage = 0;
         S->epoch = 0;
@@ -1431,8 +1496,10 @@ hipError_t launch_lk_begin(const LkArgs &G, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_lk_round(const LkArgs &G, hipStream_t s)
+hipError_t launch_lk_round(const LkArgs &G0, hipStream_t s, uint32_t round)
 {
+    LkArgs G = G0;
+    G.parity = round & 1u;
     if (G.pairmin) {  // split scan
         const uint64_t lanes = (uint64_t)2u * G.n * G.k * (G.k + 1u) * (G.split_levels == 3u ? G.k + 1u : 1u);
         const uint32_t k1 = G.k + 1u, per_pair = lk_subs(G);
@@ -1453,12 +1520,16 @@ hipError_t launch_lk_round(const LkArgs &G, hipStream_t s)
             hipLaunchKernelGGL(k_lk_scan<false>, dim3((2u * G.n + 255u) / 256u), dim3(256), 0, s, G);
         }
     }
-    hipLaunchKernelGGL(k_lk_control, dim3(1), dim3(kLkNT), 0, s, G);
+    if (G.chip_step) {
+        hipLaunchKernelGGL(k_lk_control<true>, dim3((G.n + kLkNT - 1u) / kLkNT), dim3(kLkNT), 0, s, G);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_lk_control<false>, dim3(1), dim3(kLkNT), 0, s, G);
     if (G.n >= kLkRebuildSplitN) hipLaunchKernelGGL(k_lk_rebuild, dim3((G.n + 255u) / 256u), dim3(256), 0, s, G);
     return hipGetLastError();
 }
 
-size_t lk_chain_slot_words() { return (size_t)kLkMaxChain + 2; }
+size_t lk_chain_slot_words() { return (size_t)kLkSlot; }
 
 hipError_t launch_knn(const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, hipStream_t s, int form)
 {

@@ -1186,7 +1186,7 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const float *dm_pac
     if (const char *e = getenv("TL_LK_SMALL_MAX_N")) small_max_n = (uint32_t)atoi(e);
     if (const char *e = getenv("TL_LK_SMALL_NT")) small_nt = atoi(e);
 #endif
-    const uint32_t variant_flags = TL_FLAG_LK_ONE_WORKGROUP | TL_FLAG_LK_NO_SPLIT | TL_FLAG_LK_SPLIT2 | TL_FLAG_LK_NO_SUBCHAINS | TL_FLAG_LK_SEPARATE_PICK | TL_FLAG_LK_NO_GRAPH;
+    const uint32_t variant_flags = TL_FLAG_LK_ONE_WORKGROUP | TL_FLAG_LK_NO_SPLIT | TL_FLAG_LK_SPLIT2 | TL_FLAG_LK_NO_SUBCHAINS | TL_FLAG_LK_SEPARATE_PICK | TL_FLAG_LK_NO_GRAPH | TL_FLAG_LK_SEPARATE_STEP;
     const bool lk_small = ((c->flags & TL_FLAG_LK_SMALL) || (!(c->flags & variant_flags) && n <= small_max_n)) &&
                           lk_small_lds_bytes(n, k_small) + 4096 <= (size_t)c->lds_bytes;
     const bool multi_cu = !(c->flags & TL_FLAG_LK_ONE_WORKGROUP) && !lk_small;
@@ -1252,6 +1252,7 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const float *dm_pac
     G.subchains = keep_sub ? (uint32_t *)(w + o_sub) : nullptr;
     G.split_levels = levels;
     G.fused_pick = fused_pick ? 1u : 0u;
+    G.chip_step = (fused_pick && levels == 3u && n >= 1500u && !(c->flags & TL_FLAG_LK_SEPARATE_STEP)) ? 1u : 0u;
     if (split_scan) HIPCHK(c, hipMemsetAsync(G.pairmin, 0xFF, (size_t)2 * n * 4, c->stream));
     uint64_t cnt[4] = {0, 0, 0, 0};
     if (!multi_cu) {
@@ -1272,7 +1273,7 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const float *dm_pac
                 graph_ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
                 if (graph_ok) {
                     hipError_t le = hipSuccess;
-                    for (int r = 0; r < 64 && le == hipSuccess; ++r) le = launch_lk_round(G, c->stream);
+                    for (int r = 0; r < 64 && le == hipSuccess; ++r) le = launch_lk_round(G, c->stream, (uint32_t)r);
                     const hipError_t ce = hipStreamEndCapture(c->stream, &graph);
                     graph_ok = le == hipSuccess && ce == hipSuccess && graph &&
                                hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) == hipSuccess;
@@ -1281,7 +1282,7 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const float *dm_pac
             }
             hipError_t e = hipSuccess;
             if (gexec) e = hipGraphLaunch(gexec, c->stream);
-            else for (int r = 0; r < 64 && e == hipSuccess; ++r) e = launch_lk_round(G, c->stream);
+            else for (int r = 0; r < 64 && e == hipSuccess; ++r) e = launch_lk_round(G, c->stream, (uint32_t)r);
             if (e == hipSuccess) e = hipMemcpyAsync(&hs, G.state, sizeof(hs), hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) {

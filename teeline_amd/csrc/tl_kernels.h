@@ -150,6 +150,8 @@ struct LkState {             // device-side state machine of the multi-CU LK var
     uint64_t scans, searches, moves, exchanged;
     uint32_t window;         // pairs [0, window) the next scan looks at (a prefix: the lowest pair index wins anyway)
     uint32_t applied;        // k_lk_control applied a move into `alt`: k_lk_rebuild copies it back and rebuilds pos / next / prev
+    uint32_t key2[2];        // chip-wide step: the scan's key, double-buffered by round parity
+    uint32_t flip, flip_next;  // chip-wide step: which tour buffer is current (0: tour, 1: alt); handed over by the next scan
 };
 struct LkArgs {
     const float2 *xy;
@@ -171,6 +173,9 @@ struct LkArgs {
     uint32_t n, k, max_depth, epochs, platoo_epochs;
     uint32_t lds_budget;    // LDS bytes a scan workgroup may use for its xy/next copies
     uint32_t split_levels;  // split scan: 2 = k(k+1) sub-searches per pair, 3 = k(k+1)^2
+    uint32_t chip_step;     // fused scan at n >= 1500: k_lk_control<true> (state machine + move application, chip-wide) replaces
+                            // k_lk_control<false> + k_lk_rebuild
+    uint32_t parity;        // round & 1 (set per launch)
     uint32_t fused_pick;    // split scan, one workgroup per pair: the workgroup picks its first chain and validates it itself
                             // (no k_lk_scan_pick launch, no pairmin / subchains traffic)
 };
@@ -182,7 +187,7 @@ hipError_t launch_nn_seed_dm(const float *dm, uint32_t n, uint32_t *path, int ld
 hipError_t launch_lk_solve(const LkArgs &G, hipStream_t s, bool small = false, int threads = 1024);
 size_t lk_small_lds_bytes(uint32_t n, uint32_t k);
 hipError_t launch_lk_begin(const LkArgs &G, hipStream_t s);
-hipError_t launch_lk_round(const LkArgs &G, hipStream_t s);
+hipError_t launch_lk_round(const LkArgs &G, hipStream_t s, uint32_t round);
 size_t lk_chain_slot_words();
 
 // kdtree.hip — build_candidates through the reference's kd-tree (kdtree.rs)
