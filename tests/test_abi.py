@@ -30,6 +30,27 @@ def test_header_declares_what_the_binding_lists():
     assert header_symbols() == sorted(_capi.SYMBOLS)
 
 
+def header_constants(prefix):
+    out = {}
+    for name, val in re.findall(r"#define\s+(" + prefix + r"[A-Z0-9_]+)\s+\(?([^/\n]*?)\)?\s*(?:/\*|$)", open(HEADER).read(), flags=re.M):
+        val = val.strip().replace("u", "")
+        out[name] = eval(val, {"__builtins__": {}})  # "1 << 13", "-4", "0"
+    return out
+
+
+def test_flags_modes_and_error_codes_agree_with_the_binding():
+    from teeline_amd import _capi
+    consts = {}
+    for prefix in ("TL_FLAG_", "TL_ERR_", "TL_MODE_", "TL_DM_", "TL_DIST_"):
+        consts.update(header_constants(prefix))
+    assert len([k for k in consts if k.startswith("TL_FLAG_")]) >= 12
+    flags = [v for k, v in consts.items() if k.startswith("TL_FLAG_") and v]
+    assert len(set(flags)) == len(flags) and all(v & (v - 1) == 0 for v in flags), "create flags are distinct single bits"
+    for name, val in consts.items():
+        assert hasattr(_capi, name), f"{name} is in the header but not in teeline_amd/_capi.py"
+        assert getattr(_capi, name) == val, f"{name}: header {val}, binding {getattr(_capi, name)}"
+
+
 def test_library_exports_every_declared_symbol(lib):
     for name in header_symbols():
         assert hasattr(lib, name), f"libteeline_gpu.so does not export {name}"
