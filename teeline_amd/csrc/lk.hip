@@ -1041,7 +1041,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     uint32_t idx, sub, q1, s1, s2;
     uint64_t g;
     if (BLOCK3D) {
-        idx = blockIdx.x;
+        // workgroups are dispatched in index order: the pairs at the END of the window — around the previous hit, where the next
+        // chain most likely is and the long walks are — go first, so their walks overlap with the bulk instead of trailing it
+        const uint32_t win = G.state->window;
+        if (blockIdx.x >= win) return;
+        idx = win - 1u - blockIdx.x;
         const uint32_t k1 = G.k + 1u;
         if (G.split_levels == 3u) {
             q1 = threadIdx.z; s1 = threadIdx.y; s2 = threadIdx.x;
