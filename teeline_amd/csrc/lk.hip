@@ -1046,6 +1046,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         const uint32_t win = G.state->window;
         if (blockIdx.x >= win) return;
         idx = win - 1u - blockIdx.x;
+#ifdef TL_LK_EXPERIMENT_EXIT
+        if (G.city_ids[idx >> 1] != 0xFFFFFFFEu) return;  // one load, then exit: what does dispatching the window cost?
+#endif
         const uint32_t k1 = G.k + 1u;
         if (G.split_levels == 3u) {
             q1 = threadIdx.z; s1 = threadIdx.y; s2 = threadIdx.x;
@@ -1115,7 +1118,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             }
         }
         TL_SYNC();
+#ifdef TL_LK_EXPERIMENT_NOPHASE2  // timing experiments only (wrong results)
+        const uint32_t nq = 0;
+#else
         const uint32_t nq = s_qn < kLkTailCap ? s_qn : kLkTailCap;
+#endif
         for (uint32_t w = sub; w < nq * per; w += nthr) {
             const uint32_t e = w / per, r = w - e * per, q3 = r / k1, s4 = r - q3 * k1;
             const uint32_t key = s_q[e][7] * (per + 1u) + 1u + r;
