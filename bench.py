@@ -392,6 +392,15 @@ def main():
         ms5 = ctx.last_kernel_ms()
         extras["or_opt_scan_n5000"] = {"placements_per_s": 6.0 * n5 * n5 / (ms5 * 1e-3), "kernel_ms": ms5,
                                        "placements": 6 * n5 * n5, "note": "3 segment lengths x n starts x n insertion points x {fwd, rev} (or_opt.rs:80-164)"}
+        # BASELINE configs[4] size: Lin-Kernighan ILS at n = 13 509 (synthetic points), candidate lists through the kd-tree
+        n13 = 13509
+        p13 = TA.TspProblem(np.arange(n13), TA.synth.synth_xy(n13))
+        lk_opts = TA.LKOptions(TA.HeuristicOptions(epochs=20, platoo_epochs=10, n_nearest=5), 5)
+        TA.lin_kernighan.solve(p13, lk_opts, ctx=ctx, seed=1)
+        slk = TA.lin_kernighan.solve(p13, lk_opts, ctx=ctx, seed=1)
+        extras["lin_kernighan_n13509_20_epochs"] = {"kernel_ms": slk.stats["kernel_ms"], "total_ms": slk.stats["total_ms"], "cost": float(slk.total),
+                                                    "scans": slk.stats["sweeps"], "moves": slk.stats["moves"],
+                                                    "note": "tl_lk incl. NN seed and k-NN lists; the same run is a golden-checked -m gpu test (tests/test_gpu_full_size.py)"}
         out["extras"] = extras
     if world == 1 and not a.no_cpu_baseline:
         res, out["cpu_baseline"] = cpu_baseline(n, a.seed, xy)
