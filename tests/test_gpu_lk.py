@@ -227,3 +227,14 @@ def test_short_init_tours_are_rejected_on_the_host(ctx):
                lambda: TA.three_opt.find_best_move(p, short, ctx=ctx), lambda: TA.or_opt.find_best_move(p, short, ctx=ctx)):
         with pytest.raises(TA.TeelineGpuError):
             fn()
+
+
+def test_lk_forms_at_the_chip_step_size():
+    # n >= 1500 is where the chip-wide step kernel takes over; list lengths 1..10 cross from the one-workgroup-per-pair scan
+    # (k (k+1)^2 <= 1024 lanes: k <= 9) to the flat form, depths 1..6 cover every cut of the split and of the parked walks
+    import teeline_amd as TA
+    xy = O.synth_xy(1600, seed=9)
+    with TA.Context(0) as ctx:
+        for k, depth, epochs in ((1, 5, 3), (2, 3, 3), (3, 6, 4), (5, 4, 4), (5, 2, 3), (5, 1, 2), (9, 3, 2), (10, 3, 2)):
+            assert_same(gpu_lk(ctx, xy, seed=7, epochs=epochs, max_depth=depth, n_nearest=k),
+                        O.lin_kernighan(xy, seed=7, epochs=epochs, max_depth=depth, n_nearest=k))
