@@ -330,7 +330,8 @@ static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uin
         A.dm_full = (const float *)c->dmfull.p;
         HIPCHK(c, launch_two_opt_ref_dm(A, count, c->lds_bytes, s));
     } else {
-        HIPCHK(c, launch_two_opt_ref_lds(A, count, !(c->flags & TL_FLAG_NO_PRUNE), s, (c->flags & TL_FLAG_COUNT_WORK) != 0));
+        const int force_nt = (c->flags & TL_FLAG_2OPT_NT256) ? 256 : (c->flags & TL_FLAG_2OPT_NT512) ? 512 : 0;
+        HIPCHK(c, launch_two_opt_ref_lds(A, count, !(c->flags & TL_FLAG_NO_PRUNE), s, (c->flags & TL_FLAG_COUNT_WORK) != 0, c->cus, c->lds_bytes, force_nt));
     }
     HIPCHK(c, hipEventRecord(c->ev1, s));
     c->ev_valid = true;

@@ -59,7 +59,8 @@ struct TwoOptBatchArgs {
 
 // two_opt_ref.hip
 size_t two_opt_ref_lds_bytes(uint32_t n, uint32_t *n_pad_out, int nt);
-hipError_t launch_two_opt_ref_lds(const TwoOptBatchArgs &A, uint32_t count, bool prune, hipStream_t s, bool count_work = false);
+hipError_t launch_two_opt_ref_lds(const TwoOptBatchArgs &A, uint32_t count, bool prune, hipStream_t s, bool count_work, int cus, int lds_budget,
+                                  int force_nt);
 
 // two_opt_dm.hip — same algorithm, distances gathered from the packed matrix in HBM/L2
 size_t two_opt_ref_dm_lds_bytes(uint32_t n);

@@ -161,12 +161,17 @@ __device__ __forceinline__ uint32_t flush_deferred(float2 *P, uint16_t *perm, ui
 
 }  // namespace
 
+// NT = 1024 (16 waves) is the form of a descent that has a CU to itself.  Where the LDS holds two or four tours (n <= ~7100 /
+// ~3000) and the batch has more descents than the chip has CUs, the 8- or 4-wave forms run 2 or 4 descents per CU: a descent
+// leaves its SIMDs idle ~80 % of the time and half the waves cost it only 7 %, so a neighbour's descent
+// fills the issue slots — 1.57 x the restarts per second at n = 7000.  At most 128 VGPRs (4 waves per SIMD) in every form.
 template <int NT, bool PRUNE, bool COUNT>
-__global__ __launch_bounds__(NT) void k_two_opt_ref_lds(TwoOptBatchArgs A)
+__global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = NT / 64;
-    static_assert(NW == 16, "tile -> wave assignment below assumes 16 waves");
+    static_assert(NW == 16 || NW == 8 || NW == 4, "16 waves; 8 or 4 for two or four descents per CU");
+    static_assert(NW >= (int)kDenseLead, "the lead round has one wave per SIMD");
     const uint32_t n = A.n, npad = A.n_pad;
     const uint32_t ntile = npad >> 6;                  // tiles incl. the pad tile
     const int G = (int)((ntile + 63u) >> 6);           // 64-tile groups (<= kMaxGroups)
@@ -669,15 +674,34 @@ static hipError_t launch_one(const TwoOptBatchArgs &A, uint32_t count, size_t ld
     return hipGetLastError();
 }
 
-hipError_t launch_two_opt_ref_lds(const TwoOptBatchArgs &A, uint32_t count, bool prune, hipStream_t s, bool count_work)
+template <int NT>
+static hipError_t launch_nt(const TwoOptBatchArgs &B, uint32_t count, size_t lds, bool prune, bool count_work, hipStream_t s)
 {
-    constexpr int NT = TL_TWO_OPT_NT;
-    uint32_t n_pad = 0;
-    const size_t lds = two_opt_ref_lds_bytes(A.n, &n_pad, NT);
-    TwoOptBatchArgs B = A;
-    B.n_pad = n_pad;
     if (count_work) return prune ? launch_one<NT, true, true>(B, count, lds, s) : launch_one<NT, false, true>(B, count, lds, s);
     return prune ? launch_one<NT, true, false>(B, count, lds, s) : launch_one<NT, false, false>(B, count, lds, s);
+}
+
+// threads per descent: 0 = by the batch (below), else 1024 / 512 / 256 as forced by a tl_create flag
+hipError_t launch_two_opt_ref_lds(const TwoOptBatchArgs &A, uint32_t count, bool prune, hipStream_t s, bool count_work, int cus, int lds_budget,
+                                  int force_nt)
+{
+    uint32_t n_pad = 0;
+    const size_t lds = two_opt_ref_lds_bytes(A.n, &n_pad, TL_TWO_OPT_NT);
+    TwoOptBatchArgs B = A;
+    B.n_pad = n_pad;
+    // descents per CU the LDS allows; a flush holds kFlushSlots elements per thread, so a narrow form also needs n <= 15 NT
+    const size_t fit = lds ? (size_t)lds_budget / lds : 1;
+    int nt = TL_TWO_OPT_NT;
+    if (force_nt) {
+        nt = force_nt;
+    } else if (cus > 0 && count > (uint32_t)cus) {
+        if (fit >= 4 && count >= 3u * (uint32_t)cus) nt = 256;
+        else if (fit >= 2) nt = 512;
+    }
+    while (nt < TL_TWO_OPT_NT && (size_t)A.n > (size_t)kFlushSlots * (size_t)nt) nt *= 2;
+    if (nt == 256) return launch_nt<256>(B, count, lds, prune, count_work, s);
+    if (nt == 512) return launch_nt<512>(B, count, lds, prune, count_work, s);
+    return launch_nt<TL_TWO_OPT_NT>(B, count, lds, prune, count_work, s);
 }
 
 }  // namespace tl

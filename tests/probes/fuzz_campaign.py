@@ -7,7 +7,8 @@ import numpy as np, _oracle as O, teeline_amd as TA
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 t0 = time.time(); runs = fails = 0
-with TA.Context(0) as ctx, TA.Context(0, TA.TL_FLAG_NO_PRUNE) as ctx2:
+with TA.Context(0) as ctx, TA.Context(0, TA.TL_FLAG_NO_PRUNE) as ctx2, TA.Context(0, TA.TL_FLAG_2OPT_NT512) as ctx3, \
+        TA.Context(0, TA.TL_FLAG_2OPT_NT256) as ctx4:
     seed = 0
     while time.time() - t0 < budget:
         seed += 1
@@ -32,6 +33,10 @@ with TA.Context(0) as ctx, TA.Context(0, TA.TL_FLAG_NO_PRUNE) as ctx2:
         prob = TA.TspProblem(np.arange(n), xy)
         cases = [("coord", prob, ctx)]
         if seed % 5 == 0: cases.append(("noprune", prob, ctx2))
+        # the 8- and 4-wave forms of a descent (what a batch runs when two or four descents share a CU); a flush holds 15 elements
+        # per thread, so they take n <= 7680 / 3840 (beyond that the library falls back to the wider form by itself)
+        if seed % 2 == 0: cases.append(("nt512", prob, ctx3))
+        if seed % 3 == 0: cases.append(("nt256", prob, ctx4))
         if n <= 1500 and seed % 3 == 0:
             dm = TA.distance_matrix.build(np.arange(n), xy, ctx=ctx)
             cases.append(("matrix", TA.TspProblem(np.arange(n), xy, TA.distance_matrix.DistanceMatrix(n, dm.items, np.arange(n), "explicit")), ctx))

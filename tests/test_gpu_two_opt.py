@@ -405,3 +405,26 @@ def test_population_explicit_matrix_and_bad_input(ctx, tsplib_dir):
         assert list(sol.route()) == list(one.route()) and float(sol.total) == float(one.total)
     with pytest.raises(TA.TeelineGpuError):
         TA.two_opt.solve_population(prob, [ids, ids[:-1] + [ids[0]]], ctx=ctx)  # second tour repeats a city
+
+
+@pytest.mark.parametrize("n,restarts_per_cu", [(400, 4.1), (4000, 2.1)])
+def test_batches_with_several_descents_per_cu_match_the_oracle(ctx, n, restarts_per_cu):
+    # More descents than CUs: where the LDS holds four (n <= ~3000) or two (n <= ~7100) tours the batch runs the 4- / 8-wave form of
+    # a descent, several per CU.  Same tours as one descent per CU, whatever the form: the costs of ALL restarts against a
+    # one-per-CU run, a sample of them (first, last, two in the middle) against the oracle; and the forms forced by flag.
+    import teeline_amd as TA
+    cus = ctx.device_info()["cus"]
+    R, seed = int(cus * restarts_per_cu), 777
+    xy = O.synth_xy(n, seed=31)
+    prob = TA.TspProblem(np.arange(n), xy)
+    sol, costs = TA.two_opt.multistart(prob, R, seed=seed, ctx=ctx, return_costs=True)
+    ref = np.concatenate([TA.two_opt.multistart(prob, min(cus, R - f), seed=seed, first=f, ctx=ctx, return_costs=True)[1]
+                          for f in range(0, R, cus)])
+    assert np.asarray(costs, np.float32).tobytes() == np.asarray(ref, np.float32).tobytes()
+    for r in (0, R // 3, R // 2, R - 1):
+        rc, p, c, st = O.two_opt(xy, None, n, init=O.restart_perm(n, seed, r))
+        assert np.float32(costs[r]).tobytes() == np.float32(c).tobytes()
+    for flag in (TA.TL_FLAG_2OPT_NT512, TA.TL_FLAG_2OPT_NT256):
+        with TA.Context(0, flag) as c2:
+            init = O.restart_perm(n, seed, 5)
+            assert_same(gpu_two_opt(c2, xy, None, n, init), O.two_opt(xy, None, n, init=init), n)
