@@ -87,6 +87,7 @@ typedef enum tl_mode {
 #define TL_FLAG_LK_SEPARATE_STEP (1u << 13) /* tl_lk: state machine (one workgroup) and tour rebuild as two kernels at every n */
 #define TL_FLAG_2OPT_NT512 (1u << 14)      /* LDS 2-opt: every descent on 8 waves (default: only when two descents share a CU)   */
 #define TL_FLAG_2OPT_NT256 (1u << 15)      /* LDS 2-opt: every descent on 4 waves (default: only when four descents share a CU)  */
+#define TL_FLAG_2OPT_FX (1u << 16)         /* LDS 2-opt: the grid-coordinate form (5 B per point) wherever the instance lies on a decimal grid */
 #define TL_FLAG_LK_SMALL (1u << 9)         /* tl_lk: the LDS-resident single-workgroup form (default for small n) at every n it fits */
 /* The LDS-resident 2-opt kernel also counts the work its exact decision cascade really does (d_out_stats words 5..8: tile
  * bounds, candidates into L1 / L2 / L3).  Same results; ~8 % slower (the kernel is SGPR-bound), so bench.py uses it for one

@@ -35,7 +35,7 @@ struct tl_ctx {
     int cus = 0, lds_bytes = 0;
     std::string arch;
     std::string err;
-    DevBuf xy, dm, init, out_pos, out_cost, out_stats, misc, work, dmfull, kd;
+    DevBuf xy, dm, init, out_pos, out_cost, out_stats, misc, work, dmfull, kd, fx;
     uint32_t dm_n = 0;
     int dm_layout = -1;
 };
@@ -144,7 +144,7 @@ extern "C" void tl_destroy(tl_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->xy, &c->dm, &c->init, &c->out_pos, &c->out_cost, &c->out_stats, &c->misc, &c->work, &c->dmfull, &c->kd})
+    for (DevBuf *b : {&c->xy, &c->dm, &c->init, &c->out_pos, &c->out_cost, &c->out_stats, &c->misc, &c->work, &c->dmfull, &c->kd, &c->fx})
         if (b->p) (void)hipFree(b->p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -331,6 +331,29 @@ static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uin
         HIPCHK(c, launch_two_opt_ref_dm(A, count, c->lds_bytes, s));
     } else {
         const int force_nt = (c->flags & TL_FLAG_2OPT_NT256) ? 256 : (c->flags & TL_FLAG_2OPT_NT512) ? 512 : 0;
+        // Grid-coordinate form: where two tours fit the LDS at 7 B per city but not at 10 (n = 10^4), a batch with more
+        // descents than CUs runs two per CU — if the instance lies on a decimal grid 1/S whose decode reproduces every
+        // coordinate bit for bit (checked here, on the device, with the kernel's own decode; one 4-byte read-back).
+        if (!force_nt && n <= 10240u && ((c->flags & TL_FLAG_2OPT_FX) || two_opt_ref_fx_pays(n, count, c->cus, c->lds_bytes)) &&
+            2 * two_opt_ref_fx_lds_bytes(n) <= (size_t)c->lds_bytes) {
+            int rc3;
+            if ((rc3 = ensure(c, c->fx, (size_t)n * 8 + 16))) return rc3;
+            uint2 *g = (uint2 *)c->fx.p;
+            uint32_t *bad = (uint32_t *)((unsigned char *)c->fx.p + (size_t)n * 8);
+            static const double scales[] = {1.0, 10.0, 100.0, 1000.0, 10000.0};
+            for (double sc : scales) {
+                uint32_t hbad = 1;
+                HIPCHK(c, hipMemsetAsync(bad, 0, 4, s));
+                HIPCHK(c, launch_fx_encode(d_xy, n, sc, g, bad, s));
+                HIPCHK(c, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, s));
+                HIPCHK(c, hipStreamSynchronize(s));
+                if (hbad == 0) {
+                    A.fx_xy = g;
+                    A.fx_inv = 1.0 / sc;
+                    break;
+                }
+            }
+        }
         HIPCHK(c, launch_two_opt_ref_lds(A, count, !(c->flags & TL_FLAG_NO_PRUNE), s, (c->flags & TL_FLAG_COUNT_WORK) != 0, c->cus, c->lds_bytes, force_nt));
     }
     HIPCHK(c, hipEventRecord(c->ev1, s));

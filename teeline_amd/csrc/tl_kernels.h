@@ -55,12 +55,19 @@ struct TwoOptBatchArgs {
     uint32_t max_sweeps;
     uint32_t init_mode;
     uint32_t *work;          // per-descent global workspace (global-memory variants)
+    const uint2 *fx_xy;      // LDS kernel, grid-coordinate form: per city {x (20 bits) | y low 12 bits << 20, y high 8 bits} (k_fx_encode)
+    double fx_inv;           // ... fl64(1 / S) of its decimal grid, 0 = plain float2 form
 };
 
 // two_opt_ref.hip
 size_t two_opt_ref_lds_bytes(uint32_t n, uint32_t *n_pad_out, int nt);
 hipError_t launch_two_opt_ref_lds(const TwoOptBatchArgs &A, uint32_t count, bool prune, hipStream_t s, bool count_work, int cus, int lds_budget,
                                   int force_nt);
+// grid-coordinate form (A.fx_xy / A.fx_inv set): would it let two tours share a CU where the float2 form cannot?
+bool two_opt_ref_fx_pays(uint32_t n, uint32_t count, int cus, int lds_budget);
+size_t two_opt_ref_fx_lds_bytes(uint32_t n);
+// encode xy on the grid 1/scale: out[c] = packed grid coordinates, *bad += cities that do not decode back bit for bit
+hipError_t launch_fx_encode(const float2 *xy, uint32_t n, double scale, uint2 *out, uint32_t *bad, hipStream_t s);
 
 // two_opt_dm.hip — same algorithm, distances gathered from the packed matrix in HBM/L2
 size_t two_opt_ref_dm_lds_bytes(uint32_t n);

@@ -30,13 +30,43 @@ __device__ __forceinline__ float wave_max(float v)
     return fmaxf(fmaxf(readlane_f(v, 15), readlane_f(v, 31)), fmaxf(readlane_f(v, 47), readlane_f(v, 63)));
 }
 
+// ---- tour-ordered points.  The kernels take them either as plain float2 (8 B per city) or, for the LDS descent kernel, as
+// grid coordinates (5 B per city): TSPLIB-style inputs lie on a decimal grid — x = k / S with an integer k < 2^20 — and the f32
+// coordinate is recovered EXACTLY as fl32(fl64(k) * fl64(1/S)).  "Exactly" is not argued but checked: k_fx_encode runs this
+// very decode on every coordinate of the instance before the form is chosen (two_opt_ref.hip).  7 B per city with the u16 id
+// is what lets two tours of n = 10^4 share one CU's LDS.
+struct PtsFx {
+    uint32_t *lo;   // x (20 bits) | y's low 12 bits << 20
+    uint8_t *hi;    // y's high 8 bits
+    double inv;     // fl64(1 / S)
+    struct Raw {
+        uint32_t lo, hi;
+    };
+};
+__device__ __forceinline__ float2 fx_decode(uint32_t lo, uint32_t hi, double inv)
+{
+    const uint32_t kx = lo & 0xFFFFFu, ky = (lo >> 20) | (hi << 12);
+    return make_float2((float)((double)kx * inv), (float)((double)ky * inv));
+}
+__device__ __forceinline__ float2 pt_get(const float2 *P, uint32_t k) { return P[k]; }
+__device__ __forceinline__ float2 pt_get(const PtsFx &P, uint32_t k) { return fx_decode(P.lo[k], P.hi[k], P.inv); }
+__device__ __forceinline__ float2 pt_raw(const float2 *P, uint32_t k) { return P[k]; }
+__device__ __forceinline__ PtsFx::Raw pt_raw(const PtsFx &P, uint32_t k) { return PtsFx::Raw{P.lo[k], P.hi[k]}; }
+__device__ __forceinline__ void pt_put(float2 *P, uint32_t k, float2 r) { P[k] = r; }
+__device__ __forceinline__ void pt_put(const PtsFx &P, uint32_t k, PtsFx::Raw r)
+{
+    P.lo[k] = r.lo;
+    P.hi[k] = (uint8_t)r.hi;
+}
+
 // L0 metadata of tile t: bounding box of P[64t .. 64t+64] over the positions that take part in a
 // candidate (j <= n-2 as c, j+1 as e) and the largest squared tour-edge sq(P[j],P[j+1]) in it.
-__device__ __forceinline__ void build_tile_meta(const float2 *P, uint32_t n, uint32_t t, int lane, float4 *tbox, float *tmsq)
+template <typename PT>
+__device__ __forceinline__ void build_tile_meta(const PT &P, uint32_t n, uint32_t t, int lane, float4 *tbox, float *tmsq)
 {
     const uint32_t j = (t << 6) + (uint32_t)lane;
     const bool valid = j + 2u <= n;  // j <= n-2
-    const float2 c = P[j], e = P[j + 1u];
+    const float2 c = pt_get(P, j), e = pt_get(P, j + 1u);
     const float inf = __builtin_inff();
     const float mnx = wave_min(valid ? fminf(c.x, e.x) : inf), mny = wave_min(valid ? fminf(c.y, e.y) : inf);
     const float mxx = wave_max(valid ? fmaxf(c.x, e.x) : -inf), mxy = wave_max(valid ? fmaxf(c.y, e.y) : -inf);
@@ -132,17 +162,17 @@ __device__ __forceinline__ uint64_t tile_mask_core(float2 c, float2 e, uint32_t 
     return __builtin_amdgcn_ballot_w64(imp);
 }
 
-template <bool PRUNE, typename TC>
-__device__ __forceinline__ uint64_t tile_improving_mask(const float2 *P, uint32_t n, uint32_t tb, uint32_t jmin,
+template <bool PRUNE, typename TC, typename PT>
+__device__ __forceinline__ uint64_t tile_improving_mask(const PT &P, uint32_t n, uint32_t tb, uint32_t jmin,
                                                         float ax, float ay, float bx, float by, float sqab, int lane,
                                                         TC &tc)
 {
     const uint32_t j = tb + (uint32_t)lane;
-    return tile_mask_core<PRUNE>(P[j], P[j + 1u], j, n, jmin, ax, ay, bx, by, sqab, tc);
+    return tile_mask_core<PRUNE>(pt_get(P, j), pt_get(P, j + 1u), j, n, jmin, ax, ay, bx, by, sqab, tc);
 }
 
-template <bool PRUNE>
-__device__ __forceinline__ bool tile_first_hit(const float2 *P, uint32_t n, uint32_t i, uint32_t tb, uint32_t jmin,
+template <bool PRUNE, typename PT>
+__device__ __forceinline__ bool tile_first_hit(const PT &P, uint32_t n, uint32_t i, uint32_t tb, uint32_t jmin,
                                                float ax, float ay, float bx, float by, float sqab,
                                                uint32_t *keyslot, int lane)
 {
@@ -170,13 +200,13 @@ __device__ __forceinline__ bool tile_first_hit(const float2 *P, uint32_t n, uint
 #define TL_CHAIN_TILES 2
 #endif
 static constexpr uint32_t kChainTiles = TL_CHAIN_TILES;
-template <bool PRUNE, typename TC>
-__device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint32_t i, uint32_t tb, uint32_t jmin,
+template <bool PRUNE, typename TC, typename PT>
+__device__ __forceinline__ uint32_t dense_tile(const PT &P, uint32_t n, uint32_t i, uint32_t tb, uint32_t jmin,
                                                float ax, float ay, float bx, float by, float sqab,
                                                uint32_t *hl, uint32_t *keyslot, int lane, TC &tc)
 {
     uint32_t j = tb + (uint32_t)lane;
-    float2 c = P[j], e = P[j + 1u];
+    float2 c = pt_get(P, j), e = pt_get(P, j + 1u);
     uint64_t m = tile_mask_core<PRUNE>(c, e, j, n, jmin, ax, ay, bx, by, sqab, tc);
     if (m == 0) return 0;  // the common case: no chain state was ever set up
     uint32_t from = jmin, nh = 0, hitv = 0, mykey = 0;  // lane h of hitv holds the h-th hit column
@@ -212,8 +242,8 @@ __device__ __forceinline__ uint32_t dense_tile(const float2 *P, uint32_t n, uint
             ++idle;
             tb += 64u;
             j += 64u;
-            c = P[j];
-            e = P[j + 1u];
+            c = pt_get(P, j);
+            e = pt_get(P, j + 1u);
             m = tile_mask_core<PRUNE>(c, e, j, n, from, ax, ay, bx, by, sqab, tc);
         }
         if (stop) break;

@@ -48,6 +48,7 @@ constexpr uint32_t kQCap = 32;        // u32 words per chained-hit list: 2 + kMa
                                       // so the next step writes the other parity.  The 4 KB are also the cost-sum scratch.
 constexpr uint32_t kPendMax = 64;     // deferred reversals of one row: lane m of every wave keeps hit m (= the flush's segment table)
 constexpr int kFlushSlots = 15;       // elements per thread a flush can hold: 15 x 1024 covers every n that fits the LDS
+constexpr int kFlushSlotsFx = 20;     // grid-coordinate form on 8 waves: 20 x 512 covers n = 10^4 (two tours per CU)
 constexpr int kMaxGroups = 4;         // 64-tile groups: n_pad <= 4 * 64 * 64 = 16384
 
 #ifdef TL_PROFILE
@@ -84,14 +85,15 @@ __device__ __forceinline__ uint32_t dpp_shr0(uint32_t v)
 __device__ __forceinline__ uint32_t readlane_u(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 
 // `g`: lane m < k holds hit column g_m (the row's deferred-hit register of every wave), lanes >= k hold 0xFFFFFFFF.
-template <int NT>
-__device__ __forceinline__ uint32_t flush_deferred(float2 *P, uint16_t *perm, uint32_t g, uint32_t lo, uint32_t k, int lane, int wave)
+template <int NT, int SLOTS, typename PT>
+__device__ __forceinline__ uint32_t flush_deferred(const PT &P, uint16_t *perm, uint32_t g, uint32_t lo, uint32_t k, int lane, int wave)
 {
+    using Raw = decltype(pt_raw(P, 0u));
     const bool have = (uint32_t)lane < k;
     const uint32_t ghi = readlane_u(g, k - 1u);
     const uint32_t wfirst = lo + ((uint32_t)wave << 6);  // this wave's first window (wave-uniform)
-    float2 val[kFlushSlots];
-    uint32_t pk[kFlushSlots];  // perm id | target << 16
+    Raw val[SLOTS];
+    uint32_t pk[SLOTS];  // perm id | target << 16
     if (wfirst <= ghi) {  // waves without a window go straight to the barriers
         // g of the lane below (row_shr stays inside its row of 16: lanes 16, 32, 48 are patched)
         uint32_t gprev = dpp_shr0<0x111>(g);
@@ -122,7 +124,7 @@ __device__ __forceinline__ uint32_t flush_deferred(float2 *P, uint16_t *perm, ui
         const uint32_t base = lo + (isrev ? t_rev - pre : t_rev + pre - len);
         const uint32_t cst = isrev ? base + g : base - start;  // target = cst - p (reversed) or cst + p (kept)
 #pragma unroll
-        for (int q = 0; q < kFlushSlots; ++q) {
+        for (int q = 0; q < SLOTS; ++q) {
             const uint32_t w0 = wfirst + (uint32_t)(q * NT);
             if (w0 > ghi) break;
             const uint32_t p = w0 + (uint32_t)lane;
@@ -137,7 +139,7 @@ __device__ __forceinline__ uint32_t flush_deferred(float2 *P, uint16_t *perm, ui
                 dst = p >= sm ? (rv ? cm - p : cm + p) : dst;
             }
             if (p <= ghi) {
-                val[q] = P[p];
+                val[q] = pt_raw(P, p);
                 pk[q] = (uint32_t)perm[p] | (dst << 16);
             }
         }
@@ -145,12 +147,12 @@ __device__ __forceinline__ uint32_t flush_deferred(float2 *P, uint16_t *perm, ui
     TL_SYNC();
     if (wfirst <= ghi) {
 #pragma unroll
-        for (int q = 0; q < kFlushSlots; ++q) {
+        for (int q = 0; q < SLOTS; ++q) {
             const uint32_t w0 = wfirst + (uint32_t)(q * NT);
             if (w0 > ghi) break;
             if (w0 + (uint32_t)lane <= ghi) {
                 const uint32_t dst = pk[q] >> 16;
-                P[dst] = val[q];
+                pt_put(P, dst, val[q]);
                 perm[dst] = (uint16_t)pk[q];
             }
         }
@@ -165,9 +167,10 @@ __device__ __forceinline__ uint32_t flush_deferred(float2 *P, uint16_t *perm, ui
 // ~3000) and the batch has more descents than the chip has CUs, the 8- or 4-wave forms run 2 or 4 descents per CU: a descent
 // leaves its SIMDs idle ~80 % of the time and half the waves cost it only 7 %, so a neighbour's descent
 // fills the issue slots — 1.57 x the restarts per second at n = 7000.  At most 128 VGPRs (4 waves per SIMD) in every form.
-template <int NT, bool PRUNE, bool COUNT>
+template <int NT, bool PRUNE, bool COUNT, bool FX>
 __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 {
+    constexpr int kSlots = FX ? kFlushSlotsFx : kFlushSlots;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = NT / 64;
     static_assert(NW == 16 || NW == 8 || NW == 4, "16 waves; 8 or 4 for two or four descents per CU");
@@ -175,9 +178,22 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     const uint32_t n = A.n, npad = A.n_pad;
     const uint32_t ntile = npad >> 6;                  // tiles incl. the pad tile
     const int G = (int)((ntile + 63u) >> 6);           // 64-tile groups (<= kMaxGroups)
-    float2 *P = reinterpret_cast<float2 *>(smem);
-    uint16_t *perm = reinterpret_cast<uint16_t *>(smem + (size_t)npad * 8);
-    unsigned char *tailp = smem + (size_t)npad * 10;
+    // tour-ordered points: float2 (8 B per city), or grid coordinates (4 + 1 B, PtsFx) — then two tours of n = 10^4 fit one CU
+    using PT = typename std::conditional<FX, PtsFx, float2 *>::type;
+    PT P;
+    uint16_t *perm;
+    unsigned char *tailp;
+    if constexpr (FX) {
+        P.lo = reinterpret_cast<uint32_t *>(smem);
+        P.hi = reinterpret_cast<uint8_t *>(smem + (size_t)npad * 4);
+        P.inv = A.fx_inv;
+        perm = reinterpret_cast<uint16_t *>(smem + (size_t)npad * 5);
+        tailp = smem + (size_t)npad * 7;
+    } else {
+        P = reinterpret_cast<float2 *>(smem);
+        perm = reinterpret_cast<uint16_t *>(smem + (size_t)npad * 8);
+        tailp = smem + (size_t)npad * 10;
+    }
     float4 *tbox = reinterpret_cast<float4 *>(tailp);                        // kMaxGroups*64 entries
     float *tmsq = reinterpret_cast<float *>(tailp + kMaxGroups * 64 * 16);     // kMaxGroups*64
     Ctl *ctl = reinterpret_cast<Ctl *>(tailp + kMaxGroups * 64 * 20);
@@ -221,7 +237,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     if (A.init_mode == TL_INIT_SEEDED) {
         // Fisher-Yates `for i in (1..n).rev(): j = rng % (i+1); swap` from splitmix64(seed + r):
         // the draws are counter-based, so compute them in parallel, then one lane applies the swaps.
-        uint16_t *draws = reinterpret_cast<uint16_t *>(P);  // P is not live yet
+        uint16_t *draws = reinterpret_cast<uint16_t *>(smem);  // the points are not live yet
         const uint64_t s = A.seed + (uint64_t)(A.first + d);
         for (uint32_t i = 1 + tid; i < n; i += NT) {
             const uint64_t kth = (uint64_t)(n - 1 - i);  // i = n-1 is draw 0
@@ -249,7 +265,14 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         tmsq[k] = -1.0f;
     }
     TL_SYNC();
-    for (uint32_t k = tid; k < npad; k += NT) P[k] = (k < n) ? xy[perm[k]] : make_float2(0.f, 0.f);
+    if constexpr (FX) {
+        for (uint32_t k = tid; k < npad; k += NT) {
+            const uint2 g = (k < n) ? A.fx_xy[perm[k]] : make_uint2(0u, 0u);
+            pt_put(P, k, PtsFx::Raw{g.x, g.y});
+        }
+    } else {
+        for (uint32_t k = tid; k < npad; k += NT) P[k] = (k < n) ? xy[perm[k]] : make_float2(0.f, 0.f);
+    }
     TL_SYNC();
     for (uint32_t t = (uint32_t)wave; t < ntile; t += NW) build_tile_meta(P, n, t, lane, tbox, tmsq);
     TL_SYNC();
@@ -291,7 +314,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #ifdef TL_PROFILE
             ++nflush;
 #endif
-            rev_lane += flush_deferred<NT>(P, perm, pendv, prow + 1u, np, lane, wave);
+            rev_lane += flush_deferred<NT, kSlots>(P, perm, pendv, prow + 1u, np, lane, wave);
             pendv = 0xFFFFFFFFu;
 #ifdef TL_PROFILE2
             { const uint64_t t2 = __builtin_amdgcn_s_memtime(); q2[12] += t2 - t_it; t_it = t2; }
@@ -335,8 +358,8 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #endif
 
         // lane-resident row table: lane l holds P[i0+l] and sq(P[i0+l], P[i0+l+1])
-        const float2 rp = P[i0 + (uint32_t)lane];
-        const float2 rq = P[i0 + (uint32_t)lane + 1u];
+        const float2 rp = pt_get(P, i0 + (uint32_t)lane);
+        const float2 rq = pt_get(P, i0 + (uint32_t)lane + 1u);
         const float rowsq = sqdist(rp, rq);
 
         if (pruned) {
@@ -411,7 +434,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             float bx = readlane_f(rp.x, 1), by = readlane_f(rp.y, 1);
             float sqab = readlane_f(rowsq, 0);
             if (np) {  // p[i+1] after the deferred reversals = the old p[g_last], still in place (two_opt.rs:50)
-                const float2 bq = P[hlast];
+                const float2 bq = pt_get(P, hlast);
                 bx = readlane_f(bq.x, 0);
                 by = readlane_f(bq.y, 0);
                 sqab = sqdist(make_float2(ax, ay), make_float2(bx, by));
@@ -495,23 +518,23 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 for (uint32_t t = tid; t < half; t += 2 * NT) {
                     const uint32_t t2 = t + NT;
                     const bool two = t2 < half;
-                    const float2 x = P[lo + t], y = P[hi - t];
+                    const auto x = pt_raw(P, lo + t), y = pt_raw(P, hi - t);
                     const uint16_t u = perm[lo + t], v = perm[hi - t];
                     uint16_t u2 = u, v2 = v;
-                    float2 x2 = x, y2 = y;
+                    auto x2 = x, y2 = y;
                     if (two) {
-                        x2 = P[lo + t2];
-                        y2 = P[hi - t2];
+                        x2 = pt_raw(P, lo + t2);
+                        y2 = pt_raw(P, hi - t2);
                         u2 = perm[lo + t2];
                         v2 = perm[hi - t2];
                     }
-                    P[lo + t] = y;
-                    P[hi - t] = x;
+                    pt_put(P, lo + t, y);
+                    pt_put(P, hi - t, x);
                     perm[lo + t] = v;
                     perm[hi - t] = u;
                     if (two) {
-                        P[lo + t2] = y2;
-                        P[hi - t2] = x2;
+                        pt_put(P, lo + t2, y2);
+                        pt_put(P, hi - t2, x2);
                         perm[lo + t2] = v2;
                         perm[hi - t2] = u2;
                     }
@@ -573,11 +596,11 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         }
     }
     float total = 0.0f;
-    if (n >= 2) total = dist(P[n - 1], P[0]);
+    if (n >= 2) total = dist(pt_get(P, n - 1), pt_get(P, 0));
     TL_SYNC();
     for (uint32_t base = 0; base + 1 < n; base += NT) {
         const uint32_t k = base + tid;
-        scratch[tid] = (k + 1 < n) ? dist(P[k], P[k + 1]) : 0.0f;
+        scratch[tid] = (k + 1 < n) ? dist(pt_get(P, k), pt_get(P, k + 1)) : 0.0f;
         TL_SYNC();
         if (tid == 0) {
             const uint32_t cnt = (n - 1 - base) < (uint32_t)NT ? (n - 1 - base) : (uint32_t)NT;
@@ -664,21 +687,62 @@ size_t two_opt_ref_lds_bytes(uint32_t n, uint32_t *n_pad_out, int nt)
     return (size_t)n_pad * 10 + meta + lists;
 }
 
-template <int NT, bool PRUNE, bool COUNT>
+size_t two_opt_ref_fx_lds_bytes(uint32_t n)
+{
+    const uint32_t n_pad = ((n + 64u + 63u) / 64u) * 64u;
+    if (n_pad > (uint32_t)kMaxGroups * 64u * 64u) return ~(size_t)0;
+    return (size_t)n_pad * 7 + (size_t)kMaxGroups * 64 * 20 + kCtlBytes + (size_t)32 * kQCap * 4;
+}
+
+// The grid form costs a decode per point read, so it is used only where it buys a second descent per CU: a batch with more
+// descents than CUs whose tours fit the LDS twice at 7 B per city but not at 10 (7 100 < n <= 10 240 on MI355X).
+bool two_opt_ref_fx_pays(uint32_t n, uint32_t count, int cus, int lds_budget)
+{
+    const size_t plain = two_opt_ref_lds_bytes(n, nullptr, TL_TWO_OPT_NT), fx = two_opt_ref_fx_lds_bytes(n);
+    return cus > 0 && count > (uint32_t)cus && 2 * plain > (size_t)lds_budget && 2 * fx <= (size_t)lds_budget &&
+           (size_t)n <= (size_t)kFlushSlotsFx * 512;
+}
+
+__global__ __launch_bounds__(256) void k_fx_encode(const float2 *__restrict__ xy, uint32_t n, double scale, double inv, uint2 *__restrict__ out,
+                                                   uint32_t *__restrict__ bad)
+{
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= n) return;
+    const float2 p = xy[c];
+    const double gx = rint((double)p.x * scale), gy = rint((double)p.y * scale);
+    bool ok = gx >= 0.0 && gy >= 0.0 && gx < 1048576.0 && gy < 1048576.0;
+    uint2 g = make_uint2(0u, 0u);
+    if (ok) {
+        const uint32_t kx = (uint32_t)gx, ky = (uint32_t)gy;
+        g = make_uint2(kx | ((ky & 0xFFFu) << 20), ky >> 12);
+        const float2 q = fx_decode(g.x, g.y, inv);  // the kernel's own decode: bit for bit, or the form is not used
+        ok = __float_as_uint(q.x) == __float_as_uint(p.x) && __float_as_uint(q.y) == __float_as_uint(p.y);
+    }
+    out[c] = g;
+    if (!ok) atomicAdd(bad, 1u);
+}
+
+hipError_t launch_fx_encode(const float2 *xy, uint32_t n, double scale, uint2 *out, uint32_t *bad, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fx_encode, dim3((n + 255u) / 256u), dim3(256), 0, s, xy, n, scale, 1.0 / scale, out, bad);
+    return hipGetLastError();
+}
+
+template <int NT, bool PRUNE, bool COUNT, bool FX>
 static hipError_t launch_one(const TwoOptBatchArgs &A, uint32_t count, size_t lds, hipStream_t s)
 {
-    auto kern = k_two_opt_ref_lds<NT, PRUNE, COUNT>;
+    auto kern = k_two_opt_ref_lds<NT, PRUNE, COUNT, FX>;
     hipError_t e = allow_max_lds(reinterpret_cast<const void *>(kern));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(count), dim3(NT), lds, s, A);
     return hipGetLastError();
 }
 
-template <int NT>
+template <int NT, bool FX>
 static hipError_t launch_nt(const TwoOptBatchArgs &B, uint32_t count, size_t lds, bool prune, bool count_work, hipStream_t s)
 {
-    if (count_work) return prune ? launch_one<NT, true, true>(B, count, lds, s) : launch_one<NT, false, true>(B, count, lds, s);
-    return prune ? launch_one<NT, true, false>(B, count, lds, s) : launch_one<NT, false, false>(B, count, lds, s);
+    if (count_work) return prune ? launch_one<NT, true, true, FX>(B, count, lds, s) : launch_one<NT, false, true, FX>(B, count, lds, s);
+    return prune ? launch_one<NT, true, false, FX>(B, count, lds, s) : launch_one<NT, false, false, FX>(B, count, lds, s);
 }
 
 // threads per descent: 0 = by the batch (below), else 1024 / 512 / 256 as forced by a tl_create flag
@@ -689,6 +753,10 @@ hipError_t launch_two_opt_ref_lds(const TwoOptBatchArgs &A, uint32_t count, bool
     const size_t lds = two_opt_ref_lds_bytes(A.n, &n_pad, TL_TWO_OPT_NT);
     TwoOptBatchArgs B = A;
     B.n_pad = n_pad;
+    if (A.fx_xy && A.fx_inv != 0.0) {  // grid-coordinate form: two descents per CU on 8 waves (the caller has checked that it fits)
+        if ((size_t)A.n > (size_t)kFlushSlotsFx * 512) return hipErrorInvalidValue;
+        return launch_nt<512, true>(B, count, two_opt_ref_fx_lds_bytes(A.n), prune, count_work, s);
+    }
     // descents per CU the LDS allows; a flush holds kFlushSlots elements per thread, so a narrow form also needs n <= 15 NT
     const size_t fit = lds ? (size_t)lds_budget / lds : 1;
     int nt = TL_TWO_OPT_NT;
@@ -699,9 +767,9 @@ hipError_t launch_two_opt_ref_lds(const TwoOptBatchArgs &A, uint32_t count, bool
         else if (fit >= 2) nt = 512;
     }
     while (nt < TL_TWO_OPT_NT && (size_t)A.n > (size_t)kFlushSlots * (size_t)nt) nt *= 2;
-    if (nt == 256) return launch_nt<256>(B, count, lds, prune, count_work, s);
-    if (nt == 512) return launch_nt<512>(B, count, lds, prune, count_work, s);
-    return launch_nt<TL_TWO_OPT_NT>(B, count, lds, prune, count_work, s);
+    if (nt == 256) return launch_nt<256, false>(B, count, lds, prune, count_work, s);
+    if (nt == 512) return launch_nt<512, false>(B, count, lds, prune, count_work, s);
+    return launch_nt<TL_TWO_OPT_NT, false>(B, count, lds, prune, count_work, s);
 }
 
 }  // namespace tl

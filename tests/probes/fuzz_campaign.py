@@ -8,7 +8,7 @@ import numpy as np, _oracle as O, teeline_amd as TA
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 t0 = time.time(); runs = fails = 0
 with TA.Context(0) as ctx, TA.Context(0, TA.TL_FLAG_NO_PRUNE) as ctx2, TA.Context(0, TA.TL_FLAG_2OPT_NT512) as ctx3, \
-        TA.Context(0, TA.TL_FLAG_2OPT_NT256) as ctx4:
+        TA.Context(0, TA.TL_FLAG_2OPT_NT256) as ctx4, TA.Context(0, TA.TL_FLAG_2OPT_FX) as ctx5:
     seed = 0
     while time.time() - t0 < budget:
         seed += 1
@@ -16,7 +16,7 @@ with TA.Context(0) as ctx, TA.Context(0, TA.TL_FLAG_NO_PRUNE) as ctx2, TA.Contex
         n = int(rng.integers(4, 3200)) if seed % 4 else int(rng.integers(4, 200))
         if os.environ.get("FUZZ_BIG"):  # long rows: deferred reversals over many register slots, all tile groups
             n = int(rng.integers(3200, 14500))
-        kind = seed % 6
+        kind = seed % 8
         if kind == 0: xy = rng.random((n, 2)) * 1000
         elif kind == 1: xy = rng.integers(0, int(rng.integers(2, 40)), (n, 2))
         elif kind == 2:
@@ -25,6 +25,8 @@ with TA.Context(0) as ctx, TA.Context(0, TA.TL_FLAG_NO_PRUNE) as ctx2, TA.Contex
             t = np.sort(rng.random(n)) * 1000; xy = np.stack([t, 0.25 * t], 1)          # sorted collinear: long chains per row
         elif kind == 4:
             a = np.sort(rng.random(n)) * 2 * np.pi; xy = np.stack([np.cos(a), np.sin(a)], 1) * 300 + 300
+        elif kind == 6: xy = (rng.integers(0, 1000000, (n, 2)).astype(np.float32) / np.float32(10.0 ** int(rng.integers(0, 5)))).astype(np.float32)  # decimal grids
+        elif kind == 7: xy = rng.integers(0, 1 << int(rng.integers(8, 21)), (n, 2))                       # integer coordinates up to 2^20
         else: xy = rng.normal(0, 1, (n, 2)) * 10.0 ** rng.integers(-3, 4, (n, 1))
         xy = np.ascontiguousarray(xy, dtype=np.float32)
         start = seed % 3
@@ -37,6 +39,9 @@ with TA.Context(0) as ctx, TA.Context(0, TA.TL_FLAG_NO_PRUNE) as ctx2, TA.Contex
         # per thread, so they take n <= 7680 / 3840 (beyond that the library falls back to the wider form by itself)
         if seed % 2 == 0: cases.append(("nt512", prob, ctx3))
         if seed % 3 == 0: cases.append(("nt256", prob, ctx4))
+        # grid-coordinate form of the tour (used where the instance lies on a decimal grid: kinds 0 / 2 / 4 / 5 mostly do not, kind 1
+        # — integer lattices — does; the library falls back to float2 by itself)
+        if seed % 2 == 1: cases.append(("fx", prob, ctx5))
         if n <= 1500 and seed % 3 == 0:
             dm = TA.distance_matrix.build(np.arange(n), xy, ctx=ctx)
             cases.append(("matrix", TA.TspProblem(np.arange(n), xy, TA.distance_matrix.DistanceMatrix(n, dm.items, np.arange(n), "explicit")), ctx))

@@ -61,6 +61,46 @@ def test_config3_seeded_batch_n10000_device_entry(ctx, large):
     assert crc(O.restart_perm(n, 12345, 0)) == g["restarts"]["0"]["init_crc32"]
 
 
+def test_config3_two_descents_per_cu_grid_form_n10000(ctx, large):
+    # More restarts than CUs at n = 10^4: the batch runs the grid-coordinate form (2 x 20-bit coordinates per city, decoded
+    # exactly — checked by the library for every coordinate of the instance), two descents per CU.  Restarts 0..7 against the
+    # committed goldens, every restart against a one-descent-per-CU run of the float2 form.
+    import ctypes as C
+    import torch
+    from teeline_amd import _capi
+    g = large["synthetic10000_seed12345"]
+    n = g["n"]
+    cus = ctx.device_info()["cus"]
+    R = 2 * cus + 8
+    xy = O.synth_xy(n)
+    dev = torch.device("cuda", 0)
+    d_xy = torch.from_numpy(xy).to(dev)
+    s = torch.cuda.current_stream()
+
+    def run(first, count):
+        d_pos = torch.empty((count, n), dtype=torch.int32, device=dev)
+        d_cost = torch.empty(count, dtype=torch.float32, device=dev)
+        d_stats = torch.zeros((count, _capi.TL_DEV_STATS_STRIDE), dtype=torch.int64, device=dev)
+        ctx.check(ctx.lib.tl_two_opt_batch_dev(ctx.handle, d_xy.data_ptr(), n, None, 12345, first, count, _capi.TL_MODE_REF_ORDER,
+                                               d_pos.data_ptr(), d_cost.data_ptr(), d_stats.data_ptr(), C.c_void_p(s.cuda_stream)))
+        torch.cuda.synchronize()
+        return d_pos.cpu().numpy().astype(np.uint32), d_cost.cpu().numpy(), d_stats.cpu().numpy(), ctx.last_kernel_ms()
+
+    pos, cost, st, ms_two = run(0, R)
+    for r in range(8):
+        e = g["restarts"][str(r)]
+        assert f5(cost[r]) == e["cost"] and crc(pos[r]) == e["route_crc32"]
+        assert int(st[r, 0]) == e["stats"]["sweeps"] and int(st[r, 1]) == e["stats"]["moves"] and int(st[r, 2]) == e["stats"]["reversed"]
+    ms_one = 0.0
+    for first in range(0, R, cus):
+        p1, c1, s1, ms = run(first, min(cus, R - first))
+        ms_one += ms
+        k = len(c1)
+        assert c1.tobytes() == cost[first:first + k].tobytes()
+        assert np.array_equal(p1, pos[first:first + k]) and np.array_equal(s1[:, :4], st[first:first + k, :4])
+    assert ms_two < ms_one, (ms_two, ms_one)  # what the form is for
+
+
 def test_config3_multistart_entry_n10000(ctx, large):
     import teeline_amd as TA
     g = large["synthetic10000_seed12345"]

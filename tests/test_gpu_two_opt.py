@@ -428,3 +428,20 @@ def test_batches_with_several_descents_per_cu_match_the_oracle(ctx, n, restarts_
         with TA.Context(0, flag) as c2:
             init = O.restart_perm(n, seed, 5)
             assert_same(gpu_two_opt(c2, xy, None, n, init), O.two_opt(xy, None, n, init=init), n)
+
+
+def test_grid_coordinate_form_matches_the_oracle_where_the_instance_lies_on_a_grid():
+    # TL_FLAG_2OPT_FX: tours kept as 2 x 20-bit grid coordinates (decoded exactly) instead of float2.  Decimal grids of 0..4
+    # digits and integer coordinates take the form; arbitrary floats, negative or too large coordinates fall back to float2
+    # inside the library — the results must be the oracle's either way.
+    import teeline_amd as TA
+    rng = np.random.default_rng(5)
+    with TA.Context(0, TA.TL_FLAG_2OPT_FX) as c2:
+        for n, digits in ((700, 3), (1500, 0), (1200, 1), (900, 4), (2500, 2)):
+            xy = (rng.integers(0, 1000000, (n, 2)).astype(np.float32) / np.float32(10.0 ** digits)).astype(np.float32)
+            for init in (None, O.restart_perm(n, 3, 1)):
+                assert_same(gpu_two_opt(c2, xy, None, n, init), O.two_opt(xy, None, n, init=init), n)
+        for xy in (rng.random((800, 2)).astype(np.float32) * 1000, (rng.integers(-500, 500, (600, 2))).astype(np.float32),
+                   rng.integers(0, 1 << 22, (500, 2)).astype(np.float32)):
+            n = len(xy)
+            assert_same(gpu_two_opt(c2, xy, None, n, None), O.two_opt(xy, None, n), n)
