@@ -298,6 +298,25 @@ def main():
     out["roofline"] = valu_roofline(n, R, a.seed, first, info, k_ms, clock_hz, work, cand_per_launch, a.steps)
     if world == 1 and not a.no_extras:
         extras = {}
+        # Two descents per CU: with more restarts than CUs the library keeps the tours as grid coordinates (7 B per city instead
+        # of 10; exact decode, checked per instance) so that two tours of n = 10^4 share a CU's LDS.  Same tours: the first R
+        # restarts of the double batch must be the timed batch's.
+        R2 = 2 * R
+        d_pos2 = torch.empty((R2, n), dtype=torch.int32, device=dev)
+        d_cost2 = torch.empty(R2, dtype=torch.float32, device=dev)
+        d_stats2 = torch.zeros((R2, _capi.TL_DEV_STATS_STRIDE), dtype=torch.int64, device=dev)
+        ms2 = []
+        for _ in range(2):
+            with torch.cuda.stream(stream):
+                ctx.check(lib.tl_two_opt_batch_dev(h, d_xy.data_ptr(), n, None, a.seed, first, R2, _capi.TL_MODE_REF_ORDER,
+                                                   d_pos2.data_ptr(), d_cost2.data_ptr(), d_stats2.data_ptr(), C.c_void_p(stream.cuda_stream)))
+            torch.cuda.synchronize()
+            ms2.append(ctx.last_kernel_ms())
+        assert torch.equal(d_pos2[:R], d_pos) and torch.equal(d_cost2[:R], d_cost), "the two-descents-per-CU batch gave other tours"
+        cands2 = int(d_stats2[:, 0].sum().item()) * per_sweep
+        extras["multistart_two_descents_per_cu"] = {"restarts": R2, "kernel_ms": min(ms2), "candidates_per_s": cands2 / (min(ms2) * 1e-3),
+                                                    "vs_one_per_cu": (cands2 / (min(ms2) * 1e-3)) / (cand_per_launch / (k_ms * 1e-3)),
+                                                    "note": "tl_two_opt_batch_dev with 2 x the CU count of restarts; first half bit-identical to the timed batch (asserted)"}
         prob = TA.TspProblem(np.arange(n), xy)
         init = TA.synth.restart_perm(n, a.seed, 0)
         sol = TA.two_opt.solve(prob, None, None, [int(v) for v in init], ctx=ctx)
