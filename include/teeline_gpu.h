@@ -242,7 +242,9 @@ int tl_two_opt_population(tl_ctx *ctx, const float *xy, uint32_t n, const float 
  * into L3, shader clocks, 100 MHz ticks, reserved...}.  stream: the hipStream_t to enqueue on,
  * or NULL for the context's own stream — which is NON-BLOCKING, i.e. not ordered with the legacy default stream: a
  * caller that passes NULL must wait on tl_last_kernel_ms() (or a device synchronise) before touching the outputs.
- * Asynchronous: returns after enqueueing. */
+ * Asynchronous: returns after enqueueing — except that a batch with more descents than the device has CUs at 7 100 < n <= 10 240
+ * first asks the device whether the coordinates lie on a decimal grid (then two descents share a CU): one 4-byte read-back,
+ * i.e. a synchronisation of `stream`, before the descents are enqueued. */
 int tl_two_opt_batch_dev(tl_ctx *ctx, const float *d_xy, uint32_t n, const uint32_t *d_init,
                          uint64_t seed, uint32_t first, uint32_t count, int mode, uint32_t *d_out_pos,
                          float *d_out_cost, uint64_t *d_out_stats, void *stream);
