@@ -298,128 +298,131 @@ def main():
     out["roofline"] = valu_roofline(n, R, a.seed, first, info, k_ms, clock_hz, work, cand_per_launch, a.steps)
     if world == 1 and not a.no_extras:
         extras = {}
-        # Two descents per CU: with more restarts than CUs the library keeps the tours as grid coordinates (7 B per city instead
-        # of 10; exact decode, checked per instance) so that two tours of n = 10^4 share a CU's LDS.  Same tours: the first R
-        # restarts of the double batch must be the timed batch's.
-        R2 = 2 * R
-        d_pos2 = torch.empty((R2, n), dtype=torch.int32, device=dev)
-        d_cost2 = torch.empty(R2, dtype=torch.float32, device=dev)
-        d_stats2 = torch.zeros((R2, _capi.TL_DEV_STATS_STRIDE), dtype=torch.int64, device=dev)
-        ms2 = []
-        for _ in range(2):
-            with torch.cuda.stream(stream):
-                ctx.check(lib.tl_two_opt_batch_dev(h, d_xy.data_ptr(), n, None, a.seed, first, R2, _capi.TL_MODE_REF_ORDER,
-                                                   d_pos2.data_ptr(), d_cost2.data_ptr(), d_stats2.data_ptr(), C.c_void_p(stream.cuda_stream)))
-            torch.cuda.synchronize()
-            ms2.append(ctx.last_kernel_ms())
-        assert torch.equal(d_pos2[:R], d_pos) and torch.equal(d_cost2[:R], d_cost), "the two-descents-per-CU batch gave other tours"
-        cands2 = int(d_stats2[:, 0].sum().item()) * per_sweep
-        extras["multistart_two_descents_per_cu"] = {"restarts": R2, "kernel_ms": min(ms2), "candidates_per_s": cands2 / (min(ms2) * 1e-3),
-                                                    "vs_one_per_cu": (cands2 / (min(ms2) * 1e-3)) / (cand_per_launch / (k_ms * 1e-3)),
-                                                    "note": "tl_two_opt_batch_dev with 2 x the CU count of restarts; first half bit-identical to the timed batch (asserted)"}
-        prob = TA.TspProblem(np.arange(n), xy)
-        init = TA.synth.restart_perm(n, a.seed, 0)
-        sol = TA.two_opt.solve(prob, None, None, [int(v) for v in init], ctx=ctx)
-        extras["single_descent_random_start"] = {"candidates_per_s": sol.stats["candidates"] / (sol.stats["kernel_ms"] * 1e-3),
-                                                 "kernel_ms": sol.stats["kernel_ms"], "cost": float(sol.total),
-                                                 "moves": sol.stats["moves"], "sweeps": sol.stats["sweeps"]}
-        rc_nn = TA.nearest_neighbor.solve(prob, ctx=ctx)
-        sol_g = TA.two_opt.solve(prob, None, None, rc_nn.route(), ctx=ctx)
-        extras["single_descent_nn_start"] = {"candidates_per_s": sol_g.stats["candidates"] / (sol_g.stats["kernel_ms"] * 1e-3),
-                                             "kernel_ms": sol_g.stats["kernel_ms"], "cost": float(sol_g.total), "nn_cost": float(rc_nn.total),
-                                             "moves": sol_g.stats["moves"], "sweeps": sol_g.stats["sweeps"],
-                                             "note": "BASELINE configs[2]: one REF_ORDER descent from the NN seed on ONE CU; expected cost 77647.55469"}
-        sol_b = TA.two_opt.solve(prob, None, None, rc_nn.route(), ctx=ctx, mode=TA.TL_MODE_BEST_SWEEP)
-        extras["best_sweep_nn_start"] = {"candidates_per_s": sol_b.stats["candidates"] / (sol_b.stats["kernel_ms"] * 1e-3),
-                                         "kernel_ms": sol_b.stats["kernel_ms"], "cost": float(sol_b.total), "sweeps": sol_b.stats["sweeps"],
-                                         "note": "TL_MODE_BEST_SWEEP (own mode, whole chip per sweep), single descent"}
-        with TA.Context(local, TA.TL_FLAG_NO_PRUNE) as c2:
-            s2 = TA.two_opt.multistart(prob, R, seed=a.seed, first=0, ctx=c2)
-            extras["no_prune_multistart"] = {"candidates_per_s": s2.stats["candidates"] / (s2.stats["kernel_ms"] * 1e-3),
-                                             "kernel_ms": s2.stats["kernel_ms"], "best_cost": float(s2.total),
-                                             "note": "TL_FLAG_NO_PRUNE: every candidate decided with two fresh correctly rounded sqrt"}
-        dm, ms = TA.distance_matrix.build(np.arange(n), xy, ctx=ctx, return_ms=True)  # warm-up (workspace allocation)
-        dm_ms = []
-        for _ in range(5):
-            dm, ms = TA.distance_matrix.build(np.arange(n), xy, ctx=ctx, return_ms=True)
-            dm_ms.append(ms)
-        ms = float(np.mean(dm_ms))
-        gb = n * (n - 1) / 2 * 4 / 1e9
-        extras["dm_build_packed"] = {"kernel_ms": ms, "kernel_ms_min": float(min(dm_ms)), "launches": len(dm_ms), "GBps": gb / (ms * 1e-3), "frac_of_hbm_peak": gb / (ms * 1e-3) / HBM_PEAK_GBPS,
-                                     "bytes": n * (n - 1) // 2 * 4}
-        # the HBM-bound kernel of the path (DistanceMatrix::build): a roofline object of its own, traffic from its PMC passes
-        rdm = {"bound": "hbm", "achieved": gb / (ms * 1e-3), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gb / (ms * 1e-3) / HBM_PEAK_GBPS,
-               "traffic": None, "kernel": "k_dm_build_packed_blocked", "kernel_ms_avg": ms,
-               "note": "4 B written per distance; a plain fill of the same 200 MB reaches 6.65 TB/s on this part (scripts/hbm_fill_probe.py), "
-                       "row-blocked build: column coordinates loaded once per 4 rows (DESIGN.md §4.1)"}
-        dpath = latest_profile("r*_dm_build_hbm_traffic.json")
-        if dpath and n == 10000:
-            try:
-                dj = json.load(open(dpath))
-                rdm["traffic"] = dj.get("traffic_bytes_per_launch")
-                rdm["traffic_source"] = dj.get("source")
-            except Exception:
-                pass
-        extras["dm_build_packed"]["roofline"] = rdm
-        # BASELINE configs[1]: pr1002-sized instance (the file is not in the reference tree -> synthetic n = 1002, labelled),
-        # full REF_ORDER sweep to the local optimum with every distance gathered from the fp32 matrix in HBM
-        n2 = 1002
-        xy2 = TA.synth.synth_xy(n2)
-        dm2 = TA.distance_matrix.build(np.arange(n2), xy2, ctx=ctx)
-        pm2 = TA.TspProblem(np.arange(n2), xy2, TA.distance_matrix.DistanceMatrix(n2, dm2.items, np.arange(n2), "explicit"))
-        nn2 = [int(v) for v in TA.nearest_neighbor.solve(TA.TspProblem(np.arange(n2), xy2), ctx=ctx).route()]
-        cfg1 = {}
-        for name, init in (("nn_start", nn2), ("identity_start", None)):
+        try:  # the extras must never cost the run its headline line
+            # Two descents per CU: with more restarts than CUs the library keeps the tours as grid coordinates (7 B per city instead
+            # of 10; exact decode, checked per instance) so that two tours of n = 10^4 share a CU's LDS.  Same tours: the first R
+            # restarts of the double batch must be the timed batch's.
+            R2 = 2 * R
+            d_pos2 = torch.empty((R2, n), dtype=torch.int32, device=dev)
+            d_cost2 = torch.empty(R2, dtype=torch.float32, device=dev)
+            d_stats2 = torch.zeros((R2, _capi.TL_DEV_STATS_STRIDE), dtype=torch.int64, device=dev)
+            ms2 = []
             for _ in range(2):
-                sm = TA.two_opt.solve(pm2, None, None, init, ctx=ctx)
-            cps = sm.stats["candidates"] / (sm.stats["kernel_ms"] * 1e-3)
-            cfg1[name] = {"kernel_ms": sm.stats["kernel_ms"], "candidates_per_s": cps, "cost": float(sm.total),
-                          "sweeps": sm.stats["sweeps"], "moves": sm.stats["moves"],
-                          "algorithmic_GBps_at_16B_per_candidate": cps * 16.0 / 1e9}
-        cfg1["note"] = ("one descent = one workgroup on ONE CU; latency-bound (a step per move), the 4 MB full matrix stays in L2/MALL; "
-                        "kernel_ms includes the packed -> full expansion")
-        # the same kernel with the chip full: a population of 256 tours (the seeded restart permutations 0..255), one descent
-        # per CU, every distance gathered from the one 4 MB matrix in L2 — the throughput form of configs[1]
-        pop = [[int(v) for v in TA.synth.restart_perm(n2, a.seed, r)] for r in range(256)]
-        for _ in range(2):
-            sols = TA.two_opt.solve_population(pm2, pop, ctx=ctx)
-        pst = sols[0].stats
-        pcps = pst["candidates"] / (pst["kernel_ms"] * 1e-3)
-        L2_GATHER_PEAK_GBPS = 17000.0  # MI355X_MICROARCH.md "Indexed rows": rows served from the XCDs' L2, 16.8-18.8 TB/s chip-wide
-        cfg1["population_256_random_tours"] = {
-            "kernel_ms": pst["kernel_ms"], "candidates_per_s": pcps, "moves": pst["moves"], "sweeps": pst["sweeps"],
-            "best_cost": float(min(float(s_.total) for s_ in sols)),
-            "roofline": {"bound": "l2_gather", "achieved": pcps * 16.0 / 1e9, "peak": L2_GATHER_PEAK_GBPS, "unit": "GB/s",
-                         "frac": pcps * 16.0 / 1e9 / L2_GATHER_PEAK_GBPS, "traffic": None, "kernel": "k_two_opt_ref_dm",
-                         "note": "16 algorithmic bytes per candidate (perm[j+1], D[a][c], D[b][e], D[c][e]; SURVEY.md §8(d)) against the "
-                                 "L2-served gather rate of the guide; the descent is bound by the chain of dependent latencies of a "
-                                 "step, not by that bandwidth"}}
-        extras["two_opt_matrix_in_hbm_n1002"] = cfg1
-        n3 = 1002
-        p3 = TA.TspProblem(np.arange(n3), TA.synth.synth_xy(n3))
-        nn3 = [int(v) for v in TA.nearest_neighbor.solve(p3, ctx=ctx).route()]
-        TA.three_opt.find_best_move(p3, nn3, ctx=ctx)
-        TA.three_opt.find_best_move(p3, nn3, ctx=ctx)
-        ms3 = ctx.last_kernel_ms()
-        tri = n3 * (n3 - 1) * (n3 - 2) // 6 - (n3 - 2)
-        extras["three_opt_scan_n1002"] = {"triples_per_s": tri / (ms3 * 1e-3), "kernel_ms": ms3, "triples": tri}
-        n5 = 5000
-        p5 = TA.TspProblem(np.arange(n5), TA.synth.synth_xy(n5))
-        nn5 = [int(v) for v in TA.nearest_neighbor.solve(p5, ctx=ctx).route()]
-        TA.or_opt.find_best_move(p5, nn5, ctx=ctx)
-        TA.or_opt.find_best_move(p5, nn5, ctx=ctx)
-        ms5 = ctx.last_kernel_ms()
-        extras["or_opt_scan_n5000"] = {"placements_per_s": 6.0 * n5 * n5 / (ms5 * 1e-3), "kernel_ms": ms5,
-                                       "placements": 6 * n5 * n5, "note": "3 segment lengths x n starts x n insertion points x {fwd, rev} (or_opt.rs:80-164)"}
-        # BASELINE configs[4] size: Lin-Kernighan ILS at n = 13 509 (synthetic points), candidate lists through the kd-tree
-        n13 = 13509
-        p13 = TA.TspProblem(np.arange(n13), TA.synth.synth_xy(n13))
-        lk_opts = TA.LKOptions(TA.HeuristicOptions(epochs=20, platoo_epochs=10, n_nearest=5), 5)
-        TA.lin_kernighan.solve(p13, lk_opts, ctx=ctx, seed=1)
-        slk = TA.lin_kernighan.solve(p13, lk_opts, ctx=ctx, seed=1)
-        extras["lin_kernighan_n13509_20_epochs"] = {"kernel_ms": slk.stats["kernel_ms"], "total_ms": slk.stats["total_ms"], "cost": float(slk.total),
-                                                    "scans": slk.stats["sweeps"], "moves": slk.stats["moves"],
-                                                    "note": "tl_lk incl. NN seed and k-NN lists; the same run is a golden-checked -m gpu test (tests/test_gpu_full_size.py)"}
+                with torch.cuda.stream(stream):
+                    ctx.check(lib.tl_two_opt_batch_dev(h, d_xy.data_ptr(), n, None, a.seed, first, R2, _capi.TL_MODE_REF_ORDER,
+                                                       d_pos2.data_ptr(), d_cost2.data_ptr(), d_stats2.data_ptr(), C.c_void_p(stream.cuda_stream)))
+                torch.cuda.synchronize()
+                ms2.append(ctx.last_kernel_ms())
+            assert torch.equal(d_pos2[:R], d_pos) and torch.equal(d_cost2[:R], d_cost), "the two-descents-per-CU batch gave other tours"
+            cands2 = int(d_stats2[:, 0].sum().item()) * per_sweep
+            extras["multistart_two_descents_per_cu"] = {"restarts": R2, "kernel_ms": min(ms2), "candidates_per_s": cands2 / (min(ms2) * 1e-3),
+                                                        "vs_one_per_cu": (cands2 / (min(ms2) * 1e-3)) / (cand_per_launch / (k_ms * 1e-3)),
+                                                        "note": "tl_two_opt_batch_dev with 2 x the CU count of restarts; first half bit-identical to the timed batch (asserted)"}
+            prob = TA.TspProblem(np.arange(n), xy)
+            init = TA.synth.restart_perm(n, a.seed, 0)
+            sol = TA.two_opt.solve(prob, None, None, [int(v) for v in init], ctx=ctx)
+            extras["single_descent_random_start"] = {"candidates_per_s": sol.stats["candidates"] / (sol.stats["kernel_ms"] * 1e-3),
+                                                     "kernel_ms": sol.stats["kernel_ms"], "cost": float(sol.total),
+                                                     "moves": sol.stats["moves"], "sweeps": sol.stats["sweeps"]}
+            rc_nn = TA.nearest_neighbor.solve(prob, ctx=ctx)
+            sol_g = TA.two_opt.solve(prob, None, None, rc_nn.route(), ctx=ctx)
+            extras["single_descent_nn_start"] = {"candidates_per_s": sol_g.stats["candidates"] / (sol_g.stats["kernel_ms"] * 1e-3),
+                                                 "kernel_ms": sol_g.stats["kernel_ms"], "cost": float(sol_g.total), "nn_cost": float(rc_nn.total),
+                                                 "moves": sol_g.stats["moves"], "sweeps": sol_g.stats["sweeps"],
+                                                 "note": "BASELINE configs[2]: one REF_ORDER descent from the NN seed on ONE CU; expected cost 77647.55469"}
+            sol_b = TA.two_opt.solve(prob, None, None, rc_nn.route(), ctx=ctx, mode=TA.TL_MODE_BEST_SWEEP)
+            extras["best_sweep_nn_start"] = {"candidates_per_s": sol_b.stats["candidates"] / (sol_b.stats["kernel_ms"] * 1e-3),
+                                             "kernel_ms": sol_b.stats["kernel_ms"], "cost": float(sol_b.total), "sweeps": sol_b.stats["sweeps"],
+                                             "note": "TL_MODE_BEST_SWEEP (own mode, whole chip per sweep), single descent"}
+            with TA.Context(local, TA.TL_FLAG_NO_PRUNE) as c2:
+                s2 = TA.two_opt.multistart(prob, R, seed=a.seed, first=0, ctx=c2)
+                extras["no_prune_multistart"] = {"candidates_per_s": s2.stats["candidates"] / (s2.stats["kernel_ms"] * 1e-3),
+                                                 "kernel_ms": s2.stats["kernel_ms"], "best_cost": float(s2.total),
+                                                 "note": "TL_FLAG_NO_PRUNE: every candidate decided with two fresh correctly rounded sqrt"}
+            dm, ms = TA.distance_matrix.build(np.arange(n), xy, ctx=ctx, return_ms=True)  # warm-up (workspace allocation)
+            dm_ms = []
+            for _ in range(5):
+                dm, ms = TA.distance_matrix.build(np.arange(n), xy, ctx=ctx, return_ms=True)
+                dm_ms.append(ms)
+            ms = float(np.mean(dm_ms))
+            gb = n * (n - 1) / 2 * 4 / 1e9
+            extras["dm_build_packed"] = {"kernel_ms": ms, "kernel_ms_min": float(min(dm_ms)), "launches": len(dm_ms), "GBps": gb / (ms * 1e-3), "frac_of_hbm_peak": gb / (ms * 1e-3) / HBM_PEAK_GBPS,
+                                         "bytes": n * (n - 1) // 2 * 4}
+            # the HBM-bound kernel of the path (DistanceMatrix::build): a roofline object of its own, traffic from its PMC passes
+            rdm = {"bound": "hbm", "achieved": gb / (ms * 1e-3), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gb / (ms * 1e-3) / HBM_PEAK_GBPS,
+                   "traffic": None, "kernel": "k_dm_build_packed_blocked", "kernel_ms_avg": ms,
+                   "note": "4 B written per distance; a plain fill of the same 200 MB reaches 6.65 TB/s on this part (scripts/hbm_fill_probe.py), "
+                           "row-blocked build: column coordinates loaded once per 4 rows (DESIGN.md §4.1)"}
+            dpath = latest_profile("r*_dm_build_hbm_traffic.json")
+            if dpath and n == 10000:
+                try:
+                    dj = json.load(open(dpath))
+                    rdm["traffic"] = dj.get("traffic_bytes_per_launch")
+                    rdm["traffic_source"] = dj.get("source")
+                except Exception:
+                    pass
+            extras["dm_build_packed"]["roofline"] = rdm
+            # BASELINE configs[1]: pr1002-sized instance (the file is not in the reference tree -> synthetic n = 1002, labelled),
+            # full REF_ORDER sweep to the local optimum with every distance gathered from the fp32 matrix in HBM
+            n2 = 1002
+            xy2 = TA.synth.synth_xy(n2)
+            dm2 = TA.distance_matrix.build(np.arange(n2), xy2, ctx=ctx)
+            pm2 = TA.TspProblem(np.arange(n2), xy2, TA.distance_matrix.DistanceMatrix(n2, dm2.items, np.arange(n2), "explicit"))
+            nn2 = [int(v) for v in TA.nearest_neighbor.solve(TA.TspProblem(np.arange(n2), xy2), ctx=ctx).route()]
+            cfg1 = {}
+            for name, init in (("nn_start", nn2), ("identity_start", None)):
+                for _ in range(2):
+                    sm = TA.two_opt.solve(pm2, None, None, init, ctx=ctx)
+                cps = sm.stats["candidates"] / (sm.stats["kernel_ms"] * 1e-3)
+                cfg1[name] = {"kernel_ms": sm.stats["kernel_ms"], "candidates_per_s": cps, "cost": float(sm.total),
+                              "sweeps": sm.stats["sweeps"], "moves": sm.stats["moves"],
+                              "algorithmic_GBps_at_16B_per_candidate": cps * 16.0 / 1e9}
+            cfg1["note"] = ("one descent = one workgroup on ONE CU; latency-bound (a step per move), the 4 MB full matrix stays in L2/MALL; "
+                            "kernel_ms includes the packed -> full expansion")
+            # the same kernel with the chip full: a population of 256 tours (the seeded restart permutations 0..255), one descent
+            # per CU, every distance gathered from the one 4 MB matrix in L2 — the throughput form of configs[1]
+            pop = [[int(v) for v in TA.synth.restart_perm(n2, a.seed, r)] for r in range(256)]
+            for _ in range(2):
+                sols = TA.two_opt.solve_population(pm2, pop, ctx=ctx)
+            pst = sols[0].stats
+            pcps = pst["candidates"] / (pst["kernel_ms"] * 1e-3)
+            L2_GATHER_PEAK_GBPS = 17000.0  # MI355X_MICROARCH.md "Indexed rows": rows served from the XCDs' L2, 16.8-18.8 TB/s chip-wide
+            cfg1["population_256_random_tours"] = {
+                "kernel_ms": pst["kernel_ms"], "candidates_per_s": pcps, "moves": pst["moves"], "sweeps": pst["sweeps"],
+                "best_cost": float(min(float(s_.total) for s_ in sols)),
+                "roofline": {"bound": "l2_gather", "achieved": pcps * 16.0 / 1e9, "peak": L2_GATHER_PEAK_GBPS, "unit": "GB/s",
+                             "frac": pcps * 16.0 / 1e9 / L2_GATHER_PEAK_GBPS, "traffic": None, "kernel": "k_two_opt_ref_dm",
+                             "note": "16 algorithmic bytes per candidate (perm[j+1], D[a][c], D[b][e], D[c][e]; SURVEY.md §8(d)) against the "
+                                     "L2-served gather rate of the guide; the descent is bound by the chain of dependent latencies of a "
+                                     "step, not by that bandwidth"}}
+            extras["two_opt_matrix_in_hbm_n1002"] = cfg1
+            n3 = 1002
+            p3 = TA.TspProblem(np.arange(n3), TA.synth.synth_xy(n3))
+            nn3 = [int(v) for v in TA.nearest_neighbor.solve(p3, ctx=ctx).route()]
+            TA.three_opt.find_best_move(p3, nn3, ctx=ctx)
+            TA.three_opt.find_best_move(p3, nn3, ctx=ctx)
+            ms3 = ctx.last_kernel_ms()
+            tri = n3 * (n3 - 1) * (n3 - 2) // 6 - (n3 - 2)
+            extras["three_opt_scan_n1002"] = {"triples_per_s": tri / (ms3 * 1e-3), "kernel_ms": ms3, "triples": tri}
+            n5 = 5000
+            p5 = TA.TspProblem(np.arange(n5), TA.synth.synth_xy(n5))
+            nn5 = [int(v) for v in TA.nearest_neighbor.solve(p5, ctx=ctx).route()]
+            TA.or_opt.find_best_move(p5, nn5, ctx=ctx)
+            TA.or_opt.find_best_move(p5, nn5, ctx=ctx)
+            ms5 = ctx.last_kernel_ms()
+            extras["or_opt_scan_n5000"] = {"placements_per_s": 6.0 * n5 * n5 / (ms5 * 1e-3), "kernel_ms": ms5,
+                                           "placements": 6 * n5 * n5, "note": "3 segment lengths x n starts x n insertion points x {fwd, rev} (or_opt.rs:80-164)"}
+            # BASELINE configs[4] size: Lin-Kernighan ILS at n = 13 509 (synthetic points), candidate lists through the kd-tree
+            n13 = 13509
+            p13 = TA.TspProblem(np.arange(n13), TA.synth.synth_xy(n13))
+            lk_opts = TA.LKOptions(TA.HeuristicOptions(epochs=20, platoo_epochs=10, n_nearest=5), 5)
+            TA.lin_kernighan.solve(p13, lk_opts, ctx=ctx, seed=1)
+            slk = TA.lin_kernighan.solve(p13, lk_opts, ctx=ctx, seed=1)
+            extras["lin_kernighan_n13509_20_epochs"] = {"kernel_ms": slk.stats["kernel_ms"], "total_ms": slk.stats["total_ms"], "cost": float(slk.total),
+                                                        "scans": slk.stats["sweeps"], "moves": slk.stats["moves"],
+                                                        "note": "tl_lk incl. NN seed and k-NN lists; the same run is a golden-checked -m gpu test (tests/test_gpu_full_size.py)"}
+        except Exception as exc:
+            extras["error"] = repr(exc)
         out["extras"] = extras
     if world == 1 and not a.no_cpu_baseline:
         res, out["cpu_baseline"] = cpu_baseline(n, a.seed, xy)
