@@ -185,3 +185,21 @@ def test_empty_and_tiny_inputs_of_every_entry_point(ctx):
         TA.two_opt.multistart(prob(O.synth_xy(50, seed=1)), 0, ctx=ctx)
     with pytest.raises(TA.TeelineGpuError):
         TA.two_opt.solve_population(prob(O.synth_xy(5, seed=1)), [[0, 1, 2, 3, 3]], ctx=ctx)
+
+
+def test_forced_kernel_forms_fall_back_beyond_their_sizes(ctx):
+    # TL_FLAG_2OPT_FX / _NT512 / _NT256 force a form only where it exists: the grid form up to n = 10 240, the 8- / 4-wave
+    # forms up to 15 x 512 / 15 x 256 cities (a flush holds 15 elements per thread).  Beyond, the library runs the wide
+    # float2 form: same tours as the default context.
+    import teeline_amd as TA
+    n = 12000
+    rng = np.random.default_rng(12)
+    xy = (rng.integers(0, 1000000, (n, 2)).astype(np.float32) / np.float32(1000.0)).astype(np.float32)
+    prob = TA.TspProblem(np.arange(n), xy)
+    nn = TA.nearest_neighbor.solve(prob, ctx=ctx).route()
+    ref = TA.two_opt.solve(prob, None, None, nn, ctx=ctx)
+    for flag in (TA.TL_FLAG_2OPT_FX, TA.TL_FLAG_2OPT_NT512, TA.TL_FLAG_2OPT_NT256):
+        with TA.Context(0, flag) as c2:
+            sol = TA.two_opt.solve(prob, None, None, nn, ctx=c2)
+            assert list(sol.route()) == list(ref.route()) and sol.total == ref.total
+            assert sol.stats["moves"] == ref.stats["moves"] and sol.stats["sweeps"] == ref.stats["sweeps"]
