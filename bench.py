@@ -424,6 +424,9 @@ def main():
         except Exception as exc:
             extras["error"] = repr(exc)
         out["extras"] = extras
+        if "multistart_two_descents_per_cu" in extras:  # the same kernel with a batch of 2 x CUs restarts (two descents per CU), for the record
+            out["value_with_two_descents_per_cu"] = {"value": extras["multistart_two_descents_per_cu"]["candidates_per_s"], "unit": "candidates/s",
+                                                     "restarts_per_gpu": extras["multistart_two_descents_per_cu"]["restarts"]}
     if world == 1 and not a.no_cpu_baseline:
         res, out["cpu_baseline"] = cpu_baseline(n, a.seed, xy)
         # the oracle's descents of restarts 0..cores-1 are the same units the GPU just ran: cost bits and sweep / move
