@@ -763,7 +763,7 @@ hipError_t launch_two_opt_ref_lds(const TwoOptBatchArgs &A, uint32_t count, bool
     if (force_nt) {
         nt = force_nt;
     } else if (cus > 0 && count > (uint32_t)cus) {
-        if (fit >= 4 && count >= 3u * (uint32_t)cus) nt = 256;
+        if (fit >= 4 && count > 2u * (uint32_t)cus) nt = 256;  // (up to two per CU the 8-wave form is the faster one: scripts/per_cu_threshold.py)
         else if (fit >= 2) nt = 512;
     }
     while (nt < TL_TWO_OPT_NT && (size_t)A.n > (size_t)kFlushSlots * (size_t)nt) nt *= 2;
