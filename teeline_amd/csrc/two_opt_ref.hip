@@ -696,11 +696,15 @@ size_t two_opt_ref_fx_lds_bytes(uint32_t n)
 
 // The grid form costs a decode per point read, so it is used only where it buys a second descent per CU: a batch with more
 // descents than CUs whose tours fit the LDS twice at 7 B per city but not at 10 (7 100 < n <= 10 240 on MI355X).
+// ... or a third and fourth: more than two descents per CU where four tours fit at 7 B per city but not at 10 (3 050 < n <= 4 300).
 bool two_opt_ref_fx_pays(uint32_t n, uint32_t count, int cus, int lds_budget)
 {
     const size_t plain = two_opt_ref_lds_bytes(n, nullptr, TL_TWO_OPT_NT), fx = two_opt_ref_fx_lds_bytes(n);
-    return cus > 0 && count > (uint32_t)cus && 2 * plain > (size_t)lds_budget && 2 * fx <= (size_t)lds_budget &&
-           (size_t)n <= (size_t)kFlushSlotsFx * 512;
+    if (cus <= 0 || count <= (uint32_t)cus) return false;
+    const bool two = 2 * plain > (size_t)lds_budget && 2 * fx <= (size_t)lds_budget && (size_t)n <= (size_t)kFlushSlotsFx * 512;
+    const bool four = count > 2u * (uint32_t)cus && 4 * plain > (size_t)lds_budget && 4 * fx <= (size_t)lds_budget &&
+                      (size_t)n <= (size_t)kFlushSlotsFx * 256;
+    return two || four;
 }
 
 __global__ __launch_bounds__(256) void k_fx_encode(const float2 *__restrict__ xy, uint32_t n, double scale, double inv, uint2 *__restrict__ out,
@@ -753,9 +757,12 @@ hipError_t launch_two_opt_ref_lds(const TwoOptBatchArgs &A, uint32_t count, bool
     const size_t lds = two_opt_ref_lds_bytes(A.n, &n_pad, TL_TWO_OPT_NT);
     TwoOptBatchArgs B = A;
     B.n_pad = n_pad;
-    if (A.fx_xy && A.fx_inv != 0.0) {  // grid-coordinate form: two descents per CU on 8 waves (the caller has checked that it fits)
+    if (A.fx_xy && A.fx_inv != 0.0) {  // grid-coordinate form: two descents per CU on 8 waves, or four on 4 (the caller has checked that it fits)
+        const size_t fl = two_opt_ref_fx_lds_bytes(A.n);
+        if (cus > 0 && count > 2u * (uint32_t)cus && 4 * fl <= (size_t)lds_budget && (size_t)A.n <= (size_t)kFlushSlotsFx * 256)
+            return launch_nt<256, true>(B, count, fl, prune, count_work, s);
         if ((size_t)A.n > (size_t)kFlushSlotsFx * 512) return hipErrorInvalidValue;
-        return launch_nt<512, true>(B, count, two_opt_ref_fx_lds_bytes(A.n), prune, count_work, s);
+        return launch_nt<512, true>(B, count, fl, prune, count_work, s);
     }
     // descents per CU the LDS allows; a flush holds kFlushSlots elements per thread, so a narrow form also needs n <= 15 NT
     const size_t fit = lds ? (size_t)lds_budget / lds : 1;

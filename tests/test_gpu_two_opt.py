@@ -407,7 +407,7 @@ def test_population_explicit_matrix_and_bad_input(ctx, tsplib_dir):
         TA.two_opt.solve_population(prob, [ids, ids[:-1] + [ids[0]]], ctx=ctx)  # second tour repeats a city
 
 
-@pytest.mark.parametrize("n,restarts_per_cu", [(400, 4.1), (4000, 2.1)])
+@pytest.mark.parametrize("n,restarts_per_cu", [(400, 4.1), (4000, 1.6), (3600, 2.1)])  # 4-wave float2, 8-wave float2, 4-wave grid form
 def test_batches_with_several_descents_per_cu_match_the_oracle(ctx, n, restarts_per_cu):
     # More descents than CUs: where the LDS holds four (n <= ~3000) or two (n <= ~7100) tours the batch runs the 4- / 8-wave form of
     # a descent, several per CU.  Same tours as one descent per CU, whatever the form: the costs of ALL restarts against a
