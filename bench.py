@@ -14,7 +14,14 @@ workload: BASELINE configs 3/4 — synthetic EUC_2D n=10000 (xorshift64 generato
           generated on the device inside the timed region (they are part of the job).
 candidates are counted as the reference's loop visits them: sweeps x (n-3)(n-2)/2 per descent.
 
-Usage: python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+Usage: python bench.py --gpus N --steps K --warmup W
+  N > 1 under torch.distributed.run (RANK / WORLD_SIZE set): this process is one rank of N.
+  N > 1 bare (no WORLD_SIZE): bench.py starts the N ranks itself — a child `python -m torch.distributed.run --nnodes=1
+        --nproc-per-node N --master-addr 127.0.0.1 ...` of this same file, started before anything here touches the GPU —
+        relays rank 0's JSON line and exits with the child's code; a line whose `ranks_seen` is not N is an error.
+  --single-process: no RCCL, ONE process drives N devices through tl_two_opt_multistart_devices (the path a Rust caller
+        has); cross-check of the RCCL number.
+  --dry-launch: rehearsal of the launch + collective plumbing on CPU (gloo, a stub step, no GPU, no oracle): NOT a measurement.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -52,7 +59,47 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the single-descent / no-prune / matrix-build extras")
     ap.add_argument("--no-work-count", action="store_true",
                     help="skip the one untimed launch of the counting kernel variant (PMC passes: only the timed kernel runs)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1 without RCCL: one process, one tl_ctx per device, tl_two_opt_multistart_devices")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="CPU rehearsal of the N-rank launch and the collectives (gloo, stub step): prints a line with value null")
     return ap.parse_args()
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(a):
+    """`bench.py --gpus N` (N > 1) started bare: run the N ranks as children of a torch.distributed.run child.  Nothing in
+    this process has touched the GPU (argparse + imports only), and the ranks are fresh processes, never a re-exec.
+    Relays rank 0's JSON line; non-zero exit if the child failed, printed no line, or the line saw another rank count."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')]
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith('{"metric"'):
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0:
+        for ln in lines:
+            print(ln)
+        raise SystemExit(proc.returncode)
+    if len(lines) != 1:
+        raise SystemExit(f"bench.py: the {a.gpus}-rank child printed {len(lines)} result lines instead of one")
+    seen = json.loads(lines[0]).get("ranks_seen")
+    print(lines[0])
+    if seen != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the job saw {seen} ranks")
+    return 0
 
 
 def cpu_baseline(n, seed, xy):
@@ -142,13 +189,122 @@ def valu_roofline(n, R, seed, first, info, k_ms, clock_hz, work, cand_per_launch
     return r
 
 
+METRIC = "2-opt candidate swaps evaluated/sec + final tour cost, TSPLIB EUC_2D n=10000"
+
+
+def gather_rank_ms(ms_local, device, dist):
+    """every rank's own ms_per_step, in rank order (the headline ms_per_step is their maximum)."""
+    t = torch.tensor([float(ms_local)], dtype=torch.float64, device=device)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(t.item())]
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
+def dry_launch(a, rank, world):
+    """The N-rank plumbing without a GPU: gloo process group, the same sharding, key packing, min-all-reduce, tour hand-round
+    and whole-job aggregation as a real run, around a STUB step (deterministic fake costs; no kernel, no oracle).  What it
+    proves is the launch path and the rank count — the printed line carries value null and "dry_launch": true."""
+    import torch.distributed as dist
+    from teeline_amd.host import multistart as ms
+    dev = torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = dist.get_world_size() if world > 1 else 1
+    if seen != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the process group has {seen} ranks")
+    n, R = 64, 4
+    first, R = ms.shard_total(rank, world, a.restarts_total) if a.restarts_total > 0 else ms.shard(rank, R)
+    ids = torch.arange(first, first + R, dtype=torch.int64)
+    costs = (((ids * 3 + 1) % 8) + ids // 8).to(torch.float32) + 1.0       # stub: a fixed cost per restart id (restart 5 wins)
+    tours = torch.stack([torch.roll(torch.arange(n, dtype=torch.int32), int(r)) for r in ids.tolist()])
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        keys = ms.pack_keys(costs, first)
+        best = ms.allreduce_best(keys, dist if world > 1 else None)
+        tour = ms.share_best_tour(keys, tours, best, dist if world > 1 else None)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    total, dt_max = ms.aggregate_throughput(R * a.steps, dt, dev, dist if world > 1 else None)
+    per_rank = gather_rank_ms(dt / max(a.steps, 1) * 1e3, dev, dist if world > 1 else None)
+    cost, restart = ms.unpack_key(best.item())
+    ok = tour.tolist() == torch.roll(torch.arange(n, dtype=torch.int32), int(restart)).tolist()
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("bench.py --dry-launch: the shared tour is not the winner's")
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "candidates/s", "n_gpus": world, "ranks_seen": seen,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt_max / max(a.steps, 1) * 1e3,
+                          "ms_per_step_per_rank": per_rank, "higher_is_better": True, "dry_launch": True,
+                          "scaling": "strong" if a.restarts_total > 0 else "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "stub", "config": {"workload": "dry launch: gloo ranks, stub step (no GPU, no kernel, no oracle) — not a measurement"},
+                          "stub_units_all_ranks": total, "best_restart": restart, "launcher": "torch.distributed.run" if world > 1 else "none"}))
+
+
+def single_process(a):
+    """--single-process: ONE process, one tl_ctx per device, the restarts dealt over them by tl_two_opt_multistart_devices
+    (no RCCL: the minimum of N packed keys is taken on the host inside the library).  The cross-check of the RCCL number and
+    the fallback where no launcher is available.  The entry takes host buffers (80 KB of coordinates up, costs / counters and the
+    winner's tour down per call), so this rate includes that PCIe traffic."""
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libteeline_gpu has no CPU fallback")
+    if torch.cuda.device_count() < a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but {torch.cuda.device_count()} device(s) visible")
+    import teeline_amd as TA
+    n = a.n
+    xy = TA.synth.synth_xy(n)
+    prob = TA.TspProblem(np.arange(n), xy)
+    ctxs = [TA.Context(d) for d in range(a.gpus)]
+    strong = a.restarts_total > 0
+    count = a.restarts_total if strong else a.restarts * a.gpus
+    per_sweep = (n - 3) * (n - 2) // 2
+    for _ in range(max(a.warmup, 0)):
+        TA.two_opt.multistart_devices(prob, count, ctxs, seed=a.seed)
+    cands, kms = 0, []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        sol = TA.two_opt.multistart_devices(prob, count, ctxs, seed=a.seed)
+        cands += sol.stats["sweeps"] * per_sweep
+        kms.append(sol.stats["kernel_ms"])
+    dt = time.perf_counter() - t0
+    info = ctxs[0].device_info()
+    print(json.dumps({
+        "metric": METRIC, "value": cands / dt, "unit": "candidates/s", "n_gpus": a.gpus, "ranks_seen": 1, "devices_driven": a.gpus,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[3]: synthetic EUC_2D n={n}, multi-start REF_ORDER 2-opt, {count} seeded random restarts dealt over "
+                               f"{a.gpus} device(s) by ONE process (tl_two_opt_multistart_devices, no collective: host min of {a.gpus} keys)",
+                   "n": n, "restarts_total": count, "mode": "REF_ORDER", "restart_seed": a.seed, "launcher": "single-process"},
+        "final_tour_cost": float(sol.total), "best_restart": sol.stats["best_restart"],
+        "slowest_shard_kernel_ms": float(np.mean(kms)), "device": info,
+        "note": "host-buffer entry: the rate includes the per-call PCIe traffic (coordinates up; costs, counters and the winner's tour down)",
+        "roofline": None, "cpu_baseline": None}))
+    for c in ctxs:
+        c.close()
+
+
 def main():
     a = parse()
+    launched = "WORLD_SIZE" in os.environ
+    if a.gpus > 1 and not launched and not a.single_process:
+        # started bare: be the launcher (before any torch.cuda / teeline_amd call in this process)
+        raise SystemExit(self_launch(a))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.single_process:
+        if world > 1:
+            raise SystemExit("--single-process under a multi-rank launcher")
+        return single_process(a)
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {a.gpus} GPUs")
+    if a.dry_launch:
+        return dry_launch(a, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libteeline_gpu has no CPU fallback")
     torch.cuda.set_device(local)
@@ -251,6 +407,10 @@ def main():
     clock_hz = float(np.mean(st_host[:, 9].astype(np.float64) / np.maximum(ticks, 1.0))) * REFCLK_HZ if ticks.min() > 0 else 0.0
 
     total, dt_max = TA.multistart.aggregate_throughput(cands, dt, dev, dist)
+    ranks_seen = dist.get_world_size() if dist is not None else 1
+    if ranks_seen != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the process group has {ranks_seen} ranks")
+    per_rank_ms = gather_rank_ms(dt / a.steps * 1e3, dev, dist)
     best_cost, best_restart = TA.multistart.unpack_key(key.item())
 
     if rank != 0:
@@ -264,11 +424,12 @@ def main():
     k_ms = float(np.mean(kernel_ms))
     cand_per_launch = cands / a.steps
     out = {
-        "metric": "2-opt candidate swaps evaluated/sec + final tour cost, TSPLIB EUC_2D n=10000",
+        "metric": METRIC,
         "value": total / dt_max,
         "unit": "candidates/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": dt_max / a.steps * 1e3,
+        "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt_max / a.steps * 1e3, "ms_per_step_per_rank": per_rank_ms,
+        "launcher": "torch.distributed.run" if "WORLD_SIZE" in os.environ else "none",
         "higher_is_better": True,
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None,

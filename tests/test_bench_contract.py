@@ -55,5 +55,33 @@ def test_roofline_is_rederivable_from_the_committed_counters():
 def test_bench_flags_parse():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0
-    for flag in ("--gpus", "--steps", "--warmup", "--restarts", "--restarts-total"):
+    for flag in ("--gpus", "--steps", "--warmup", "--restarts", "--restarts-total", "--single-process", "--dry-launch"):
         assert flag in out.stdout
+
+
+def _bare_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return env
+
+
+def test_bare_gpus_2_starts_two_ranks_itself():
+    # `bench.py --gpus N` without an external launcher used to run ONE rank and print n_gpus 1.  Now the bare
+    # call is the launcher: two gloo ranks (stub step, no GPU, no oracle), rank 0's line relayed, ranks_seen == 2.
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch", "--steps", "2"],
+                         capture_output=True, text=True, timeout=300, env=_bare_env())
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and len(line["ms_per_step_per_rank"]) == 2
+    assert line["dry_launch"] is True and line["value"] is None          # a rehearsal never carries a number
+    assert line["best_restart"] == 5                                      # the stub's winner lives on rank 1: its tour crossed ranks
+    assert line["launcher"] == "torch.distributed.run"
+
+
+def test_rank_count_mismatch_is_an_error_not_a_one_gpu_run():
+    env = _bare_env()
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode != 0 and "refusing" in (out.stderr + out.stdout)
