@@ -61,6 +61,9 @@ def parse():
                     help="skip the one untimed launch of the counting kernel variant (PMC passes: only the timed kernel runs)")
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1 without RCCL: one process, one tl_ctx per device, tl_two_opt_multistart_devices")
+    ap.add_argument("--force-launcher", action="store_true",
+                    help="take the self-launch path even for --gpus 1 (one rank under torch.distributed.run, RCCL initialised): "
+                         "the rehearsal of that path on a one-GPU box")
     ap.add_argument("--dry-launch", action="store_true",
                     help="CPU rehearsal of the N-rank launch and the collectives (gloo, stub step): prints a line with value null")
     return ap.parse_args()
@@ -82,6 +85,8 @@ def self_launch(a):
     import subprocess
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if a.gpus == 1:
+        env["TL_BENCH_FORCE_DIST"] = "1"   # --force-launcher: one rank, but through the process group and RCCL all the same
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
@@ -291,7 +296,7 @@ def single_process(a):
 def main():
     a = parse()
     launched = "WORLD_SIZE" in os.environ
-    if a.gpus > 1 and not launched and not a.single_process:
+    if (a.gpus > 1 or a.force_launcher) and not launched and not a.single_process:
         # started bare: be the launcher (before any torch.cuda / teeline_amd call in this process)
         raise SystemExit(self_launch(a))
     rank = int(os.environ.get("RANK", "0"))

@@ -22,3 +22,8 @@ print("sweeps histogram:", {int(k): int((sw == k).sum()) for k in np.unique(sw)}
 print(f"cycles per sweep: {np.mean(cyc / sw)/1e6:.2f} M; corr(cycles, sweeps) = {np.corrcoef(cyc, sw)[0,1]:.3f}; steps mean {steps.mean():.0f}; moves mean {mv.mean():.0f}")
 order = np.argsort(-cyc)[:5]
 print("slowest:", [(int(r), int(sw[r]), round(cyc[r] / 1e6, 1)) for r in order])
+if st[:, 13].max() > 0:  # role-split kernel diagnostics
+    nd, npr, nfd = st[:, 13], st[:, 14], st[:, 15]
+    print(f"descriptors mean {nd.mean():.0f} max {nd.max()}; pruned steps mean {npr.mean():.0f}; dense steps mean {(steps - npr).mean():.0f}; flush-at-descriptor mean {nfd.mean():.1f}")
+    for r in list(order) + list(np.argsort(cyc)[:3]):
+        print(f"  restart {int(r)}: {cyc[r]/1e6:.1f} M cycles, sweeps {int(sw[r])}, steps {int(steps[r])} (pruned {int(npr[r])}), descriptors {int(nd[r])}, moves {int(mv[r])}")

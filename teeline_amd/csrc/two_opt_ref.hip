@@ -59,11 +59,15 @@ constexpr int kMaxGroups = 4;         // 64-tile groups: n_pad <= 4 * 64 * 64 = 
 
 struct Ctl {                     // kCtlBytes of LDS
     uint32_t keys[4];
+    uint32_t desc[4];           // the descriptor the control wave publishes before barrier B0 (sweep start / exit / block shape)
     unsigned long long cnt[6];  // cascade work of the descent (TileCounts summed over the waves; counting instantiation)
     unsigned long long clk0, rt0;  // s_memtime / s_memrealtime at the start of the descent (kept here, not in SGPRs)
     uint32_t bad_init;
+    uint32_t req[2];            // the control wave asks for its descriptor (block-shape change), by step parity
+    uint32_t pad_[5];
+    uint32_t pend[64];          // deferred hit columns of the current dense row (lane m of a flush reads hit m)
 };
-constexpr size_t kCtlBytes = 128;
+constexpr size_t kCtlBytes = 384;
 static_assert(sizeof(Ctl) <= kCtlBytes, "Ctl block");
 
 // Deferred reversals (dense mode).  The hits (i, g_0 < g_1 < ... < g_{k-1}) of ONE row all reverse a prefix that starts at
@@ -159,6 +163,169 @@ __device__ __forceinline__ uint32_t flush_deferred(const PT &P, uint16_t *perm, 
     }
     TL_SYNC();
     return have ? g - (lo - 1u) : 0u;
+}
+
+// two_opt.rs:50,69-79  swap_2opt(path, lo, hi): in-place reversal by the whole workgroup, two pairs per thread in flight.
+// The caller puts a barrier behind it.
+template <int NT, typename PT>
+__device__ __forceinline__ void reverse_segment(const PT &P, uint16_t *perm, uint32_t lo, uint32_t hi, int tid)
+{
+    const uint32_t half = (hi - lo + 1u) >> 1;
+    for (uint32_t t = (uint32_t)tid; t < half; t += 2 * NT) {
+        const uint32_t t2 = t + NT;
+        const bool two = t2 < half;
+        const auto x = pt_raw(P, lo + t), y = pt_raw(P, hi - t);
+        const uint16_t u = perm[lo + t], v = perm[hi - t];
+        uint16_t u2 = u, v2 = v;
+        auto x2 = x, y2 = y;
+        if (two) {
+            x2 = pt_raw(P, lo + t2);
+            y2 = pt_raw(P, hi - t2);
+            u2 = perm[lo + t2];
+            v2 = perm[hi - t2];
+        }
+        pt_put(P, lo + t, y);
+        pt_put(P, hi - t, x);
+        perm[lo + t] = v;
+        perm[hi - t] = u;
+        if (two) {
+            pt_put(P, lo + t2, y2);
+            pt_put(P, hi - t2, x2);
+            perm[lo + t2] = v2;
+            perm[hi - t2] = u2;
+        }
+    }
+}
+
+// a = P[i], b = P[bidx] of a dense row as wave-uniform values, sq(a, b) with them
+template <typename PT>
+__device__ __forceinline__ void load_row_ab(const PT &P, uint32_t i, uint32_t bidx, int lane, float &ax, float &ay, float &bx, float &by, float &sqab)
+{
+    const float2 ab = pt_get(P, lane == 0 ? i : bidx);
+    ax = readlane_f(ab.x, 0);
+    ay = readlane_f(ab.y, 0);
+    bx = readlane_f(ab.x, 1);
+    by = readlane_f(ab.y, 1);
+    sqab = sqdist(make_float2(ax, ay), make_float2(bx, by));
+}
+
+// ---- role-split kernel: the scan cursor every wave carries, the accounting only the control wave keeps, and the step boundary
+struct Cursor {
+    uint32_t i0, j0;              // where the reference's loop stands: row, resume column
+    uint32_t np;                  // dense mode: hits of row i0 whose reversals are deferred (columns in ctl->pend)
+    uint32_t slot, par;           // step % 3 (key slot), step & 1 (hit lists, request word)
+    uint32_t dirty_lo, dirty_hi;  // tiles whose L0 metadata is stale
+    bool pruned;                  // block shape
+};
+struct Acct {
+    uint64_t moves, reversed, rev_lane;  // rev_lane: per-lane share of `reversed` from the flushes (summed over lanes at the end)
+    float gap_est, since;                // candidates between moves (block-shape heuristic only)
+    bool improved;
+};
+
+// The deferred reversals of row c.i0, composed (flush_deferred), by every wave.  `sync_first`: the hits were filed in this very
+// boundary (by their owner, behind B2), so a barrier comes before they are read.
+template <bool CONTROL, int NT, int SLOTS, typename PT>
+__device__ __forceinline__ void flush_pending(Cursor &c, Acct &a, const PT &P, uint16_t *perm, Ctl *ctl, int lane, int wave, bool sync_first)
+{
+    if (sync_first) TL_SYNC();
+    uint32_t g = ctl->pend[lane];
+    g = (uint32_t)lane < c.np ? g : 0xFFFFFFFFu;
+    const uint32_t ghi = readlane_u(g, c.np - 1u);
+    const uint32_t r = flush_deferred<NT, SLOTS>(P, perm, g, c.i0 + 1u, c.np, lane, wave);
+    if (CONTROL) a.rev_lane += r;
+    const uint32_t t0 = c.i0 >> 6, t1 = ghi >> 6;  // L0 metadata of tiles with a changed position or tour-edge
+    c.dirty_lo = t0 < c.dirty_lo ? t0 : c.dirty_lo;
+    c.dirty_hi = t1 > c.dirty_hi ? t1 : c.dirty_hi;
+    c.np = 0;
+}
+
+// End of a step, behind barrier B2: every wave reads the same words and advances its cursor the same way (the control wave adds
+// its accounting).  R: rows of the block just scanned.  my_hits: the hit columns this wave chained in the step (lane h = h-th
+// hit), filed in ctl->pend if they are the step's.  Returns true where the control wave's descriptor comes next (sweep ended, or
+// it asked for another block shape).
+template <bool CONTROL, int NT, int SLOTS, typename PT>
+__device__ __forceinline__ bool step_boundary(Cursor &c, Acct &a, const PT &P, uint16_t *perm, Ctl *ctl, const uint32_t *queues, uint32_t n, uint32_t nrows,
+                                              uint32_t R, int lane, int wave, int tid, uint32_t my_hits, float &bx, float &by, bool &reload)
+{
+    const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->keys[c.slot]);
+    const uint32_t req = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->req[c.par]);
+    const float rowlen = (float)(n - 2u - c.i0);
+    reload = false;
+    if (!c.pruned) {
+        if (key == kNoKey) {  // row i0 is finished: its reversals are due, composed
+            if (CONTROL) a.since += rowlen;
+            if (c.np) flush_pending<CONTROL, NT, SLOTS>(c, a, P, perm, ctl, lane, wave, false);
+            c.i0 += 1u;
+            c.j0 = c.i0 + 2u;
+            reload = true;
+        } else {
+            // the wave owning the first hit chained every improving move inside its tile (dense_tile).  Nothing of the row's
+            // remaining scan reads [i+1..hit], so the reversals wait in ctl->pend until the row ends (flush_deferred); the scan
+            // goes on at `resume` with b = the old p[hit].
+            const uint4 hv = *reinterpret_cast<const uint4 *>(queues + ((key & 0xFFFFu) * 2u + c.par) * kQCap);
+            const uint32_t nh = (uint32_t)__builtin_amdgcn_readfirstlane((int)hv.x);
+            const uint32_t resume = (uint32_t)__builtin_amdgcn_readfirstlane((int)hv.y);
+            if (!CONTROL && (key & 0xFFFFu) == (uint32_t)wave && (uint32_t)lane < nh) ctl->pend[c.np + (uint32_t)lane] = my_hits;
+            if (CONTROL) {
+                a.moves += nh;
+                // gap estimate: the first hit exactly, chained hits as evenly spaced
+                a.since += (float)((key >> 16) - c.j0);
+                a.gap_est = 0.5f * (a.gap_est + a.since);
+                a.since = 0.0f;
+                if (nh > 1u) a.gap_est = fminf(a.gap_est, 0.5f * a.gap_est + 16.0f);  // chained hits are < 64 columns apart
+                a.improved = true;
+            }
+            c.np += nh;
+            c.j0 = resume;
+            if (c.j0 > n - 2u) {  // the row's last column is behind us
+                flush_pending<CONTROL, NT, SLOTS>(c, a, P, perm, ctl, lane, wave, true);
+                c.i0 += 1u;
+                c.j0 = c.i0 + 2u;
+                reload = true;
+            } else if (c.np + kMaxChainHits > kPendMax) {  // the hit register is nearly full
+                flush_pending<CONTROL, NT, SLOTS>(c, a, P, perm, ctl, lane, wave, true);
+                reload = true;
+            } else {
+                bx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((int)hv.z));
+                by = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((int)hv.w));
+            }
+        }
+    } else if (key == kNoKey) {
+        if (CONTROL) a.since += (float)R * rowlen;
+        c.i0 += R;
+        c.j0 = c.i0 + 2u;
+    } else {
+        // pruned mode: one hit, applied at once by every wave (moves are rare here)
+        const uint32_t is = key >> 16, js = key & 0xFFFFu;
+        reverse_segment<NT>(P, perm, is + 1u, js, tid);  // two_opt.rs:50,69-79  swap_2opt(path, i+1, j)
+        TL_SYNC();
+        if (CONTROL) {
+            a.since += (float)(is - c.i0) * rowlen;
+            a.moves += 1u;
+            a.reversed += (uint64_t)(js - is);
+            // For a hit in a later row of the block js - j0 wraps to a huge value: the estimate then keeps the pruned block
+            // shape for a dozen moves, which measured faster than the "correct" gap (126 vs 137 ms per 256 restarts) — except
+            // in the one step a requested change to the dense shape lags behind: there the true gap is taken, or that step's hit
+            // would undo the request.
+            a.since += (req != 0u && is > c.i0) ? (float)(js - (is + 2u)) : (float)(js - c.j0);
+            a.gap_est = 0.5f * (a.gap_est + a.since);
+            a.since = 0.0f;
+            a.improved = true;
+        }
+        const uint32_t t0 = is >> 6, t1 = js >> 6;  // L0 metadata of every tile that saw a changed position or tour-edge
+        c.dirty_lo = t0 < c.dirty_lo ? t0 : c.dirty_lo;
+        c.dirty_hi = t1 > c.dirty_hi ? t1 : c.dirty_hi;
+        c.i0 = is;
+        c.j0 = js + 1u;
+        if (c.j0 > n - 2u) {
+            c.i0 += 1u;
+            c.j0 = c.i0 + 2u;
+        }
+    }
+    c.slot = c.slot == 2u ? 0u : c.slot + 1u;
+    c.par ^= 1u;
+    return c.i0 >= nrows || req != 0u;
 }
 
 }  // namespace
@@ -280,14 +447,16 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     // ---------------------------------------------------------------- descent
     const uint32_t nrows = n - 3;  // rows i in [0, n-3); j in [i+2, n-2]
     const uint32_t last_tile = n >= 2 ? (n - 2u) >> 6 : 0u;
-    uint32_t i0 = 0, j0 = 2;
-    bool improved = false;
     uint32_t sweeps = 1, step = 0, status = 0;
     uint64_t moves = 0, reversed = 0;
+    uint64_t rev_lane = 0;        // per-lane share of `reversed` from the flushes (summed over lanes at the end)
+    typename std::conditional<COUNT, TileCounts, NoCounts>::type tc;  // work really done by this wave's cascade (SALU counters)
+#ifdef TL_TWO_OPT_CLASSIC
+    uint32_t i0 = 0, j0 = 2;
+    bool improved = false;
     uint32_t np = 0, hlast = 0, prow = 0;  // dense mode: np hits of row `prow` whose reversals are deferred; the last one
     uint32_t pendv = 0xFFFFFFFFu;          // ... lane m < np of every wave holds hit column g_m
     bool flush_due = false;                // row `prow` is finished (or the hit register is nearly full)
-    uint64_t rev_lane = 0;        // per-lane share of `reversed` from the flushes (summed over lanes at the end)
     float gap_est = 0.0f, since = 0.0f;
     uint32_t dirty_lo = 0xFFFFFFFFu, dirty_hi = 0;               // tiles whose L0 metadata is stale
 #ifdef TL_PROFILE
@@ -301,7 +470,6 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #ifdef TL_PROFILE2
     uint64_t q2[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    typename std::conditional<COUNT, TileCounts, NoCounts>::type tc;  // work really done by this wave's cascade (SALU counters)
     uint32_t slot = 0;  // step % 3
     while (n >= 4) {
 #ifdef TL_PROFILE2
@@ -579,6 +747,264 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         slot = slot_next;
     }
 
+#else
+
+    // Role split.  The reference's loop is a chain of ~35 k steps per descent (n = 10^4, random start), and what a step costs is not
+    // only its scan but the instructions EVERY wave executes around it: four waves share a SIMD's issue port, so an instruction
+    // all 16 waves run costs 16 cycles per step and a dependent instruction of a lone wave 8 (tests/probes/step_sync_probe.hip;
+    // an s_barrier of 16 waves: 21).  So the descent's ACCOUNTING — move / reversal / sweep counters, the gap estimate behind the
+    // block shape, the sweep-end and exit decisions — lives in ONE wave (wave 0, "control"), which does not scan, and the other
+    // waves ("workers") carry only the cursor a scan needs: (i0, j0, pending hits, block shape, key slot).
+    //  * Every wave advances that cursor by itself at a step's end (step_boundary): it is a function of words all waves read
+    //    behind the same barrier — the step's key, the owner's hit list (count, resume column, the row's new b), the control
+    //    wave's request word — so the workers go from step to step without waiting for anybody; the control wave runs the
+    //    same function (it must meet every barrier) and does its accounting beside the workers' next scan.
+    //  * The control wave steps in — an 8-byte descriptor (op | pruned << 2, i0 | j0 << 16) before barrier B0 — only where a
+    //    decision is its own: a sweep has ended (next sweep or exit) or the block shape should change (requested through
+    //    req[parity] one boundary ahead: either shape gives the same results, so the request may lag).
+    //  * Barriers per step, met by every wave:  (B0 | flush: 2) | dense: B1 (lead round / rest), B2 | pruned: (tile
+    //    metadata: 1), B2 | boundary: (flush behind a hit step: 1 + 2; flush: 2; pruned hit: 1).
+    // Dense keys are (column << 16) | posting wave (the row is implied; the tag finds the owner's hit list), pruned keys
+    // (row << 16) | column.  Key slots rotate with step % 3 — the control wave resets the next step's slot before B2 — and
+    // every wave has two hit lists, used by the step's parity (a list is read after B2 while its owner may already write the
+    // next step's).  The owner of a step's hits files them in ctl->pend itself (it still holds them in a register).
+    enum : uint32_t { OP_GO = 0u, OP_EXIT = 2u };
+    constexpr int NWK = NW - 1;                                  // workers
+    constexpr uint32_t kLead = kDenseLead < (uint32_t)NWK ? kDenseLead : (uint32_t)NWK;
+    static_assert(4u <= kQCap, "a hit list fits its slot");
+    if (n >= 4 && wave == 0) {
+        // ------------------------------------------------------------ control wave
+        Cursor c{0u, 2u, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, false};
+        Acct acct{0ull, 0ull, 0ull, 0.0f, 0.0f, false};
+        bool need_desc = true;
+        uint32_t n_desc = 0, n_pruned_steps = 0, n_flush_desc = 0;  // diagnostics (stats words 13..15)
+#ifdef TL_PROFILE2
+        uint64_t q2[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t t_it = __builtin_amdgcn_s_memtime();
+#endif
+        for (;;) {
+            if (need_desc) {
+                ++n_desc;
+                n_flush_desc += c.np ? 1u : 0u;
+                bool done = false;
+                if (c.i0 >= nrows) {  // sweep finished (two_opt.rs:26-28)
+                    if (!acct.improved) {
+                        done = true;
+                    } else if (sweeps >= A.max_sweeps) {
+                        status = 1;
+                        done = true;
+                    } else {
+                        acct.improved = false;
+                        ++sweeps;
+                        c.i0 = 0;
+                        c.j0 = 2;
+                    }
+                }
+                // block shape: dense (moves every few rows: one row, every tile) or pruned (up to kRMax rows, L0)
+                c.pruned = PRUNE && !done && fmaxf(acct.gap_est, acct.since) > TL_DENSE_ROWS * (float)(n - 2u - c.i0);
+                if (lane == 0)
+                    *reinterpret_cast<uint2 *>(ctl->desc) = make_uint2((done ? OP_EXIT : OP_GO) | (c.pruned ? 4u : 0u), c.i0 | (c.j0 << 16));
+                TL_SYNC();  // B0
+                if (lane == 0) {  // behind B0: a slow worker may have been reading its request word until it got here
+                    ctl->req[0] = 0u;
+                    ctl->req[1] = 0u;
+                }
+                if (c.np) flush_pending<true, NT, kSlots>(c, acct, P, perm, ctl, lane, wave, false);
+                if (done) break;
+            }
+            const uint32_t slot_next = c.slot == 2u ? 0u : c.slot + 1u;
+            if (lane == 0) ctl->keys[slot_next] = kNoKey;  // slot of the next step (its last readers are two barriers behind)
+            ++step;
+            n_pruned_steps += c.pruned ? 1u : 0u;
+            const uint32_t R = c.pruned ? ((uint32_t)kRMax < nrows - c.i0 ? (uint32_t)kRMax : nrows - c.i0) : 1u;
+            if (c.pruned) {
+                if (c.dirty_lo <= c.dirty_hi) {
+                    c.dirty_lo = 0xFFFFFFFFu;
+                    c.dirty_hi = 0;
+                    TL_SYNC();  // the workers rebuild the stale tile boxes
+                }
+            } else {
+                TL_SYNC();  // B1: lead round
+            }
+            TL_SYNC();  // B2
+#ifdef TL_PROFILE2
+            const bool was_pruned = c.pruned;
+            const uint64_t moves_before = acct.moves;
+#endif
+            float bx_ = 0.f, by_ = 0.f;
+            bool reload_ = false;
+            need_desc = step_boundary<true, NT, kSlots>(c, acct, P, perm, ctl, queues, n, nrows, R, lane, wave, tid, 0u, bx_, by_, reload_);
+            // the block shape the gap estimate asks for; a change is requested for the next boundary
+            if (PRUNE && c.i0 < nrows) {
+                const bool want = fmaxf(acct.gap_est, acct.since) > TL_DENSE_ROWS * (float)(n - 2u - c.i0);
+                if (lane == 0) ctl->req[c.par] = want != c.pruned ? 1u : 0u;
+            }
+#ifdef TL_PROFILE2
+            {
+                const uint64_t t2 = __builtin_amdgcn_s_memtime();
+                const int b = (was_pruned ? 0 : 6) + (acct.moves == moves_before ? 3 : 0);
+                q2[b] += 1;
+                q2[b + 1] += t2 - t_it;
+                t_it = t2;
+            }
+#endif
+        }
+        moves = acct.moves;
+        reversed = acct.reversed;
+        rev_lane = acct.rev_lane;
+#if !defined(TL_PROFILE2) && !defined(TL_PROFILE3)
+        if (tid == 0) {
+            uint64_t *st = A.out_stats + (size_t)d * TL_STATS_STRIDE;
+            st[13] = n_desc;          // descriptors published (sweep ends + block-shape changes)
+            st[14] = n_pruned_steps;  // steps in pruned shape
+            st[15] = n_flush_desc;    // descriptors that forced a flush
+        }
+#endif
+#ifdef TL_PROFILE2
+        if (tid == 0) {
+            uint64_t *st = A.out_stats + (size_t)d * TL_STATS_STRIDE;
+            st[5] = q2[0]; st[6] = q2[1]; st[7] = q2[2]; st[8] = q2[3]; st[9] = q2[4]; st[10] = q2[5];
+            st[11] = q2[6]; st[12] = q2[7]; st[13] = q2[9]; st[14] = q2[10]; st[15] = q2[12];
+        }
+#endif
+    } else if (n >= 4) {
+        // ------------------------------------------------------------ worker waves
+        const int wk = wave - 1;
+#ifdef TL_PROFILE3
+        uint64_t q3[6] = {0, 0, 0, 0, 0, 0};  // dense steps of this wave: boundary, lead tile, B1 wait, round 2, B2 wait, steps
+        uint64_t t3 = __builtin_amdgcn_s_memtime();
+#define TL_STAMP3(k) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); q3[k] += t_ - t3; t3 = t_; } while (0)
+#else
+#define TL_STAMP3(k) do { } while (0)
+#endif
+        Cursor c{0u, 2u, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, false};
+        Acct acct{0ull, 0ull, 0ull, 0.0f, 0.0f, false};  // unused by a worker
+        bool need_desc = true, reload = true;
+        float ax = 0.f, ay = 0.f, bx = 0.f, by = 0.f;
+        for (;;) {
+            if (need_desc) {
+                TL_SYNC();  // B0
+                const uint2 dv = *reinterpret_cast<const uint2 *>(ctl->desc);
+                const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dv.x), w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dv.y);
+                if (c.np) flush_pending<false, NT, kSlots>(c, acct, P, perm, ctl, lane, wave, false);
+                if ((w0 & 3u) == OP_EXIT) break;
+                c.pruned = (w0 & 4u) != 0u;
+                c.i0 = w1 & 0xFFFFu;
+                c.j0 = w1 >> 16;
+                reload = true;
+            }
+            uint32_t *keyslot = &ctl->keys[c.slot];
+            uint32_t my_hits = 0;
+            const uint32_t R = c.pruned ? ((uint32_t)kRMax < nrows - c.i0 ? (uint32_t)kRMax : nrows - c.i0) : 1u;
+            if (!c.pruned) {
+                // ---- dense step: one row, every tile from the resume column on.  Lead round: kLead waves (one per SIMD) look at
+                // the first tiles, everybody else parks at B1 — moves come every few candidates here, and a wave chaining hits
+                // runs ~3x faster when it does not share its SIMD's issue slots with busy neighbours.  Then (no hit yet) all
+                // workers take the rest of the row.  a = p[i]; b = p[i+1], or after a step with hits the old p[g_last]
+                // (two_opt.rs:50), which the owner of the hits left in its list.
+                if (reload) {
+                    const float2 ab = pt_get(P, c.i0 + (lane == 0 ? 0u : 1u));
+                    ax = readlane_f(ab.x, 0);
+                    ay = readlane_f(ab.y, 0);
+                    bx = readlane_f(ab.x, 1);
+                    by = readlane_f(ab.y, 1);
+                }
+                const float sqab = sqdist(make_float2(ax, ay), make_float2(bx, by));
+                uint32_t *hl_mine = queues + ((uint32_t)wave * 2u + c.par) * kQCap;
+                const uint32_t t0 = c.j0 >> 6;
+                TL_STAMP3(0);
+                if ((uint32_t)wk < kLead && t0 + (uint32_t)wk <= last_tile)
+                    dense_tile<PRUNE, true>(P, n, (uint32_t)wave, (t0 + (uint32_t)wk) << 6, c.j0, ax, ay, bx, by, sqab, hl_mine, keyslot, lane, tc, &my_hits);
+                TL_STAMP3(1);
+                TL_SYNC();  // B1
+                TL_STAMP3(2);
+                // A wave stops only at a hit in a column BEFORE its tile (a lead-round hit stops everybody at once).  A hit that
+                // another wave has just posted further right must not stop it: this tile may hold an earlier one.
+                for (uint32_t t = t0 + kLead + (uint32_t)wk; t <= last_tile; t += (uint32_t)NWK) {
+                    const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot);
+                    if ((kb >> 16) < (t << 6)) break;  // an earlier column already improves (kNoKey reads as column 65535)
+                    if (dense_tile<PRUNE, true>(P, n, (uint32_t)wave, t << 6, c.j0, ax, ay, bx, by, sqab, hl_mine, keyslot, lane, tc, &my_hits)) break;
+                }
+                TL_STAMP3(3);
+            } else {
+                // ---- pruned step: worker w owns rows w, w+NWK, ... of the block.  L0 (lanes = tiles) yields the live-tile
+                // mask of the row in SGPRs, L1 (lanes = j) runs on those tiles right away — no exchange between waves,
+                // and every row has its diagonal tile live, so the rows are naturally balanced.
+                if (c.dirty_lo <= c.dirty_hi) {  // L0 metadata is rebuilt lazily: only tiles touched by reversals since the last pruned step
+                    for (uint32_t t = c.dirty_lo + (uint32_t)wk; t <= c.dirty_hi; t += (uint32_t)NWK) build_tile_meta(P, n, t, lane, tbox, tmsq);
+                    c.dirty_lo = 0xFFFFFFFFu;
+                    c.dirty_hi = 0;
+                    TL_SYNC();
+                }
+                // lane-resident row table: lane l holds P[i0+l] and sq(P[i0+l], P[i0+l+1])
+                const uint32_t i0 = c.i0, j0 = c.j0;
+                const float2 rp = pt_get(P, i0 + (uint32_t)lane);
+                const float2 rq = pt_get(P, i0 + (uint32_t)lane + 1u);
+                const float rowsq = sqdist(rp, rq);
+                float4 box[kMaxGroups];
+                float msq[kMaxGroups];
+#pragma unroll
+                for (int gI = 0; gI < kMaxGroups; ++gI) {
+                    if (gI < G) {
+                        box[gI] = tbox[((uint32_t)gI << 6) + (uint32_t)lane];
+                        msq[gI] = tmsq[((uint32_t)gI << 6) + (uint32_t)lane];
+                    }
+                }
+                for (int r = wk; r < (int)R; r += NWK) {
+                    const uint32_t i = i0 + (uint32_t)r;
+                    if (r >= NWK) {  // a hit in an earlier row makes this one moot
+                        const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot);
+                        if (kb != kNoKey && (kb >> 16) < i) break;
+                    }
+                    const float rax = readlane_f(rp.x, r), ray = readlane_f(rp.y, r);
+                    const float rbx = readlane_f(rp.x, r + 1), rby = readlane_f(rp.y, r + 1);
+                    const float rsqab = readlane_f(rowsq, r);
+                    const uint32_t jmin = (r == 0) ? j0 : (i + 2u);
+                    const uint32_t tmin = jmin >> 6;
+                    bool row_hit = false;
+                    tc.prow += 1u;
+#pragma unroll
+                    for (int gI = 0; gI < kMaxGroups; ++gI) {
+                        if (gI < G && (((uint32_t)gI + 1u) << 6) > tmin) {  // groups wholly before the row's first column: nothing to test
+                            const uint32_t tl = ((uint32_t)gI << 6) + (uint32_t)lane;
+                            const bool near_a = box_lb(rax, ray, box[gI]) < rsqab, near_b = box_lb(rbx, rby, box[gI]) < msq[gI];
+                            const bool live = (tl >= tmin) & (near_a | near_b);  // no short-circuit: both bounds are cheaper than a branch
+                            tc.l0 += 64u;
+                            uint64_t m = __builtin_amdgcn_ballot_w64(live);
+                            uint64_t hm = 0;
+                            uint32_t t = 0;
+                            while (m != 0 && hm == 0) {  // later tiles of this row are later columns
+                                t = ((uint32_t)gI << 6) + (uint32_t)(__builtin_ffsll((long long)m) - 1);
+                                m &= m - 1;
+                                tc.ptile += 1u;
+                                hm = tile_improving_mask<PRUNE>(P, n, t << 6, jmin, rax, ray, rbx, rby, rsqab, lane, tc);
+                            }
+                            if (hm) {
+                                if (lane == 0) atomicMin(keyslot, (i << 16) | ((t << 6) + (uint32_t)(__builtin_ffsll((long long)hm) - 1)));
+                                row_hit = true;
+                            }
+                        }
+                        if (row_hit) break;
+                    }
+                    if (row_hit) break;  // rows w+NWK, ... are later rows
+                }
+            }
+            TL_SYNC();  // B2
+            TL_STAMP3(4);
+#ifdef TL_PROFILE3
+            q3[5] += c.pruned ? 0 : 1;
+#endif
+            need_desc = step_boundary<false, NT, kSlots>(c, acct, P, perm, ctl, queues, n, nrows, R, lane, wave, tid, my_hits, bx, by, reload);
+        }
+#ifdef TL_PROFILE3
+        if (lane == 0 && (wave == 1 || wave == 6)) {  // a lead wave and a non-lead one
+            uint64_t *st = A.out_stats + (size_t)d * TL_STATS_STRIDE + (wave == 1 ? 5 : 11);
+            for (int q = 0; q < (wave == 1 ? 6 : 5); ++q) st[q] = q3[q];
+        }
+#endif
+    }
+#endif
+
     // ---------------------------------------------------------------- results
     uint32_t *__restrict__ out = A.out_pos + (size_t)d * n;
     for (uint32_t k = tid; k < n; k += NT) out[k] = perm[k];
@@ -634,7 +1060,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         st[2] = reversed;
         st[3] = status;
         st[4] = step;
-#if !defined(TL_PROFILE) && !defined(TL_PROFILE2)
+#if !defined(TL_PROFILE) && !defined(TL_PROFILE2) && !defined(TL_PROFILE3)
         // [5..8] cascade work (counting instantiation only, else 0): L0 tile bounds, candidates into L1, into L2, into L3;
         // [9] shader clocks of the descent
         // (s_memtime), [10] the same interval in constant 100 MHz ticks (s_memrealtime) -> the clock the CU really held
@@ -647,7 +1073,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         st[9] = __builtin_amdgcn_s_memtime() - ctl->clk0;
         st[10] = __builtin_amdgcn_s_memrealtime() - ctl->rt0;
 #endif
-#ifdef TL_PROFILE2
+#if defined(TL_PROFILE2) && defined(TL_TWO_OPT_CLASSIC)
         // [5..7] pruned hit steps: count, cycles, rows advanced; [8..10] pruned no-hit steps: count, cycles, rows;
         // [11..12] dense hit steps: count, cycles; [13..14] dense no-hit: count, cycles; [15] flush cycles
         st[5] = q2[0]; st[6] = q2[1]; st[7] = q2[2]; st[8] = q2[3]; st[9] = q2[4]; st[10] = q2[5];
