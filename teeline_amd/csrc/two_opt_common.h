@@ -193,24 +193,29 @@ __device__ __forceinline__ bool tile_first_hit(const PT &P, uint32_t n, uint32_t
 // 29.6k steps per descent and 128.1 / 123.2 / 123.2 / 127.3 / 133.2 / 143.6 ms (the chance of a hit in the next tile falls
 // from ~18 % over the first two to ~5 % and ~3 % further out); choosing the count from the recent gap between moves, or
 // requesting the next tile's coordinates ahead, measured no better.
-// Hits are recorded in `hl` (hl[0] = count, hl[1] = column at which the scan resumes, hl[2..] = hit columns; with JKEY
-// hl[2], hl[3] = the row's b after the last hit, the hit columns go to *hits_out, lane h = h-th hit); the first one is posted
-// to the key slot.  Only the list of the wave that owns the globally first hit is used afterwards.
-// Returns the number of hits.
+// The chain is recorded in `hl` (hl[0] = count, hl[1] = column at which the scan resumes, hl[2], hl[3] = the row's b after the
+// last hit) and in *hits_out (lane h = h-th hit column); the first hit is posted to the key slot.  Only the list of the wave that
+// owns the globally first hit is used afterwards.  Returns the number of hits.
 #ifndef TL_CHAIN_TILES
-#define TL_CHAIN_TILES 2
+#define TL_CHAIN_TILES 1
 #endif
 static constexpr uint32_t kChainTiles = TL_CHAIN_TILES;
-// Key posted for the first hit: (i << 16) | column (JKEY false: `i` = the row; the classic kernel) or (column << 16) | i
-// (JKEY true: `i` = the posting wave; the role-split kernel, whose dense rows are implied and whose control wave finds the
-// owner's hit list by that tag).  Both order hits of one row by column.
-template <bool PRUNE, bool JKEY = false, typename TC, typename PT>
-__device__ __forceinline__ uint32_t dense_tile(const PT &P, uint32_t n, uint32_t i, uint32_t tb, uint32_t jmin,
+// The key posted for the first hit is (column << 16) | wtag: the row is implied, and the tag (the posting wave) finds the owner's
+// hit list.  STOPCHK (the waves of the second round): the key slot is read beside the tile's points — one LDS round trip per
+// tile instead of two; a wave that finds an earlier column already posted returns kTileStopped.
+constexpr uint32_t kTileStopped = 0xFFFFFFFFu;
+template <bool PRUNE, bool STOPCHK, typename TC, typename PT>
+__device__ __forceinline__ uint32_t dense_tile(const PT &P, uint32_t n, uint32_t wtag, uint32_t tb, uint32_t jmin,
                                                float ax, float ay, float bx, float by, float sqab,
-                                               uint32_t *hl, uint32_t *keyslot, int lane, TC &tc, uint32_t *hits_out = nullptr)
+                                               uint32_t *hl, uint32_t *keyslot, int lane, TC &tc, uint32_t *hits_out)
 {
     uint32_t j = tb + (uint32_t)lane;
     float2 c = pt_get(P, j), e = pt_get(P, j + 1u);
+    uint32_t kbv = 0;
+    if (STOPCHK) kbv = *keyslot;
+    if (STOPCHK) {  // an earlier column already improves (kNoKey reads as column 65535)
+        if (((uint32_t)__builtin_amdgcn_readfirstlane((int)kbv) >> 16) < tb) return kTileStopped;
+    }
     uint64_t m = tile_mask_core<PRUNE>(c, e, j, n, jmin, ax, ay, bx, by, sqab, tc);
     if (m == 0) return 0;  // the common case: no chain state was ever set up
     uint32_t from = jmin, nh = 0, hitv = 0, mykey = 0;  // lane h of hitv holds the h-th hit column
@@ -220,7 +225,7 @@ __device__ __forceinline__ uint32_t dense_tile(const PT &P, uint32_t n, uint32_t
         const uint32_t jh = tb + (uint32_t)l;
         hitv = ((uint32_t)lane == nh) ? jh : hitv;
         if (nh == 0) {
-            mykey = JKEY ? ((jh << 16) | i) : ((i << 16) | jh);
+            mykey = (jh << 16) | wtag;
             if (lane == 0) atomicMin(keyslot, mykey);  // post at once: it stops the other waves' scans
         }
         ++nh;
@@ -252,18 +257,11 @@ __device__ __forceinline__ uint32_t dense_tile(const PT &P, uint32_t n, uint32_t
         }
         if (stop) break;
     }
-    if (JKEY) {  // role-split kernel: the list carries the row's b after these hits (the other waves go on from it); the hit
-                 // columns stay in this wave's register (lane h = h-th hit) — the owner files them itself after the barrier
-        *hits_out = hitv;
-        if (lane == 0)
-            *reinterpret_cast<uint4 *>(hl) = make_uint4(nh, capped ? from : (tb + 64u), __builtin_bit_cast(uint32_t, bx), __builtin_bit_cast(uint32_t, by));
-    } else {
-        if ((uint32_t)lane < nh) hl[2u + (uint32_t)lane] = hitv;
-        if (lane == 0) {
-            hl[0] = nh;
-            hl[1] = capped ? from : (tb + 64u);  // every tile up to tb is exhausted unless the chain was cut short
-        }
-    }
+    // the list carries the row's b after these hits (the other waves go on from it); the hit columns stay in this wave's
+    // register (lane h = h-th hit) — the owner files them itself after the barrier
+    *hits_out = hitv;
+    if (lane == 0)
+        *reinterpret_cast<uint4 *>(hl) = make_uint4(nh, capped ? from : (tb + 64u), __builtin_bit_cast(uint32_t, bx), __builtin_bit_cast(uint32_t, by));
     return nh;
 }
 

@@ -51,11 +51,6 @@ constexpr int kFlushSlots = 15;       // elements per thread a flush can hold: 1
 constexpr int kFlushSlotsFx = 20;     // grid-coordinate form on 8 waves: 20 x 512 covers n = 10^4 (two tours per CU)
 constexpr int kMaxGroups = 4;         // 64-tile groups: n_pad <= 4 * 64 * 64 = 16384
 
-#ifdef TL_PROFILE
-#define TL_STAMP(var) do { if (tid == 0) { const uint64_t _t = __builtin_amdgcn_s_memtime(); prof[(var) + (pmode ? 8 : 0)] += _t - tlast; tlast = _t; } } while (0)
-#else
-#define TL_STAMP(var) do { } while (0)
-#endif
 
 struct Ctl {                     // kCtlBytes of LDS
     uint32_t keys[4];
@@ -253,12 +248,13 @@ __device__ __forceinline__ bool step_boundary(Cursor &c, Acct &a, const PT &P, u
     const float rowlen = (float)(n - 2u - c.i0);
     reload = false;
     if (!c.pruned) {
+        // what a dense step's end asks for: flush the row's deferred reversals (behind a barrier if hits were filed just now),
+        // go to the next row
+        bool flush = false, sync_first = false, next_row = false;
         if (key == kNoKey) {  // row i0 is finished: its reversals are due, composed
             if (CONTROL) a.since += rowlen;
-            if (c.np) flush_pending<CONTROL, NT, SLOTS>(c, a, P, perm, ctl, lane, wave, false);
-            c.i0 += 1u;
-            c.j0 = c.i0 + 2u;
-            reload = true;
+            flush = c.np != 0u;
+            next_row = true;
         } else {
             // the wave owning the first hit chained every improving move inside its tile (dense_tile).  Nothing of the row's
             // remaining scan reads [i+1..hit], so the reversals wait in ctl->pend until the row ends (flush_deferred); the scan
@@ -278,19 +274,20 @@ __device__ __forceinline__ bool step_boundary(Cursor &c, Acct &a, const PT &P, u
             }
             c.np += nh;
             c.j0 = resume;
-            if (c.j0 > n - 2u) {  // the row's last column is behind us
-                flush_pending<CONTROL, NT, SLOTS>(c, a, P, perm, ctl, lane, wave, true);
-                c.i0 += 1u;
-                c.j0 = c.i0 + 2u;
-                reload = true;
-            } else if (c.np + kMaxChainHits > kPendMax) {  // the hit register is nearly full
-                flush_pending<CONTROL, NT, SLOTS>(c, a, P, perm, ctl, lane, wave, true);
-                reload = true;
-            } else {
+            next_row = c.j0 > n - 2u;                                    // the row's last column is behind us
+            flush = next_row || c.np + kMaxChainHits > kPendMax;          // ... or the hit register is nearly full
+            sync_first = true;
+            if (!flush) {
                 bx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((int)hv.z));
                 by = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((int)hv.w));
             }
         }
+        if (flush) flush_pending<CONTROL, NT, SLOTS>(c, a, P, perm, ctl, lane, wave, sync_first);
+        if (next_row) {
+            c.i0 += 1u;
+            c.j0 = c.i0 + 2u;
+        }
+        reload = flush || next_row;
     } else if (key == kNoKey) {
         if (CONTROL) a.since += (float)R * rowlen;
         c.i0 += R;
@@ -341,7 +338,6 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = NT / 64;
     static_assert(NW == 16 || NW == 8 || NW == 4, "16 waves; 8 or 4 for two or four descents per CU");
-    static_assert(NW >= (int)kDenseLead, "the lead round has one wave per SIMD");
     const uint32_t n = A.n, npad = A.n_pad;
     const uint32_t ntile = npad >> 6;                  // tiles incl. the pad tile
     const int G = (int)((ntile + 63u) >> 6);           // 64-tile groups (<= kMaxGroups)
@@ -451,303 +447,6 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     uint64_t moves = 0, reversed = 0;
     uint64_t rev_lane = 0;        // per-lane share of `reversed` from the flushes (summed over lanes at the end)
     typename std::conditional<COUNT, TileCounts, NoCounts>::type tc;  // work really done by this wave's cascade (SALU counters)
-#ifdef TL_TWO_OPT_CLASSIC
-    uint32_t i0 = 0, j0 = 2;
-    bool improved = false;
-    uint32_t np = 0, hlast = 0, prow = 0;  // dense mode: np hits of row `prow` whose reversals are deferred; the last one
-    uint32_t pendv = 0xFFFFFFFFu;          // ... lane m < np of every wave holds hit column g_m
-    bool flush_due = false;                // row `prow` is finished (or the hit register is nearly full)
-    float gap_est = 0.0f, since = 0.0f;
-    uint32_t dirty_lo = 0xFFFFFFFFu, dirty_hi = 0;               // tiles whose L0 metadata is stale
-#ifdef TL_PROFILE
-    uint64_t prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    bool pmode = false;
-    uint64_t nsteps_pruned = 0, nmoves_pruned = 0;
-    uint64_t tlast = __builtin_amdgcn_s_memtime();
-    uint64_t rows_total = 0, livetiles = 0, nflush = 0;
-#endif
-
-#ifdef TL_PROFILE2
-    uint64_t q2[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    uint32_t slot = 0;  // step % 3
-    while (n >= 4) {
-#ifdef TL_PROFILE2
-        uint64_t t_it = __builtin_amdgcn_s_memtime();
-#endif
-        // deferred reversals are applied (one call site) when their row is finished, when the hit register runs full, or when the
-        // next block is a pruned one, which reads every row of the block
-        if (np && (flush_due || (PRUNE && i0 < nrows && fmaxf(gap_est, since) > TL_DENSE_ROWS * (float)(n - 2u - i0)))) {
-            TL_STAMP(7);
-#ifdef TL_PROFILE
-            ++nflush;
-#endif
-            rev_lane += flush_deferred<NT, kSlots>(P, perm, pendv, prow + 1u, np, lane, wave);
-            pendv = 0xFFFFFFFFu;
-#ifdef TL_PROFILE2
-            { const uint64_t t2 = __builtin_amdgcn_s_memtime(); q2[12] += t2 - t_it; t_it = t2; }
-#endif
-            const uint32_t t0 = prow >> 6, t1 = hlast >> 6;  // L0 metadata of tiles with a changed position or tour-edge
-            dirty_lo = t0 < dirty_lo ? t0 : dirty_lo;
-            dirty_hi = t1 > dirty_hi ? t1 : dirty_hi;
-            np = 0;
-            flush_due = false;
-            TL_STAMP(5);
-        }
-        if (i0 >= nrows) {  // sweep finished (two_opt.rs:26-28)
-            if (!improved) break;
-            if (sweeps >= A.max_sweeps) {
-                status = 1;
-                break;
-            }
-            improved = false;
-            ++sweeps;
-            i0 = 0;
-            j0 = 2;
-        }
-        const uint32_t slot_next = slot == 2u ? 0u : slot + 1u;
-        if (tid == 0) ctl->keys[slot_next] = kNoKey;  // slot of the next step
-        ++step;
-        uint32_t *keyslot = &ctl->keys[slot];
-
-        // block geometry: dense mode (moves every few rows: one row, every tile) or pruned mode (R rows, L0)
-        const float rowlen = (float)(n - 2u - i0);
-        const float g = fmaxf(gap_est, since);
-        int R = 1;
-        if (PRUNE && g > TL_DENSE_ROWS * rowlen) {
-            R = kRMax;
-            if ((uint32_t)R > nrows - i0) R = (int)(nrows - i0);
-        }
-        const bool pruned = PRUNE && R > 1;
-        const uint32_t hpar = (step & 1u) << 4;
-#ifdef TL_PROFILE
-        pmode = pruned;
-        nsteps_pruned += pruned ? 1 : 0;
-#endif
-
-        // lane-resident row table: lane l holds P[i0+l] and sq(P[i0+l], P[i0+l+1])
-        const float2 rp = pt_get(P, i0 + (uint32_t)lane);
-        const float2 rq = pt_get(P, i0 + (uint32_t)lane + 1u);
-        const float rowsq = sqdist(rp, rq);
-
-        if (pruned) {
-            // L0 metadata is rebuilt lazily: only tiles touched by reversals since the last pruned step
-            if (dirty_lo <= dirty_hi) {
-                for (uint32_t t = dirty_lo + (uint32_t)wave; t <= dirty_hi; t += NW) build_tile_meta(P, n, t, lane, tbox, tmsq);
-                dirty_lo = 0xFFFFFFFFu;
-                dirty_hi = 0;
-                TL_SYNC();
-            }
-            // ---- pruned mode: wave w owns rows w, w+16, ... of the block.  L0 (lanes = tiles) yields the live-tile
-            // mask of the row in SGPRs, L1 (lanes = j) runs on those tiles right away — no exchange between waves,
-            // and every row has its diagonal tile live, so the rows are naturally balanced.
-            float4 box[kMaxGroups];
-            float msq[kMaxGroups];
-#pragma unroll
-            for (int gI = 0; gI < kMaxGroups; ++gI) {
-                if (gI < G) {
-                    box[gI] = tbox[((uint32_t)gI << 6) + (uint32_t)lane];
-                    msq[gI] = tmsq[((uint32_t)gI << 6) + (uint32_t)lane];
-                }
-            }
-            for (int r = wave; r < R; r += NW) {
-                const uint32_t i = i0 + (uint32_t)r;
-                if (r >= NW) {  // a hit in an earlier row makes this one moot
-                    const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot);
-                    if (kb != kNoKey && (kb >> 16) < i) break;
-                }
-                const float ax = readlane_f(rp.x, r), ay = readlane_f(rp.y, r);
-                const float bx = readlane_f(rp.x, r + 1), by = readlane_f(rp.y, r + 1);
-                const float sqab = readlane_f(rowsq, r);
-                const uint32_t jmin = (r == 0) ? j0 : (i + 2u);
-                const uint32_t tmin = jmin >> 6;
-                bool row_hit = false;
-                tc.prow += 1u;
-#pragma unroll
-                for (int gI = 0; gI < kMaxGroups; ++gI) {
-                    if (gI < G && (((uint32_t)gI + 1u) << 6) > tmin) {  // groups wholly before the row's first column: nothing to test
-                        const uint32_t tl = ((uint32_t)gI << 6) + (uint32_t)lane;
-                        const bool near_a = box_lb(ax, ay, box[gI]) < sqab, near_b = box_lb(bx, by, box[gI]) < msq[gI];
-                        const bool live = (tl >= tmin) & (near_a | near_b);  // no short-circuit: both bounds are cheaper than a branch
-                        tc.l0 += 64u;
-                        uint64_t m = __builtin_amdgcn_ballot_w64(live);
-                        uint64_t hm = 0;
-                        uint32_t t = 0;
-                        while (m != 0 && hm == 0) {  // later tiles of this row are later columns
-                            t = ((uint32_t)gI << 6) + (uint32_t)(__builtin_ffsll((long long)m) - 1);
-                            m &= m - 1;
-                            tc.ptile += 1u;
-#ifdef TL_PROFILE
-                            ++livetiles;
-#endif
-                            hm = tile_improving_mask<PRUNE>(P, n, t << 6, jmin, ax, ay, bx, by, sqab, lane, tc);
-                        }
-                        if (hm) {
-                            if (lane == 0) atomicMin(keyslot, (i << 16) | ((t << 6) + (uint32_t)(__builtin_ffsll((long long)hm) - 1)));
-                            row_hit = true;
-                        }
-                    }
-                    if (row_hit) break;
-                }
-                if (row_hit) break;  // rows w+16, ... are later rows
-            }
-            TL_STAMP(0);
-        } else {
-            // ---- dense mode: one row, every tile from the resume column on.
-            // Round 1: only kDenseLead waves look at the first tiles (one per SIMD), everybody else parks at the barrier —
-            // moves come every few candidates here, and a wave chaining hits runs ~3x faster when it does not share
-            // its SIMD's issue slots with three busy neighbours.  Round 2 (no hit yet): all waves take the rest of the row.
-            const uint32_t i = i0, t0 = j0 >> 6;
-            const float ax = readlane_f(rp.x, 0), ay = readlane_f(rp.y, 0);
-            float bx = readlane_f(rp.x, 1), by = readlane_f(rp.y, 1);
-            float sqab = readlane_f(rowsq, 0);
-            if (np) {  // p[i+1] after the deferred reversals = the old p[g_last], still in place (two_opt.rs:50)
-                const float2 bq = pt_get(P, hlast);
-                bx = readlane_f(bq.x, 0);
-                by = readlane_f(bq.y, 0);
-                sqab = sqdist(make_float2(ax, ay), make_float2(bx, by));
-            }
-            if ((uint32_t)wave < kDenseLead && t0 + (uint32_t)wave <= last_tile) {
-                const uint32_t t = t0 + (uint32_t)wave;
-#ifdef TL_PROFILE
-                ++livetiles;
-#endif
-                dense_tile<PRUNE>(P, n, i, t << 6, j0, ax, ay, bx, by, sqab, queues + ((t & 15u) | hpar) * kQCap, keyslot, lane, tc);
-            }
-            TL_SYNC();
-            // Round 2.  A wave stops only at a hit in a column BEFORE its tile (a lead-round hit stops everybody at once).  A
-            // hit that another wave has just posted further right must not stop it: this tile may hold an earlier one (a
-            // blanket "some key is posted -> skip round 2" test here was a race between waves leaving the barrier).
-            for (uint32_t t = t0 + kDenseLead + (uint32_t)wave; t <= last_tile; t += NW) {
-                const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot);
-                if ((kb & 0xFFFFu) < (t << 6)) break;  // an earlier column already improves (kNoKey reads as column 65535)
-#ifdef TL_PROFILE
-                ++livetiles;
-#endif
-                if (dense_tile<PRUNE>(P, n, i, t << 6, j0, ax, ay, bx, by, sqab, queues + ((t & 15u) | hpar) * kQCap, keyslot, lane, tc)) break;
-            }
-        }
-        TL_STAMP(2);
-        TL_SYNC();
-        TL_STAMP(3);
-        const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->keys[slot]);
-#ifdef TL_PROFILE2
-        const uint32_t i0_before = i0;
-#endif
-#ifdef TL_PROFILE
-        rows_total += (uint64_t)R;
-#endif
-
-        if (key == kNoKey) {
-            flush_due = np != 0;  // row i0 is finished: its reversals are due, composed
-            since += (float)R * rowlen;
-            i0 += (uint32_t)R;
-            j0 = i0 + 2u;
-        } else if (!pruned) {
-            // dense mode: the wave owning the first hit chained every improving move inside its tile (dense_tile) and left
-            // the list in the tile's slot.  Nothing of the row's remaining scan reads [i+1..hit], so the reversals wait
-            // in `pendv` until the row ends (flush_deferred); the scan goes on at `resume` with b = the old p[hit].
-            const uint32_t js = key & 0xFFFFu;
-            const uint32_t *hl = queues + ((((js >> 6) & 15u) | hpar) * kQCap);
-            static_assert(2u + kMaxChainHits <= kQCap, "a hit list fits its slot");
-            const uint32_t hsel = (uint32_t)lane - np;  // lanes np .. np+nh-1 take the new hits
-            const uint32_t hval = hl[2u + (hsel < kMaxChainHits ? hsel : 0u)];
-            const uint32_t nh = (uint32_t)__builtin_amdgcn_readfirstlane((int)hl[0]);
-            const uint32_t resume = (uint32_t)__builtin_amdgcn_readfirstlane((int)hl[1]);
-            pendv = hsel < nh ? hval : pendv;
-            np += nh;
-            hlast = readlane_u(pendv, np - 1u);
-            prow = i0;
-            moves += nh;
-            // gap estimate (block-shape heuristic only): the first hit exactly, chained hits as evenly spaced
-            since += (float)(js - j0);
-            gap_est = 0.5f * (gap_est + since);
-            since = 0.0f;
-            if (nh > 1u) gap_est = fminf(gap_est, 0.5f * gap_est + 16.0f);  // chained hits are < 64 columns apart
-            improved = true;
-            j0 = resume;
-            const bool row_end = j0 > n - 2u;
-            flush_due = row_end || np + kMaxChainHits > kPendMax;
-            if (row_end) {
-                ++i0;
-                j0 = i0 + 2u;
-            }
-            TL_STAMP(4);
-        } else {
-            // pruned mode: one hit, applied at once (moves are rare here)
-            const uint32_t is = key >> 16, js = key & 0xFFFFu;
-            const uint32_t resume = js + 1u;
-            const uint32_t lo = is + 1u;
-            const uint32_t hi = js;
-            since += (float)(is - i0) * rowlen;
-            {
-                // two_opt.rs:50,69-79  swap_2opt(path, i+1, j); two pairs per thread in flight
-                const uint32_t half = (hi - lo + 1u) >> 1;
-                for (uint32_t t = tid; t < half; t += 2 * NT) {
-                    const uint32_t t2 = t + NT;
-                    const bool two = t2 < half;
-                    const auto x = pt_raw(P, lo + t), y = pt_raw(P, hi - t);
-                    const uint16_t u = perm[lo + t], v = perm[hi - t];
-                    uint16_t u2 = u, v2 = v;
-                    auto x2 = x, y2 = y;
-                    if (two) {
-                        x2 = pt_raw(P, lo + t2);
-                        y2 = pt_raw(P, hi - t2);
-                        u2 = perm[lo + t2];
-                        v2 = perm[hi - t2];
-                    }
-                    pt_put(P, lo + t, y);
-                    pt_put(P, hi - t, x);
-                    perm[lo + t] = v;
-                    perm[hi - t] = u;
-                    if (two) {
-                        pt_put(P, lo + t2, y2);
-                        pt_put(P, hi - t2, x2);
-                        perm[lo + t2] = v2;
-                        perm[hi - t2] = u2;
-                    }
-                }
-                TL_SYNC();
-                ++moves;
-                reversed += (uint64_t)(hi - is);
-                // (for a hit in a later row of the block hi - j0 wraps to a huge value: the estimate then keeps the pruned block
-                //  shape, which measured faster than the "correct" gap — 126 vs 137 ms per 256 restarts)
-                since += (float)(hi - j0);
-                gap_est = 0.5f * (gap_est + since);
-                since = 0.0f;
-            }
-            TL_STAMP(4);
-            // L0 metadata of every tile that saw a changed position or tour-edge (j = lo-1 .. hi) is now stale
-            {
-                const uint32_t t0 = (lo - 1u) >> 6, t1 = hi >> 6;
-                dirty_lo = t0 < dirty_lo ? t0 : dirty_lo;
-                dirty_hi = t1 > dirty_hi ? t1 : dirty_hi;
-            }
-            TL_STAMP(6);
-            improved = true;
-#ifdef TL_PROFILE
-            nmoves_pruned += 1;
-#endif
-            i0 = is;
-            j0 = resume;
-            if (j0 > n - 2u) {
-                ++i0;
-                j0 = i0 + 2u;
-            }
-        }
-#ifdef TL_PROFILE2
-        {
-            const uint64_t dt = __builtin_amdgcn_s_memtime() - t_it;
-            const int b = (pruned ? 0 : 6) + (key == kNoKey ? 3 : 0);
-            q2[b] += 1;
-            q2[b + 1] += dt;
-            q2[b + 2] += (key == kNoKey) ? (uint64_t)R : (uint64_t)((key >> 16) - i0_before);
-        }
-#endif
-        slot = slot_next;
-    }
-
-#else
 
     // Role split.  The reference's loop is a chain of ~35 k steps per descent (n = 10^4, random start), and what a step costs is not
     // only its scan but the instructions EVERY wave executes around it: four waves share a SIMD's issue port, so an instruction
@@ -818,10 +517,11 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             n_pruned_steps += c.pruned ? 1u : 0u;
             const uint32_t R = c.pruned ? ((uint32_t)kRMax < nrows - c.i0 ? (uint32_t)kRMax : nrows - c.i0) : 1u;
             if (c.pruned) {
-                if (c.dirty_lo <= c.dirty_hi) {
+                if (c.dirty_lo <= c.dirty_hi) {  // stale tile boxes: every wave takes its share (this one has nothing else to do here)
+                    for (uint32_t t = c.dirty_lo; t <= c.dirty_hi; t += (uint32_t)NW) build_tile_meta(P, n, t, lane, tbox, tmsq);
                     c.dirty_lo = 0xFFFFFFFFu;
                     c.dirty_hi = 0;
-                    TL_SYNC();  // the workers rebuild the stale tile boxes
+                    TL_SYNC();
                 }
             } else {
                 TL_SYNC();  // B1: lead round
@@ -914,24 +614,23 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 const uint32_t t0 = c.j0 >> 6;
                 TL_STAMP3(0);
                 if ((uint32_t)wk < kLead && t0 + (uint32_t)wk <= last_tile)
-                    dense_tile<PRUNE, true>(P, n, (uint32_t)wave, (t0 + (uint32_t)wk) << 6, c.j0, ax, ay, bx, by, sqab, hl_mine, keyslot, lane, tc, &my_hits);
+                    dense_tile<PRUNE, false>(P, n, (uint32_t)wave, (t0 + (uint32_t)wk) << 6, c.j0, ax, ay, bx, by, sqab, hl_mine, keyslot, lane, tc, &my_hits);
                 TL_STAMP3(1);
                 TL_SYNC();  // B1
                 TL_STAMP3(2);
                 // A wave stops only at a hit in a column BEFORE its tile (a lead-round hit stops everybody at once).  A hit that
                 // another wave has just posted further right must not stop it: this tile may hold an earlier one.
-                for (uint32_t t = t0 + kLead + (uint32_t)wk; t <= last_tile; t += (uint32_t)NWK) {
-                    const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot);
-                    if ((kb >> 16) < (t << 6)) break;  // an earlier column already improves (kNoKey reads as column 65535)
+                // (dense_tile reads the key beside the tile's points and looks at it after the tile's first mask: one LDS round trip
+                //  per tile instead of two)
+                for (uint32_t t = t0 + kLead + (uint32_t)wk; t <= last_tile; t += (uint32_t)NWK)
                     if (dense_tile<PRUNE, true>(P, n, (uint32_t)wave, t << 6, c.j0, ax, ay, bx, by, sqab, hl_mine, keyslot, lane, tc, &my_hits)) break;
-                }
                 TL_STAMP3(3);
             } else {
                 // ---- pruned step: worker w owns rows w, w+NWK, ... of the block.  L0 (lanes = tiles) yields the live-tile
                 // mask of the row in SGPRs, L1 (lanes = j) runs on those tiles right away — no exchange between waves,
                 // and every row has its diagonal tile live, so the rows are naturally balanced.
                 if (c.dirty_lo <= c.dirty_hi) {  // L0 metadata is rebuilt lazily: only tiles touched by reversals since the last pruned step
-                    for (uint32_t t = c.dirty_lo + (uint32_t)wk; t <= c.dirty_hi; t += (uint32_t)NWK) build_tile_meta(P, n, t, lane, tbox, tmsq);
+                    for (uint32_t t = c.dirty_lo + (uint32_t)wave; t <= c.dirty_hi; t += (uint32_t)NW) build_tile_meta(P, n, t, lane, tbox, tmsq);
                     c.dirty_lo = 0xFFFFFFFFu;
                     c.dirty_hi = 0;
                     TL_SYNC();
@@ -973,11 +672,12 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                             uint64_t m = __builtin_amdgcn_ballot_w64(live);
                             uint64_t hm = 0;
                             uint32_t t = 0;
-                            while (m != 0 && hm == 0) {  // later tiles of this row are later columns
+                            while (m != 0) {  // later tiles of this row are later columns
                                 t = ((uint32_t)gI << 6) + (uint32_t)(__builtin_ffsll((long long)m) - 1);
                                 m &= m - 1;
                                 tc.ptile += 1u;
                                 hm = tile_improving_mask<PRUNE>(P, n, t << 6, jmin, rax, ray, rbx, rby, rsqab, lane, tc);
+                                if (hm) break;
                             }
                             if (hm) {
                                 if (lane == 0) atomicMin(keyslot, (i << 16) | ((t << 6) + (uint32_t)(__builtin_ffsll((long long)hm) - 1)));
@@ -1003,7 +703,6 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         }
 #endif
     }
-#endif
 
     // ---------------------------------------------------------------- results
     uint32_t *__restrict__ out = A.out_pos + (size_t)d * n;
@@ -1060,7 +759,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         st[2] = reversed;
         st[3] = status;
         st[4] = step;
-#if !defined(TL_PROFILE) && !defined(TL_PROFILE2) && !defined(TL_PROFILE3)
+#if !defined(TL_PROFILE2) && !defined(TL_PROFILE3)
         // [5..8] cascade work (counting instantiation only, else 0): L0 tile bounds, candidates into L1, into L2, into L3;
         // [9] shader clocks of the descent
         // (s_memtime), [10] the same interval in constant 100 MHz ticks (s_memrealtime) -> the clock the CU really held
@@ -1072,28 +771,6 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         st[12] = ctl->cnt[5];
         st[9] = __builtin_amdgcn_s_memtime() - ctl->clk0;
         st[10] = __builtin_amdgcn_s_memrealtime() - ctl->rt0;
-#endif
-#if defined(TL_PROFILE2) && defined(TL_TWO_OPT_CLASSIC)
-        // [5..7] pruned hit steps: count, cycles, rows advanced; [8..10] pruned no-hit steps: count, cycles, rows;
-        // [11..12] dense hit steps: count, cycles; [13..14] dense no-hit: count, cycles; [15] flush cycles
-        st[5] = q2[0]; st[6] = q2[1]; st[7] = q2[2]; st[8] = q2[3]; st[9] = q2[4]; st[10] = q2[5];
-        st[11] = q2[6]; st[12] = q2[7]; st[13] = q2[9]; st[14] = q2[10]; st[15] = q2[12];
-#endif
-#ifdef TL_PROFILE
-        // dense: [5]=setup+scan [6]=wait [7]=apply [8]=apply-barrier ; pruned: [9]=setup+phaseA [10]=barrier [11]=phaseB [12]=wait [13]=apply+barrier
-        st[5] = prof[0] + prof[1] + prof[2];
-        st[6] = prof[3];
-        st[7] = prof[4];
-        st[8] = prof[6] + prof[7] + prof[15];
-        st[9] = prof[8] + prof[10];
-        st[10] = prof[5] + prof[13];  // flush_deferred
-        st[11] = nflush;
-        st[12] = prof[11];
-        st[13] = prof[12] + prof[14];
-        st[14] = nsteps_pruned;
-        st[15] = nmoves_pruned;
-        (void)rows_total;
-        (void)livetiles;
 #endif
     }
 }
