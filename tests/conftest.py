@@ -26,8 +26,12 @@ def _has_gpu():
 
 
 def pytest_collection_modifyitems(config, items):
-    # `-m gpu` on a box without a GPU must fail loudly, not skip: the product has no CPU fallback.
-    pass
+    # `-m gpu` on a box without a GPU must fail loudly, not skip and not "0 selected": the product has no CPU fallback.
+    expr = (config.getoption("-m") or "").strip()
+    wants_gpu = "gpu" in expr and "not gpu" not in expr
+    if wants_gpu and any(it.get_closest_marker("gpu") for it in items) and not _has_gpu():
+        raise pytest.UsageError("-m gpu was asked for, but no MI355X is visible here (torch.cuda.is_available() is False): "
+                                "libteeline_gpu has no CPU fallback, so these tests cannot run — use gpurun")
 
 
 @pytest.fixture(scope="session")

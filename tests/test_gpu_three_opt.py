@@ -121,3 +121,42 @@ def test_find_best_move_large(ctx, n):
     mv2 = TA.three_opt.find_best_move(problem(None, packed, n), nn, ctx=ctx)
     omv_nn = O.three_opt_find_best_move(xy, None, nn)
     assert mv2[:4] == omv_nn[:4] and mv2[4].tobytes() == omv_nn[4].tobytes()
+
+
+@pytest.fixture(scope="module")
+def goldens3(golden_dir):
+    with open(os.path.join(golden_dir, "goldens_three_opt.json")) as fh:
+        return json.load(fh)
+
+
+def _crc(p):
+    p = np.asarray(p, dtype=np.uint32)
+    return int(np.bitwise_xor.reduce(p * np.arange(1, len(p) + 1, dtype=np.uint32)))
+
+
+def _check_descent(g, gold):
+    route, cost, st = g
+    assert int(np.float32(cost).view(np.uint32)) == gold["cost_bits"], (float(cost), gold["cost"])
+    assert _crc(route) == gold["route_crc"] and route[:12].tolist() == gold["route_head"]
+    assert st["moves"] == gold["stats"]["moves"] and st["sweeps"] == gold["stats"]["sweeps"]
+    assert st["candidates"] == gold["stats"]["candidates"]
+
+
+def test_a280_full_descent_from_the_nn_seed(ctx, tsplib_dir, goldens3):
+    # full 3-opt descents were oracle-checked only up to n = 120.  a280 from the NN seed: 32 moves, among them
+    # apply_3opt's segment-swap cases 4-7 (three_opt.rs:186-218) over long segments; coordinates and matrix form.
+    d = T.parse_tsplib(os.path.join(tsplib_dir, "a280.tsp"))
+    xy, n = d["xy"], d["n"]
+    rc, nn, _ = O.nearest_neighbor(xy, None, n, 3)
+    _check_descent(gpu_three_opt(ctx, xy, None, n, nn), goldens3["a280_nn_three_opt"])
+    _check_descent(gpu_three_opt(ctx, None, O.dm_build_packed(xy), n, nn), goldens3["a280_nn_three_opt_matrix"])
+
+
+def test_synthetic_300_full_descent_from_a_random_permutation(ctx, goldens3):
+    # 225 moves from a seeded random permutation (1.0e9 triples): every pass moves a long segment
+    n = 300
+    xy = O.synth_xy(n)
+    rp = O.restart_perm(n, 4, 0)
+    assert rp[:8].tolist() == goldens3["synth300_perm_seed4_three_opt"]["perm_head"]
+    _check_descent(gpu_three_opt(ctx, xy, None, n, rp), goldens3["synth300_perm_seed4_three_opt"])
+    _check_descent(gpu_three_opt(ctx, None, O.dm_build_packed(xy), n, rp), goldens3["synth300_perm_seed4_three_opt_matrix"])
