@@ -150,6 +150,31 @@ def latest_profile(pattern):
     return f[-1] if f else None
 
 
+def scan_valu_roofline(kernel, n, ms, info, clock_hz):
+    """VALU-issue roofline of a whole-chip scan kernel (3-opt / Or-opt find_best_move): wave64 VALU instructions of ONE launch from
+    the committed rocprofv3 PMC pass (profiles/rNN_scans_pmc.json, scripts/pmc_scans.sh: same instance, same tour, so the count is a
+    property of the launch) over the kernel time measured live here; peak = SIMDs x live clock / 2.  None if no profile matches."""
+    prof = latest_profile("r*_scans_pmc.json")
+    if not prof or clock_hz <= 0:
+        return None
+    try:
+        pj = json.load(open(prof)).get(kernel)
+        if not pj or pj.get("n") != n:
+            return None
+        simds = info["cus"] * SIMDS_PER_CU
+        peak = simds * clock_hz / VALU_CYCLES_PER_WAVE_INST / 1e9
+        ach = float(pj["SQ_INSTS_VALU"]) / (ms * 1e-3) / 1e9
+        r = {"bound": "valu_issue", "achieved": ach, "peak": peak, "unit": "G wave64-VALU-instructions/s", "frac": ach / peak, "traffic": None,
+             "kernel": kernel, "kernel_ms": ms, "valu_insts_per_launch": pj["SQ_INSTS_VALU"], "source": os.path.relpath(prof, ROOT),
+             "formula": "frac = SQ_INSTS_VALU / (simds * kernel_s * clock_hz / 2); clock = the headline kernel's live in-kernel clock of this run"}
+        for k in ("SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CU_CYCLES", "kernel_ms_profiled"):
+            if k in pj:
+                r.setdefault("pmc", {})[k] = pj[k]
+        return r
+    except Exception as exc:
+        return {"source_error": repr(exc)}
+
+
 def valu_roofline(n, R, seed, first, info, k_ms, clock_hz, work, cand_per_launch, launches):
     """What bounds k_two_opt_ref_lds is VALU issue, not HBM (the tour never leaves LDS: DESIGN.md §4.2).
     achieved = wave64 VALU instructions per launch / kernel time; peak = SIMDs x clock / 2 (a wave64 VALU instruction
@@ -189,6 +214,17 @@ def valu_roofline(n, R, seed, first, info, k_ms, clock_hz, work, cand_per_launch
                           "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CU_CYCLES"):
                     if k in pj:
                         r.setdefault("pmc", {})[k] = pj[k]
+                if "SQ_INSTS_SALU" in pj and clock_hz > 0:
+                    # the scalar pipe beside the vector one: a SIMD issues one scalar instruction per 4 cycles at best (16.3 cycles per
+                    # instruction with four waves per SIMD each running a dependent scalar chain: tests/probes/step_sync_probe.hip,
+                    # profiles/r03_step_sync_probe.jsonl), i.e. one per cycle per CU
+                    salu = float(pj["SQ_INSTS_SALU"]) / (k_ms * 1e-3)
+                    salu_peak = info["cus"] * clock_hz
+                    r["salu_issue"] = {"achieved": salu / 1e9, "peak": salu_peak / 1e9, "unit": "G SALU-instructions/s", "frac": salu / salu_peak,
+                                       "formula": "SQ_INSTS_SALU / (cus * kernel_s * clock_hz): one scalar issue per cycle per CU"}
+                    # SIMD issue slots taken by both pipes together if they did not overlap (VALU 2 cycles, SALU 4 cycles of a SIMD)
+                    r["simd_issue_frac_valu_plus_salu"] = (insts * 2.0 + float(pj["SQ_INSTS_SALU"]) * 4.0) / (simds * k_ms * 1e-3 * clock_hz)
+                    r["binding_pipe"] = "salu_issue" if r["salu_issue"]["frac"] > r["frac"] else "valu_issue"
         except Exception as exc:  # a malformed profile file must not break the bench line
             r["source_error"] = repr(exc)
     return r
@@ -505,9 +541,10 @@ def main():
                 extras["no_prune_multistart"] = {"candidates_per_s": s2.stats["candidates"] / (s2.stats["kernel_ms"] * 1e-3),
                                                  "kernel_ms": s2.stats["kernel_ms"], "best_cost": float(s2.total),
                                                  "note": "TL_FLAG_NO_PRUNE: every candidate decided with two fresh correctly rounded sqrt"}
-            dm, ms = TA.distance_matrix.build(np.arange(n), xy, ctx=ctx, return_ms=True)  # warm-up (workspace allocation)
+            for _ in range(3):  # warm-up: workspace allocation and first touch of its 200 MB, and the clock after the batches above
+                dm, ms = TA.distance_matrix.build(np.arange(n), xy, ctx=ctx, return_ms=True)
             dm_ms = []
-            for _ in range(5):
+            for _ in range(10):
                 dm, ms = TA.distance_matrix.build(np.arange(n), xy, ctx=ctx, return_ms=True)
                 dm_ms.append(ms)
             ms = float(np.mean(dm_ms))
@@ -569,7 +606,18 @@ def main():
             TA.three_opt.find_best_move(p3, nn3, ctx=ctx)
             ms3 = ctx.last_kernel_ms()
             tri = n3 * (n3 - 1) * (n3 - 2) // 6 - (n3 - 2)
-            extras["three_opt_scan_n1002"] = {"triples_per_s": tri / (ms3 * 1e-3), "kernel_ms": ms3, "triples": tri}
+            extras["three_opt_scan_n1002"] = {"triples_per_s": tri / (ms3 * 1e-3), "kernel_ms": ms3, "triples": tri,
+                                              "roofline": scan_valu_roofline("k_three_opt_scan", n3, ms3, info, clock_hz)}
+            if not a.no_cpu_baseline:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import _oracle as O
+                t0c = time.perf_counter()
+                omv = O.three_opt_find_best_move(p3.xy, None, np.asarray(nn3, dtype=np.uint32))
+                wc = time.perf_counter() - t0c
+                gmv = TA.three_opt.find_best_move(p3, nn3, ctx=ctx)
+                assert gmv[:4] == omv[:4] and np.float32(gmv[4]).tobytes() == np.float32(omv[4]).tobytes(), "3-opt scan differs from the oracle"
+                extras["three_opt_scan_n1002"]["cpu_baseline"] = {"value": tri / wc, "unit": "triples/s", "cores": 1, "kind": "port",
+                                                                  "sample": f"the same scan (one find_best_move over all {tri} triples of the NN tour, n = {n3}) by the oracle on one core; wall {wc:.2f} s; same move and savings bits as the GPU's (asserted)"}
             n5 = 5000
             p5 = TA.TspProblem(np.arange(n5), TA.synth.synth_xy(n5))
             nn5 = [int(v) for v in TA.nearest_neighbor.solve(p5, ctx=ctx).route()]
@@ -577,16 +625,48 @@ def main():
             TA.or_opt.find_best_move(p5, nn5, ctx=ctx)
             ms5 = ctx.last_kernel_ms()
             extras["or_opt_scan_n5000"] = {"placements_per_s": 6.0 * n5 * n5 / (ms5 * 1e-3), "kernel_ms": ms5,
-                                           "placements": 6 * n5 * n5, "note": "3 segment lengths x n starts x n insertion points x {fwd, rev} (or_opt.rs:80-164)"}
+                                           "placements": 6 * n5 * n5, "note": "3 segment lengths x n starts x n insertion points x {fwd, rev} (or_opt.rs:80-164)",
+                                           "roofline": scan_valu_roofline("k_or_scan", n5, ms5, info, clock_hz)}
+            if not a.no_cpu_baseline:
+                t0c = time.perf_counter()
+                omv5 = O.or_opt_find_best_move(p5.xy, None, np.asarray(nn5, dtype=np.uint32))
+                wc = time.perf_counter() - t0c
+                gmv5 = TA.or_opt.find_best_move(p5, nn5, ctx=ctx)
+                assert (gmv5 is None) == (omv5 is None) and (gmv5 is None or tuple(gmv5[:4]) == tuple(omv5[:4])), "Or-opt scan differs from the oracle"
+                extras["or_opt_scan_n5000"]["cpu_baseline"] = {"value": 6.0 * n5 * n5 / wc, "unit": "placements/s", "cores": 1, "kind": "port",
+                                                               "sample": f"the same scan (one find_best_move, n = {n5}, NN tour) by the oracle on one core; wall {wc:.2f} s; same move as the GPU's (asserted)"}
             # BASELINE configs[4] size: Lin-Kernighan ILS at n = 13 509 (synthetic points), candidate lists through the kd-tree
             n13 = 13509
             p13 = TA.TspProblem(np.arange(n13), TA.synth.synth_xy(n13))
             lk_opts = TA.LKOptions(TA.HeuristicOptions(epochs=20, platoo_epochs=10, n_nearest=5), 5)
             TA.lin_kernighan.solve(p13, lk_opts, ctx=ctx, seed=1)
             slk = TA.lin_kernighan.solve(p13, lk_opts, ctx=ctx, seed=1)
-            extras["lin_kernighan_n13509_20_epochs"] = {"kernel_ms": slk.stats["kernel_ms"], "total_ms": slk.stats["total_ms"], "cost": float(slk.total),
-                                                        "scans": slk.stats["sweeps"], "moves": slk.stats["moves"],
+            lk_ms, lk_rounds, lk_moves = slk.stats["kernel_ms"], slk.stats["sweeps"], slk.stats["moves"]
+            # What bounds a round: it is a chain of dependent latencies, not bytes or flops — two dependent kernel boundaries (scan ->
+            # step -> scan; 1.45 us each between trivial kernels: MI355X_MICROARCH.md price list, row "boundary") and, inside the
+            # scan, the longest walk's dependent L2 look-ups (max_depth 5 levels x 3 look-ups x ~200 cycles at the live clock).
+            lk_floor_us = 2 * 1.45 + 15 * 200.0 / max(clock_hz, 1.0) * 1e6
+            extras["lin_kernighan_n13509_20_epochs"] = {"kernel_ms": lk_ms, "total_ms": slk.stats["total_ms"], "cost": float(slk.total),
+                                                        "scans": lk_rounds, "moves": lk_moves, "moves_per_s": lk_moves / (lk_ms * 1e-3),
+                                                        "us_per_round": lk_ms * 1e3 / max(lk_rounds, 1),
+                                                        "roofline": {"bound": "dependent_latency", "achieved": lk_rounds / (lk_ms * 1e-3), "peak": 1e6 / lk_floor_us,
+                                                                     "unit": "rounds/s", "frac": lk_floor_us / (lk_ms * 1e3 / max(lk_rounds, 1)), "traffic": None,
+                                                                     "kernel": "k_lk_scan_sub + k_lk_control per round",
+                                                                     "formula": "peak = 1 / (2 x 1.45 us kernel boundary + 15 dependent L2 look-ups x 200 cycles / clock)",
+                                                                     "pmc": (json.load(open(latest_profile("r*_scans_pmc.json"))).get("k_lk_scan_sub") if latest_profile("r*_scans_pmc.json") else None)},
                                                         "note": "tl_lk incl. NN seed and k-NN lists; the same run is a golden-checked -m gpu test (tests/test_gpu_full_size.py)"}
+            if not a.no_cpu_baseline:
+                # CPU side of the same workload, bounded: ONE ILS epoch — a double-bridge kick of the GPU run's final tour, then the
+                # oracle's lk_pass (lin_kernighan.rs:454-481) to the next local optimum — on one core; unit: applied moves per second
+                final = np.asarray([int(v) for v in slk.route()], dtype=np.uint32)
+                cand13 = TA.lin_kernighan.build_candidates(p13, 5, ctx=ctx) if hasattr(TA.lin_kernighan, "build_candidates") else O.build_candidates_kdtree(p13.xy, 5)[0]
+                q13 = n13 // 4
+                kicked = O.double_bridge(final, q13 // 3, q13 // 2, q13 - 7)
+                t0c = time.perf_counter()
+                _, _, st_lk = O.lk_pass(p13.xy, kicked, np.asarray(cand13, dtype=np.uint32), 5)
+                wc = time.perf_counter() - t0c
+                extras["lin_kernighan_n13509_20_epochs"]["cpu_baseline"] = {"value": st_lk["moves"] / wc, "unit": "moves/s", "cores": 1, "kind": "port",
+                    "sample": f"one ILS epoch at n = {n13}: double-bridge kick of the GPU run's final tour, then the oracle's lk_pass to the next local optimum ({st_lk['moves']} moves, {st_lk['sweeps']} find_lk_move scans) on one core; wall {wc:.1f} s"}
         except Exception as exc:
             extras["error"] = repr(exc)
         out["extras"] = extras
