@@ -74,21 +74,27 @@ typedef enum tl_mode {
  * results are identical, only speed changes.  The library never reads the environment. */
 #define TL_FLAG_2OPT_FORCE_HBM (1u << 1)   /* tl_two_opt: the HBM-resident REF_ORDER variant (n > LDS limit) at every n      */
 #define TL_FLAG_LK_ONE_WORKGROUP (1u << 2) /* tl_lk: the whole ILS in one persistent workgroup instead of chip-wide scans  */
+#define TL_FLAG_KNN_BRUTE (1u << 10)       /* candidate lists: brute-force scan (sixteen lanes per city) in (distance, position)
+                                              order instead of the kd-tree walk — the same lists unless two candidates of a city
+                                              are at the same f32 distance (then the reference's order is the tree's visiting order) */
+#define TL_FLAG_2OPT_NT512 (1u << 14)      /* LDS 2-opt: every descent on 8 waves (default: only when two descents share a CU)   */
+#define TL_FLAG_2OPT_NT256 (1u << 15)      /* LDS 2-opt: every descent on 4 waves (default: only when four descents share a CU)  */
+#define TL_FLAG_2OPT_FX (1u << 16)         /* LDS 2-opt: the grid-coordinate form (5 B per point) wherever the instance lies on a decimal grid */
+/* TUNING BUILDS ONLY (libteeline_gpu_tune.so, -DTL_TUNE: `python -m teeline_amd.build --tune`).  Forms that were measured and
+ * rejected and stay as cross-checks for development; the product library does not carry them and tl_create
+ * returns TL_ERR_UNSUPPORTED if one of these bits is set. */
 #define TL_FLAG_LK_NO_SPLIT (1u << 3)      /* tl_lk: one lane per (t1, orientation) pair, no sub-search split               */
 #define TL_FLAG_LK_SPLIT2 (1u << 4)        /* tl_lk: two split levels (k(k+1) sub-searches per pair) instead of three       */
 #define TL_FLAG_LK_NO_SUBCHAINS (1u << 5)  /* tl_lk: the pick step walks the winning chain again instead of reading it      */
 #define TL_FLAG_KNN_4LANES (1u << 6)       /* candidate lists: brute force, four lanes per city                              */
 #define TL_FLAG_KNN_1LANE (1u << 7)        /* candidate lists: brute force, one lane per city                                */
-#define TL_FLAG_KNN_BRUTE (1u << 10)       /* candidate lists: brute-force scan (sixteen lanes per city) in (distance, position)
-                                              order instead of the kd-tree walk — the same lists unless two candidates of a city
-                                              are at the same f32 distance (then the reference's order is the tree's visiting order) */
+#define TL_FLAG_LK_SMALL (1u << 9)         /* tl_lk: the LDS-resident single-workgroup form at every n it fits               */
 #define TL_FLAG_LK_SEPARATE_PICK (1u << 11) /* tl_lk: pick and validate the pairs' first chains in a kernel of their own (k_lk_scan_pick) */
 #define TL_FLAG_LK_NO_GRAPH (1u << 12)      /* tl_lk: enqueue every round's kernels separately instead of replaying 64 rounds as one hipGraph */
 #define TL_FLAG_LK_SEPARATE_STEP (1u << 13) /* tl_lk: state machine (one workgroup) and tour rebuild as two kernels at every n */
-#define TL_FLAG_2OPT_NT512 (1u << 14)      /* LDS 2-opt: every descent on 8 waves (default: only when two descents share a CU)   */
-#define TL_FLAG_2OPT_NT256 (1u << 15)      /* LDS 2-opt: every descent on 4 waves (default: only when four descents share a CU)  */
-#define TL_FLAG_2OPT_FX (1u << 16)         /* LDS 2-opt: the grid-coordinate form (5 B per point) wherever the instance lies on a decimal grid */
-#define TL_FLAG_LK_SMALL (1u << 9)         /* tl_lk: the LDS-resident single-workgroup form (default for small n) at every n it fits */
+#define TL_TUNE_ONLY_FLAGS                                                                                                        \
+    (TL_FLAG_LK_NO_SPLIT | TL_FLAG_LK_SPLIT2 | TL_FLAG_LK_NO_SUBCHAINS | TL_FLAG_KNN_4LANES | TL_FLAG_KNN_1LANE | TL_FLAG_LK_SMALL | \
+     TL_FLAG_LK_SEPARATE_PICK | TL_FLAG_LK_NO_GRAPH | TL_FLAG_LK_SEPARATE_STEP)
 /* The LDS-resident 2-opt kernel also counts the work its exact decision cascade really does (d_out_stats words 5..8: tile
  * bounds, candidates into L1 / L2 / L3).  Same results; ~8 % slower (the kernel is SGPR-bound), so bench.py uses it for one
  * untimed launch only. */

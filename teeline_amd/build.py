@@ -68,6 +68,28 @@ def build_jitter(force=False):
     return build(extra_flags=["-DTL_JITTER"], out=JITTER_LIB)
 
 
+TUNE_LIB = os.path.join(HERE, "libteeline_gpu_tune.so")
+
+
+def build_tune(force=False):
+    """The tuning build of the same sources (-DTL_TUNE): also carries the kernel forms that were measured and rejected (the
+    TL_TUNE_ONLY_FLAGS of include/teeline_gpu.h) and reads TL_* knobs from the environment.  Test infrastructure: the variant
+    parity tests (tests/test_gpu_lk.py) run against it in a child process; never the product library."""
+    build()
+    if not force and os.path.exists(TUNE_LIB) and os.path.getmtime(TUNE_LIB) >= os.path.getmtime(LIB):
+        return TUNE_LIB
+    return build(extra_flags=["-DTL_TUNE"], out=TUNE_LIB)
+
+
+def build_all(force=False):
+    """Product library first, then the two test-infrastructure builds of the same sources side by side (each is a full hipcc run)."""
+    import concurrent.futures as cf
+    lib = build(force=force)
+    with cf.ThreadPoolExecutor(2) as ex:
+        j, t = ex.submit(build_jitter, force), ex.submit(build_tune, force)
+        return lib, j.result(), t.result()
+
+
 CLI = os.path.join(HERE, "teeline-gpu")
 CLI_SRC = os.path.join(HERE, "host_cpp", "teeline_gpu_cli.cpp")
 CLI_HDR = os.path.join(HERE, "host_cpp", "teeline_gpu.hpp")
@@ -86,9 +108,10 @@ def build_cli(force=False):
 
 
 if __name__ == "__main__":
-    if "--tune" in sys.argv:  # tuning variant: reads TL_* knobs from the environment (never the product library)
-        print(build(force=True, verbose=True, extra_flags=["-DTL_TUNE"], out=os.path.join(HERE, "libteeline_gpu_tune.so")))
+    if "--tune" in sys.argv:  # tuning variant: rejected kernel forms + TL_* knobs from the environment (never the product library)
+        print(build_tune(force=True))
         sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_cli(force="--force" in sys.argv))
     print(build_jitter(force="--force" in sys.argv))
+    print(build_tune(force="--force" in sys.argv))

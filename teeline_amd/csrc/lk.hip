@@ -1558,11 +1558,15 @@ hipError_t launch_knn(const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, 
         else hipLaunchKernelGGL((k_knn_quad<16, 4>), dim3(gq), dim3(256), 0, s, xy, n, k, cand);
         return hipGetLastError();
     }
+#ifdef TL_TUNE  // one lane per city: a rejected form, tuning build only
     const uint32_t grid = (n + 255u) / 256u;
     if (k <= 4) hipLaunchKernelGGL(k_knn<4>, dim3(grid), dim3(256), 0, s, xy, n, k, cand);
     else if (k <= 8) hipLaunchKernelGGL(k_knn<8>, dim3(grid), dim3(256), 0, s, xy, n, k, cand);
     else hipLaunchKernelGGL(k_knn<16>, dim3(grid), dim3(256), 0, s, xy, n, k, cand);
     return hipGetLastError();
+#else
+    return hipErrorInvalidValue;
+#endif
 }
 
 hipError_t launch_nn_seed(const float2 *xy, uint32_t n, const uint32_t *cand, uint32_t k, uint32_t *path, int lds_bytes, hipStream_t s)
@@ -1660,6 +1664,10 @@ hipError_t launch_lk_solve(const LkArgs &G, hipStream_t s, bool small, int threa
         hipLaunchKernelGGL((k_lk_solve<kLkNT, false>), dim3(1), dim3(kLkNT), 0, s, G);
         return hipGetLastError();
     }
+#ifndef TL_TUNE  // the LDS-resident form loses to the chip-wide scans at every size: tuning build only
+    (void)threads;
+    return hipErrorInvalidValue;
+#else
     const size_t lds = lk_small_lds_bytes(G.n, G.k);
     auto go = [&](auto kern, int nt) -> hipError_t {
         hipError_t e = allow_max_lds(reinterpret_cast<const void *>(kern));
@@ -1669,6 +1677,7 @@ hipError_t launch_lk_solve(const LkArgs &G, hipStream_t s, bool small, int threa
     };
     (void)threads;  // 64 / 256 / 1024 threads measured (scripts/timing_lk.py): 256 is the best of the three up to n ~ 300
     return go(k_lk_solve<256, true>, 256);
+#endif
 }
 
 }  // namespace tl

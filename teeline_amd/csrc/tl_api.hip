@@ -93,8 +93,10 @@ static bool is_permutation(const uint32_t *p, uint32_t n)  // validate_tour, src
 
 // ------------------------------------------------------------------------------------------------
 extern "C" int tl_abi_version(void) { return TL_ABI_VERSION; }
-#ifdef TL_JITTER
+#if defined(TL_JITTER)
 extern "C" const char *tl_version(void) { return "teeline-gpu 0.1 (gfx950) +jitter"; }  // race-stress build (tl_device.h)
+#elif defined(TL_TUNE)
+extern "C" const char *tl_version(void) { return "teeline-gpu 0.1 (gfx950) +tune"; }  // tuning build: rejected kernel forms included
 #else
 extern "C" const char *tl_version(void) { return "teeline-gpu 0.1 (gfx950)"; }
 #endif
@@ -118,6 +120,11 @@ extern "C" int tl_create(int device, uint32_t flags, tl_ctx **out)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(nullptr, TL_ERR_NO_DEVICE, "tl_create: device %d is %s; this library is built for gfx950 only",
                     device, prop.gcnArchName);
+#ifndef TL_TUNE
+    if (flags & TL_TUNE_ONLY_FLAGS)
+        return fail(nullptr, TL_ERR_UNSUPPORTED, "tl_create: flags 0x%x name kernel forms only the tuning build carries (libteeline_gpu_tune.so)",
+                    flags & TL_TUNE_ONLY_FLAGS);
+#endif
     tl_ctx *c = new tl_ctx();
     c->device = device;
     c->flags = flags;
@@ -1048,7 +1055,13 @@ extern "C" int tl_or_opt(tl_ctx *c, const float *xy, uint32_t n, const float *dm
 }
 
 static bool max_depth_ge2_split(uint32_t) { return true; }
-static int knn_form(const tl_ctx *c) { return (c->flags & TL_FLAG_KNN_1LANE) ? 1 : (c->flags & TL_FLAG_KNN_4LANES) ? 4 : 0; }
+// A tune-only create flag: always clear in the product build (tl_create refuses them), so the branches it selects fold away.
+#ifdef TL_TUNE
+static inline uint32_t tune_flags(const tl_ctx *c) { return c->flags; }
+#else
+static inline uint32_t tune_flags(const tl_ctx *) { return 0u; }
+#endif
+static int knn_form(const tl_ctx *c) { return (tune_flags(c) & TL_FLAG_KNN_1LANE) ? 1 : (tune_flags(c) & TL_FLAG_KNN_4LANES) ? 4 : 0; }
 
 // lin_kernighan::build_candidates (lin_kernighan.rs:12-27) into d_cand (n x k): the reference's kd-tree k-NN — tree built and
 // queried on the device (kdtree.hip) — or, under the TL_FLAG_KNN_* flags, the
@@ -1057,7 +1070,7 @@ static int knn_form(const tl_ctx *c) { return (c->flags & TL_FLAG_KNN_1LANE) ? 1
 static int build_candidates_dev(tl_ctx *c, const float *xy_host, const float2 *d_xy, uint32_t n, uint32_t k, uint32_t *d_cand)
 {
     if (k == 0) return TL_OK;
-    if (c->flags & (TL_FLAG_KNN_BRUTE | TL_FLAG_KNN_4LANES | TL_FLAG_KNN_1LANE)) {
+    if ((c->flags & TL_FLAG_KNN_BRUTE) | (tune_flags(c) & (TL_FLAG_KNN_4LANES | TL_FLAG_KNN_1LANE))) {
         HIPCHK(c, launch_knn(d_xy, n, k, d_cand, c->stream, knn_form(c)));
         return TL_OK;
     }
@@ -1210,22 +1223,23 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const float *dm_pac
     if (const char *e = getenv("TL_LK_SMALL_MAX_N")) small_max_n = (uint32_t)atoi(e);
     if (const char *e = getenv("TL_LK_SMALL_NT")) small_nt = atoi(e);
 #endif
+    const uint32_t tf = tune_flags(c);  // rejected forms: tuning build only
     const uint32_t variant_flags = TL_FLAG_LK_ONE_WORKGROUP | TL_FLAG_LK_NO_SPLIT | TL_FLAG_LK_SPLIT2 | TL_FLAG_LK_NO_SUBCHAINS | TL_FLAG_LK_SEPARATE_PICK | TL_FLAG_LK_NO_GRAPH | TL_FLAG_LK_SEPARATE_STEP;
-    const bool lk_small = ((c->flags & TL_FLAG_LK_SMALL) || (!(c->flags & variant_flags) && n <= small_max_n)) &&
+    const bool lk_small = ((tf & TL_FLAG_LK_SMALL) || (!((c->flags | tf) & variant_flags) && n <= small_max_n)) &&
                           lk_small_lds_bytes(n, k_small) + 4096 <= (size_t)c->lds_bytes;
     const bool multi_cu = !(c->flags & TL_FLAG_LK_ONE_WORKGROUP) && !lk_small;
     const size_t o_pairmin = o_chains + (multi_cu ? up((size_t)2 * n * lk_chain_slot_words() * 4) : 0);
-    const bool split_scan = multi_cu && max_depth_ge2_split(o.max_depth) && !(c->flags & TL_FLAG_LK_NO_SPLIT);
+    const bool split_scan = multi_cu && max_depth_ge2_split(o.max_depth) && !(tf & TL_FLAG_LK_NO_SPLIT);
     // every successful sub-search keeps its chain (64 B) so that the pick step does not walk the winner again; sized for
     // 288 GB of HBM (45 MB at n = 13 509, k = 5), skipped beyond 4 GB
     // three split levels (k(k+1)^2 sub-searches per pair: the sequential part of a walk shrinks to k^2 nodes) while their
     // kept chains fit 4 GB, else two
-    const uint32_t levels = (split_scan && !(c->flags & TL_FLAG_LK_SPLIT2) && (size_t)2 * n * k * (k + 1) * (k + 1) * 64 <= ((size_t)4 << 30)) ? 3u : 2u;
+    const uint32_t levels = (split_scan && !(tf & TL_FLAG_LK_SPLIT2) && (size_t)2 * n * k * (k + 1) * (k + 1) * 64 <= ((size_t)4 << 30)) ? 3u : 2u;
     const size_t sub_b = split_scan ? (size_t)2 * n * k * (k + 1) * (levels == 3u ? k + 1 : 1) * 64 : 0;
     // one workgroup per pair (k(k+1)^2 or k(k+1) <= 1024 threads): the scan picks and validates the pair's first chain itself
     const bool fused_pick = split_scan && (size_t)k * (k + 1) * (levels == 3u ? k + 1 : 1) <= 1024 &&
-                            !(c->flags & (TL_FLAG_LK_SEPARATE_PICK | TL_FLAG_LK_NO_SUBCHAINS));
-    const bool keep_sub = split_scan && !fused_pick && sub_b <= ((size_t)4 << 30) && !(c->flags & TL_FLAG_LK_NO_SUBCHAINS);
+                            !(tf & (TL_FLAG_LK_SEPARATE_PICK | TL_FLAG_LK_NO_SUBCHAINS));
+    const bool keep_sub = split_scan && !fused_pick && sub_b <= ((size_t)4 << 30) && !(tf & TL_FLAG_LK_NO_SUBCHAINS);
     const size_t o_sub = o_pairmin + (split_scan ? up((size_t)2 * n * 4) : 0);
     const size_t total = o_sub + (keep_sub ? up(sub_b) : 0);
     if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->work, total)) || (rc = ensure(c, c->out_cost, 4))) return rc;
@@ -1276,7 +1290,7 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const float *dm_pac
     G.subchains = keep_sub ? (uint32_t *)(w + o_sub) : nullptr;
     G.split_levels = levels;
     G.fused_pick = fused_pick ? 1u : 0u;
-    G.chip_step = (fused_pick && levels == 3u && n >= 1500u && !(c->flags & TL_FLAG_LK_SEPARATE_STEP)) ? 1u : 0u;
+    G.chip_step = (fused_pick && levels == 3u && n >= 1500u && !(tf & TL_FLAG_LK_SEPARATE_STEP)) ? 1u : 0u;
     if (split_scan) HIPCHK(c, hipMemsetAsync(G.pairmin, 0xFF, (size_t)2 * n * 4, c->stream));
     uint64_t cnt[4] = {0, 0, 0, 0};
     if (!multi_cu) {
@@ -1290,7 +1304,7 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const float *dm_pac
         // enqueued kernels are a visible part of it.
         hipGraph_t graph = nullptr;
         hipGraphExec_t gexec = nullptr;
-        bool first = true, graph_ok = !(c->flags & TL_FLAG_LK_NO_GRAPH);
+        bool first = true, graph_ok = !(tf & TL_FLAG_LK_NO_GRAPH);
         int rc_loop = TL_OK;
         for (;;) {
             if (!first && graph_ok && !gexec) {

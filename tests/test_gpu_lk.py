@@ -41,7 +41,16 @@ def test_candidate_lists(ctx, k, tsplib_dir):
         assert got.shape == want.shape and np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("flag", ["TL_FLAG_KNN_BRUTE", "TL_FLAG_KNN_4LANES", "TL_FLAG_KNN_1LANE"])
+def _on_tune_build():
+    import teeline_amd as TA
+    return TA._capi.load().tl_version().decode().endswith("+tune")
+
+
+TUNE_ONLY = pytest.mark.skipif("not _on_tune_build()", reason="rejected kernel forms: only libteeline_gpu_tune.so carries them "
+                                                              "(test_rejected_forms_on_the_tune_build runs these in a child process)")
+
+
+@pytest.mark.parametrize("flag", ["TL_FLAG_KNN_BRUTE", pytest.param("TL_FLAG_KNN_4LANES", marks=TUNE_ONLY), pytest.param("TL_FLAG_KNN_1LANE", marks=TUNE_ONLY)])
 def test_candidate_list_builders_agree(flag):
     # the brute-force builders (TL_FLAG_KNN_BRUTE: sixteen lanes per city; _4LANES; _1LANE) scan in position order: the
     # oracle's scan lists (ascending f32 distance, ties -> lowest position), duplicates included — and the kd-tree walk's
@@ -147,6 +156,36 @@ def test_lk_wide_candidate_lists(ctx):
                     O.lin_kernighan(xy, seed=3, epochs=6, n_nearest=k, max_depth=depth))
 
 
+def test_product_library_refuses_tune_only_flags():
+    # the forms DESIGN §4.6 measured and rejected are not in the product library
+    import teeline_amd as TA
+    if _on_tune_build():
+        pytest.skip("this process runs on the tuning build")
+    for flag in (TA.TL_FLAG_LK_NO_SPLIT, TA.TL_FLAG_LK_SPLIT2, TA.TL_FLAG_LK_NO_SUBCHAINS, TA.TL_FLAG_LK_SMALL, TA.TL_FLAG_LK_SEPARATE_PICK,
+                 TA.TL_FLAG_LK_NO_GRAPH, TA.TL_FLAG_LK_SEPARATE_STEP, TA.TL_FLAG_KNN_4LANES, TA.TL_FLAG_KNN_1LANE):
+        with pytest.raises(TA.TeelineGpuError) as e:
+            TA.Context(0, flag)
+        assert e.value.code == TA._capi.TL_ERR_UNSUPPORTED
+
+
+def test_rejected_forms_on_the_tune_build():
+    # the cross-checks of the rejected forms (the two tests marked TUNE_ONLY / test_lk_variants_are_identical) against the oracle,
+    # in ONE child process bound to libteeline_gpu_tune.so (a process binds one library)
+    import subprocess
+    import sys
+    if _on_tune_build():
+        pytest.skip("already the child")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tune = os.path.join(root, "teeline_amd", "libteeline_gpu_tune.so")
+    assert os.path.exists(tune), "built by __graft_entry__.build() / python -m teeline_amd.build"
+    env = dict(os.environ, TEELINE_GPU_LIB=tune)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
+                        "variants_are_identical or builders_agree"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], r.stdout[-500:]
+
+
+@TUNE_ONLY
 def test_lk_variants_are_identical(tsplib_dir):
     # default = scans spread over all CUs, each pair's chain search split into k*(k+1)^2 sub-searches (TL_FLAG_LK_SPLIT2: k*(k+1)), device-side control
     # state machine, the pair's first chain picked and validated by the scan workgroup itself (TL_FLAG_LK_SEPARATE_PICK: by a kernel of
