@@ -1,6 +1,7 @@
 #!/bin/bash
 # SQ counters of the scan kernels bench.py's extras report (3-opt scan n = 1002, Or-opt scan n = 5000, LK n = 13 509): one rocprofv3
-# --pmc pass each (+ --kernel-trace only), summarised into profiles/<round>_scans_pmc.json.   bash scripts/pmc_scans.sh r03
+# --pmc pass each (+ --kernel-trace only), summarised into gpurun_out/<round>/scans_pmc.json (copy it to profiles/<round>_scans_pmc.json).
+#   bash scripts/pmc_scans.sh r03
 R=${1:-r03}
 OUT=$PWD/gpurun_out/$R/scans
 mkdir -p $OUT
@@ -9,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 CNT="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CU_CYCLES SQ_WAVES"
 timeout -k 10 200 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $OUT/scans -- python3 $REPO/scripts/scan_once.py scans > $OUT/scans.log 2>&1 \
 && timeout -k 10 300 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $OUT/lk -- python3 $REPO/scripts/scan_once.py lk > $OUT/lk.log 2>&1
-python3 - $OUT $REPO/profiles/${R}_scans_pmc.json <<'PY'
+python3 - $OUT $OUT/../scans_pmc.json <<'PY'
 import csv, glob, json, sys, collections
 out = {}
 def load(sub):

@@ -59,8 +59,42 @@ __device__ __forceinline__ void pt_put(const PtsFx &P, uint32_t k, PtsFx::Raw r)
     P.hi[k] = (uint8_t)r.hi;
 }
 
+// ---- whole-wave maximum of u32 keys in 6 DPP steps, result in lane 63 (no LDS, no readlane): row_shr 1, 2, 4, 8 leave each row's
+// maximum in its lane 15 (max is idempotent, so the overlapping windows do no harm), row_bcast15 / row_bcast31 carry it on to the
+// rows above.  Lanes without a DPP source read 0, the identity of an unsigned maximum.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dpp_max_step(uint32_t v)
+{
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, true);
+    return v > o ? v : o;
+}
+__device__ __forceinline__ uint32_t wave_max_key_lane63(uint32_t v)
+{
+    v = dpp_max_step<0x111, 0xf>(v);
+    v = dpp_max_step<0x112, 0xf>(v);
+    v = dpp_max_step<0x114, 0xf>(v);
+    v = dpp_max_step<0x118, 0xf>(v);
+    v = dpp_max_step<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
+    v = dpp_max_step<0x143, 0xc>(v);  // row_bcast31 into rows 2 and 3
+    return v;
+}
+// f32 <-> u32 key with the same order (negative floats: all bits flipped; others: sign bit set)
+__device__ __forceinline__ uint32_t fkey(float f)
+{
+    const uint32_t b = __builtin_bit_cast(uint32_t, f);
+    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k)
+{
+    return __builtin_bit_cast(float, k ^ ((k & 0x80000000u) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
 // L0 metadata of tile t: bounding box of P[64t .. 64t+64] over the positions that take part in a
 // candidate (j <= n-2 as c, j+1 as e) and the largest squared tour-edge sq(P[j],P[j+1]) in it.
+// Five wave reductions on order-preserving integer keys (minima as maxima of the inverted key), each 6 DPP-fused v_max_u32;
+// lane 63 ends up with all five and stores them.  (The float form — v_min/v_max_f32 with their NaN canonicalisation, four
+// readlanes and three scalar min/max per reduction — was ~150 instructions per tile; this is ~70.)  A NaN coordinate is left out
+// of the box as before (v_min/v_max_f32 return the other operand).
 template <typename PT>
 __device__ __forceinline__ void build_tile_meta(const PT &P, uint32_t n, uint32_t t, int lane, float4 *tbox, float *tmsq)
 {
@@ -68,12 +102,17 @@ __device__ __forceinline__ void build_tile_meta(const PT &P, uint32_t n, uint32_
     const bool valid = j + 2u <= n;  // j <= n-2
     const float2 c = pt_get(P, j), e = pt_get(P, j + 1u);
     const float inf = __builtin_inff();
-    const float mnx = wave_min(valid ? fminf(c.x, e.x) : inf), mny = wave_min(valid ? fminf(c.y, e.y) : inf);
-    const float mxx = wave_max(valid ? fmaxf(c.x, e.x) : -inf), mxy = wave_max(valid ? fmaxf(c.y, e.y) : -inf);
-    const float msq = wave_max(valid ? sqdist(c, e) : -1.0f);
-    if (lane == 0) {
-        tbox[t] = make_float4(mnx, mny, mxx, mxy);
-        tmsq[t] = msq;
+    // invalid lanes: +inf for the minima, -inf for the maxima, 0 for the largest edge (all-invalid tile: an empty box, never live)
+    const uint32_t kmnx = ~fkey(valid ? fminf(fminf(c.x, e.x), inf) : inf), kmny = ~fkey(valid ? fminf(fminf(c.y, e.y), inf) : inf);
+    const uint32_t kmxx = fkey(valid ? fmaxf(fmaxf(c.x, e.x), -inf) : -inf), kmxy = fkey(valid ? fmaxf(fmaxf(c.y, e.y), -inf) : -inf);
+    const float sq = sqdist(c, e);
+    const uint32_t kmsq = (valid && sq == sq) ? __builtin_bit_cast(uint32_t, sq) : 0u;  // squares are >= +0: their bits order like u32
+    const uint32_t rmnx = wave_max_key_lane63(kmnx), rmny = wave_max_key_lane63(kmny);
+    const uint32_t rmxx = wave_max_key_lane63(kmxx), rmxy = wave_max_key_lane63(kmxy);
+    const uint32_t rmsq = wave_max_key_lane63(kmsq);
+    if (lane == 63) {
+        tbox[t] = make_float4(fkey_inv(~rmnx), fkey_inv(~rmny), fkey_inv(rmxx), fkey_inv(rmxy));
+        tmsq[t] = __builtin_bit_cast(float, rmsq);
     }
 }
 

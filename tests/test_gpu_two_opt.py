@@ -445,3 +445,25 @@ def test_grid_coordinate_form_matches_the_oracle_where_the_instance_lies_on_a_gr
                    rng.integers(0, 1 << 22, (500, 2)).astype(np.float32)):
             n = len(xy)
             assert_same(gpu_two_opt(c2, xy, None, n, None), O.two_opt(xy, None, n), n)
+
+
+def test_pr1002_like_lattice_ties(ctx):
+    # pr1002 (BASELINE configs[1]; not in the reference tree) is a drilled-board instance: points on a coarse grid, so equal
+    # distances — and candidates whose two sums tie exactly, which the reference's strict `<` (two_opt.rs:49) must leave alone —
+    # are everywhere.  A 31 x 32 lattice with some sites dropped (n = 962..992) in shuffled, row-major and NN order; coordinate
+    # form, matrix form in HBM and the un-pruned form against the oracle.
+    import teeline_amd as TA
+    rng = np.random.default_rng(1002)
+    g = np.stack(np.meshgrid(np.arange(32, dtype=np.float32) * 100.0, np.arange(31, dtype=np.float32) * 100.0), -1).reshape(-1, 2)
+    for drop in (0, 30):
+        keep = np.sort(rng.permutation(len(g))[: len(g) - drop])
+        pts = np.ascontiguousarray(g[keep])
+        n = len(pts)
+        packed = O.dm_build_packed(pts)
+        rc, nn, _ = O.nearest_neighbor(pts, None, n, 3)
+        for init in (None, rng.permutation(n).astype(np.uint32), nn):
+            want = O.two_opt(pts, None, n, init=init)
+            assert_same(gpu_two_opt(ctx, pts, None, n, init), want, n)
+            assert_same(gpu_two_opt(ctx, None, packed, n, init), want, n)
+        with TA.Context(0, TA.TL_FLAG_NO_PRUNE) as c2:
+            assert_same(gpu_two_opt(c2, pts, None, n, None), O.two_opt(pts, None, n), n)
