@@ -18,12 +18,20 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 // fl(fl(dx*dx) + fl(dy*dy)): written on 2-vectors so that it becomes v_pk_add_f32, v_pk_mul_f32, v_add_f32 — the same
 // three roundings per component as the scalar form, no operand shuffling.
+// The final add is a plain v_add_f32 written as inline asm: left to itself the SLP vectoriser packs the adds of two neighbouring
+// sqdist calls into one v_pk_add_f32 and pays three v_mov to line the operands up (seen in every tile pass of the 2-opt kernels).
+__device__ __forceinline__ float add_f32_nopack(float x, float y)
+{
+    float r;
+    asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
 __device__ __forceinline__ float sqdist(float2 p, float2 q)
 {
     const v2f a = {p.x, p.y}, b = {q.x, q.y};
     v2f d = a - b;
     d = d * d;
-    return d.x + d.y;
+    return add_f32_nopack(d.x, d.y);
 }
 
 // Correctly rounded f32 sqrt, the compiler's way: hipcc (-fhip-fp32-correctly-rounded-divide-sqrt, default on)

@@ -119,14 +119,22 @@ __device__ __forceinline__ void build_tile_meta(const PT &P, uint32_t n, uint32_
 // f32 lower bound of sqdist(p, q) over every q inside the box (monotone ops only -> valid in f32).
 // d = max(lo - p, p - hi, 0) is taken on the bit patterns as signed ints: negative floats are negative
 // ints and non-negative floats order like ints, so one v_max3_i32 does it without NaN canonicalisation.
+// Written on (x, y) pairs — lo - p and p - hi are the two halves of the float4 as it is loaded — so that it becomes two
+// v_pk_add_f32, two v_max3_i32, one v_pk_mul_f32 and one add with no operand shuffling (paired the other way, a's and b's bounds
+// together, every box component is needed twice: 36 v_mov per pruned step and wave).
 __device__ __forceinline__ float box_lb(float px, float py, float4 box)
 {
-    const int ux = __builtin_bit_cast(int, box.x - px), vx = __builtin_bit_cast(int, px - box.z);
-    const int uy = __builtin_bit_cast(int, box.y - py), vy = __builtin_bit_cast(int, py - box.w);
+    const v2f p = {px, py}, lo = {box.x, box.y}, hi = {box.z, box.w};
+    const v2f u = lo - p, v = p - hi;
+    // (through float temporaries: __builtin_bit_cast applied to an ext-vector ELEMENT, `bit_cast(int, u.y)`, reads element 0 with
+    //  hipcc 7.2 — the y half of the bound silently became a copy of the x half)
+    const float uxf = u.x, uyf = u.y, vxf = v.x, vyf = v.y;
+    const int ux = __builtin_bit_cast(int, uxf), vx = __builtin_bit_cast(int, vxf);
+    const int uy = __builtin_bit_cast(int, uyf), vy = __builtin_bit_cast(int, vyf);
     const int mx = ux > vx ? ux : vx, my = uy > vy ? uy : vy;
-    const float dx = __builtin_bit_cast(float, mx > 0 ? mx : 0);
-    const float dy = __builtin_bit_cast(float, my > 0 ? my : 0);
-    return dx * dx + dy * dy;
+    v2f d = {__builtin_bit_cast(float, mx > 0 ? mx : 0), __builtin_bit_cast(float, my > 0 ? my : 0)};
+    d = d * d;
+    return add_f32_nopack(d.x, d.y);
 }
 
 #ifndef TL_DENSE_LEAD
@@ -156,6 +164,8 @@ struct NoCounts {
 // The improving columns of row (a, b) inside one 64-wide j tile (lane l holds c = P[tb+l], e = P[tb+l+1]) as a lane mask,
 // decided by the L1 -> L2 -> L3 cascade.  Straight-line code, every branch wave-uniform, the result in SGPRs.
 // sqab = sq(a, b) is a row constant the caller already holds.
+// (The logic runs on 64-bit lane masks — every ballot below is taken of a plain comparison, i.e. is the v_cmp itself, and the
+// and / or / not are scalar instructions; a ballot of a boolean expression costs a v_cndmask + v_cmp_ne pair on top.)
 template <bool PRUNE, typename TC>
 __device__ __forceinline__ uint64_t tile_mask_core(float2 c, float2 e, uint32_t j, uint32_t n, uint32_t jmin,
                                                    float ax, float ay, float bx, float by, float sqab, TC &tc)
@@ -163,25 +173,23 @@ __device__ __forceinline__ uint64_t tile_mask_core(float2 c, float2 e, uint32_t 
     const float sqce = sqdist(c, e);
     const float s1 = sqdist(make_float2(ax, ay), c);
     const float s2 = sqdist(make_float2(bx, by), e);
-    bool test = (j - jmin) <= (n - 2u - jmin);  // jmin <= j <= n-2 in one unsigned compare (callers keep jmin <= n-2)
-    bool imp;
+    const uint64_t m_rng = __builtin_amdgcn_ballot_w64((j - jmin) <= (n - 2u - jmin));  // jmin <= j <= n-2 in one unsigned compare (callers keep jmin <= n-2)
     if (PRUNE) {
-        tc.l1 += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(test));
-        test = test & ((s1 < sqab) | (s2 < sqce));                       // L1
-        const uint64_t m1 = __builtin_amdgcn_ballot_w64(test);
+        tc.l1 += (uint32_t)__builtin_popcountll(m_rng);
+        const uint64_t m1 = m_rng & (__builtin_amdgcn_ballot_w64(s1 < sqab) | __builtin_amdgcn_ballot_w64(s2 < sqce));  // L1
         if (!m1) return 0;                                               // the common case late in a sweep
         tc.l2 += (uint32_t)__builtin_popcountll(m1);
         const float neu_a = __builtin_amdgcn_sqrtf(s1) + __builtin_amdgcn_sqrtf(s2);  // L2
         const float cur_a = __builtin_amdgcn_sqrtf(sqab) + __builtin_amdgcn_sqrtf(sqce);
         const float margin = cur_a * 1.9073486e-6f;                      // 2^-19
-        imp = test & (neu_a < cur_a - margin);
+        uint64_t m_imp = m1 & __builtin_amdgcn_ballot_w64(neu_a < cur_a - margin);
         // near-ties, tiny squares (v_sqrt_f32 loses accuracy on denormals) and non-finite sums go to L3.  Squares are
         // >= +0, so their bit patterns order like unsigned ints (a NaN compares high and is caught through cur_a, or
         // makes neu_a NaN, which L2 and the reference both read as "not improving").
         const uint32_t smin = min(min(__builtin_bit_cast(uint32_t, s1), __builtin_bit_cast(uint32_t, sqce)),
                                   min(__builtin_bit_cast(uint32_t, s2), __builtin_bit_cast(uint32_t, sqab)));
-        const bool tie = test & !imp & ((neu_a <= cur_a + margin) | (smin < 0x0DA24260u /* 1e-30f */) | !(cur_a < 3.0e38f));
-        const uint64_t mt = __builtin_amdgcn_ballot_w64(tie);
+        const uint64_t mt = (m1 & ~m_imp) & (__builtin_amdgcn_ballot_w64(neu_a <= cur_a + margin) | __builtin_amdgcn_ballot_w64(smin < 0x0DA24260u /* 1e-30f */) |
+                                             ~__builtin_amdgcn_ballot_w64(cur_a < 3.0e38f));
         if (mt) {                                                        // L3
             tc.l3 += (uint32_t)__builtin_popcountll(mt);
             // the opaque copies keep the compiler from hoisting the loop-invariant exact roots into a tile or row
@@ -190,15 +198,15 @@ __device__ __forceinline__ uint64_t tile_mask_core(float2 c, float2 e, uint32_t 
             asm volatile("" : "+v"(s1v), "+v"(scev), "+v"(sabv));
             const float neu = sqrt_rn(s1v) + sqrt_rn(s2);
             const float cur = sqrt_rn(sabv) + sqrt_rn(scev);
-            imp = tie ? (neu < cur) : imp;
+            m_imp = (m_imp & ~mt) | (mt & __builtin_amdgcn_ballot_w64(neu < cur));
         }
+        return m_imp;
     } else {
-        tc.l3 += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(test));
+        tc.l3 += (uint32_t)__builtin_popcountll(m_rng);
         const float neu = sqrt_rn(s1) + sqrt_rn(s2);
         const float cur = sqrt_rn(sqab) + sqrt_rn(sqce);
-        imp = test & (neu < cur);  // two_opt.rs:35-49
+        return m_rng & __builtin_amdgcn_ballot_w64(neu < cur);  // two_opt.rs:35-49
     }
-    return __builtin_amdgcn_ballot_w64(imp);
 }
 
 template <bool PRUNE, typename TC, typename PT>

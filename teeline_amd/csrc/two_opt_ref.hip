@@ -660,33 +660,30 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                     const float rsqab = readlane_f(rowsq, r);
                     const uint32_t jmin = (r == 0) ? j0 : (i + 2u);
                     const uint32_t tmin = jmin >> 6;
-                    bool row_hit = false;
+                    uint64_t hm = 0;
+                    uint32_t t = 0;
                     tc.prow += 1u;
 #pragma unroll
                     for (int gI = 0; gI < kMaxGroups; ++gI) {
                         if (gI < G && (((uint32_t)gI + 1u) << 6) > tmin) {  // groups wholly before the row's first column: nothing to test
                             const uint32_t tl = ((uint32_t)gI << 6) + (uint32_t)lane;
-                            const bool near_a = box_lb(rax, ray, box[gI]) < rsqab, near_b = box_lb(rbx, rby, box[gI]) < msq[gI];
-                            const bool live = (tl >= tmin) & (near_a | near_b);  // no short-circuit: both bounds are cheaper than a branch
+                            // live tiles of the group as a lane mask: every ballot is a comparison's own result, the rest is scalar
+                            uint64_t m = __builtin_amdgcn_ballot_w64(tl >= tmin) &
+                                         (__builtin_amdgcn_ballot_w64(box_lb(rax, ray, box[gI]) < rsqab) | __builtin_amdgcn_ballot_w64(box_lb(rbx, rby, box[gI]) < msq[gI]));
                             tc.l0 += 64u;
-                            uint64_t m = __builtin_amdgcn_ballot_w64(live);
-                            uint64_t hm = 0;
-                            uint32_t t = 0;
                             while (m != 0) {  // later tiles of this row are later columns
                                 t = ((uint32_t)gI << 6) + (uint32_t)(__builtin_ffsll((long long)m) - 1);
                                 m &= m - 1;
                                 tc.ptile += 1u;
                                 hm = tile_improving_mask<PRUNE>(P, n, t << 6, jmin, rax, ray, rbx, rby, rsqab, lane, tc);
-                                if (hm) break;
-                            }
-                            if (hm) {
-                                if (lane == 0) atomicMin(keyslot, (i << 16) | ((t << 6) + (uint32_t)(__builtin_ffsll((long long)hm) - 1)));
-                                row_hit = true;
+                                if (hm) goto row_hit;
                             }
                         }
-                        if (row_hit) break;
                     }
-                    if (row_hit) break;  // rows w+NWK, ... are later rows
+                    continue;  // nothing in this row: rows w+NWK, ... next
+                row_hit:
+                    if (lane == 0) atomicMin(keyslot, (i << 16) | ((t << 6) + (uint32_t)(__builtin_ffsll((long long)hm) - 1)));
+                    break;  // rows w+NWK, ... are later rows
                 }
             }
             TL_SYNC();  // B2
