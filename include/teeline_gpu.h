@@ -96,8 +96,9 @@ typedef enum tl_mode {
     (TL_FLAG_LK_NO_SPLIT | TL_FLAG_LK_SPLIT2 | TL_FLAG_LK_NO_SUBCHAINS | TL_FLAG_KNN_4LANES | TL_FLAG_KNN_1LANE | TL_FLAG_LK_SMALL | \
      TL_FLAG_LK_SEPARATE_PICK | TL_FLAG_LK_NO_GRAPH | TL_FLAG_LK_SEPARATE_STEP)
 /* The LDS-resident 2-opt kernel also counts the work its exact decision cascade really does (d_out_stats words 5..8: tile
- * bounds, candidates into L1 / L2 / L3).  Same results; ~8 % slower (the kernel is SGPR-bound), so bench.py uses it for one
- * untimed launch only. */
+ * bounds, candidates into L1 / L2 / L3).  Same results; slower (the counters are live scalar registers), so bench.py uses it for one
+ * untimed launch only.  Counted: the form of one descent per CU (16 waves, float2 points); the narrower and the
+ * grid-coordinate forms run uncounted (words 5..8 stay 0). */
 #define TL_FLAG_COUNT_WORK (1u << 8)
 
 /* matrix layouts for tl_dm_build */

@@ -845,7 +845,11 @@ static hipError_t launch_one(const TwoOptBatchArgs &A, uint32_t count, size_t ld
 template <int NT, bool FX>
 static hipError_t launch_nt(const TwoOptBatchArgs &B, uint32_t count, size_t lds, bool prune, bool count_work, hipStream_t s)
 {
-    if (count_work) return prune ? launch_one<NT, true, true, FX>(B, count, lds, s) : launch_one<NT, false, true, FX>(B, count, lds, s);
+    // the counting instantiation (TL_FLAG_COUNT_WORK) exists for the form bench.py counts — one descent per CU on 16 waves, plain
+    // points; the narrower / grid-coordinate forms run uncounted (stats words 5..8 stay 0): 14 instantiations to compile, not 24
+    if constexpr (NT == TL_TWO_OPT_NT && !FX) {
+        if (count_work) return prune ? launch_one<NT, true, true, FX>(B, count, lds, s) : launch_one<NT, false, true, FX>(B, count, lds, s);
+    }
     return prune ? launch_one<NT, true, false, FX>(B, count, lds, s) : launch_one<NT, false, false, FX>(B, count, lds, s);
 }
 
