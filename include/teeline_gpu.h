@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define TL_ABI_VERSION 2
+#define TL_ABI_VERSION 3
 
 typedef struct tl_ctx tl_ctx;
 
@@ -196,6 +196,19 @@ int tl_or_opt(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed, 
 /* One find_best_move scan (or_opt.rs:80-164): (delta, seg_start i, insert_after j, seg_len, reversed). */
 int tl_or_opt_find_best_move(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *path,
                              int *found, float *delta, uint32_t *i, uint32_t *j, uint32_t *seg_len, int *reversed);
+
+/* ---- two_opt::solve with the applied moves listed (the reference's progress side channel) ----- */
+/* two_opt.rs:22-24,30-32,53-56,63-65 sends PathUpdate(start), CityChange(path[i]) per outer i of every sweep, PathUpdate(path,
+ * new_distance) per improving move and Done — to the one caller that passes a channel (teeline-qt).  The descent runs as one
+ * kernel launch, so the messages cannot be sent while it runs; this entry returns, beside tl_two_opt's results (REF_ORDER,
+ * coordinates), the list of the moves in the order the reference applies them — move_log[m] = (i << 16) | j for
+ * swap_2opt(path, i+1, j), and the word TL_TRACE_SWEEP (0xFFFFFFFF) where a new sweep begins (a row can hold moves of two
+ * consecutive sweeps back to back) — from which the caller replays the reference's exact message sequence (every path, every
+ * new_distance = d(p[i],p[j]) + d(p[i+1],p[j+1])) after the fact.  *log_len = words = stats->moves + stats->sweeps - 1; if it exceeds
+ * log_cap the log holds the first log_cap words.  n beyond the LDS-resident descent (tl_two_opt_lds_max_n) or > 65535: TL_ERR_UNSUPPORTED. */
+#define TL_TRACE_SWEEP 0xFFFFFFFFu
+int tl_two_opt_trace(tl_ctx *ctx, const float *xy, uint32_t n, const uint32_t *init_pos, uint32_t *out_pos, float *out_cost,
+                     tl_stats *stats, uint32_t *move_log, uint32_t log_cap, uint32_t *log_len);
 
 /* ---- LK candidate lists: replaces lin_kernighan::build_candidates (lin_kernighan.rs:12-27) -- */
 /* out: n x min(k, n-1) u32 — the k-NN buffer of the reference's kd-tree query per city (kdtree.rs:193-212, mod.rs:1839-1889):

@@ -12,7 +12,8 @@
 //! computed by `DistanceMatrix::tour_length` itself.
 //!
 //! Behaviour that differs from the CPU functions, all of it documented in INTEGRATION.md:
-//!   * progress: `PathUpdate` at the start, one `PathUpdate` with the final tour, `Done` (2-opt/3-opt/or-opt), instead
+//!   * progress: two_opt replays the reference's exact messages (CityChange per outer i, PathUpdate per move) from the move list of
+//!     `tl_two_opt_trace` after the kernel returns; elsewhere `PathUpdate` at the start, one `PathUpdate` with the final tour, `Done` (3-opt/or-opt), instead
 //!     of one message per outer index / move — only the Qt front-end passes a sender;
 //!   * a library error (no gfx950 device, HIP failure) panics with the library's message, like the `.expect(..)`s of the CPU
 //!     code do on bad input: the solver functions are infallible by signature;
@@ -102,11 +103,56 @@ pub mod two_opt {
         if let Some(tx) = progress_tx {
             let _ = tx.send(ProgressMessage::PathUpdate(Route::new(&start_tour(problem, init_tour)), 0.0));
         }
+        // With a progress channel (only teeline-qt passes one) the descent also lists its moves, and the reference's exact
+        // message sequence is replayed from them once the kernel is back (the descent is ONE launch: nothing can be sent
+        // while it runs).  Coordinates only; matrix problems and tours beyond the LDS-resident descent fall back to the
+        // final PathUpdate.
+        if let Some(tx) = progress_tx {
+            let traced = ffi::with_context(|ctx| if io.matrix(ctx)?.is_none() { ctx.two_opt_trace(&io.xy, init.as_deref()).map(Some) } else { Ok(None) });
+            if let Ok(Some((t, moves))) = traced {
+                replay_progress(problem, &io, init.as_deref(), &moves, t.stats.sweeps, tx);
+                let route = io.ids(&t.pos);
+                let sol = Solution::new(&route, problem);
+                debug_assert_eq!(sol.total.to_bits(), t.cost.to_bits(), "device total differs from DistanceMatrix::tour_length");
+                let _ = tx.send(ProgressMessage::Done);
+                return sol;
+            }
+        }
         let t = unwrap_gpu("two_opt (gpu)", ffi::with_context(|ctx| {
             let dm = io.matrix(ctx)?;
             ctx.two_opt(&io.xy, dm, init.as_deref(), ffi::MODE_REF_ORDER)
         }));
         finish(problem, &io, &t, progress_tx, true)
+    }
+
+    /// two_opt.rs:26-61 as messages: per sweep and outer `i` a `CityChange(path[i])` (:30-32); per move `(i, j)` the reversal
+    /// of `path[i+1..=j]` and `PathUpdate(path, new_distance)` with `new_distance = d(p[i],p[j]) + d(p[i+1],p[j+1])` taken on the
+    /// path before the move through `problem.distances` (:42-56) — the f32 sum the reference has just compared.
+    fn replay_progress(problem: &TspProblem, io: &Boundary, init: Option<&[u32]>, moves: &[Option<(u32, u32)>], sweeps: u64,
+                       tx: &mpsc::Sender<ProgressMessage>) {
+        let n = problem.cities.len();
+        let mut pos: Vec<u32> = init.map(|p| p.to_vec()).unwrap_or_else(|| (0..n as u32).collect());
+        let d = |p: u32, q: u32| problem.distances.distance_by_pos(p as usize, q as usize).expect("two_opt: invalid city pair");
+        let mut k = 0usize;
+        for _ in 0..sweeps {
+            for i in 0..n.saturating_sub(3) {
+                let _ = tx.send(ProgressMessage::CityChange(io.ids(&pos[i..=i])[0]));
+                while let Some(Some((mi, mj))) = moves.get(k).copied() {
+                    if mi as usize != i {
+                        break;
+                    }
+                    let j = mj as usize;
+                    let new_distance = d(pos[i], pos[j]) + d(pos[i + 1], pos[j + 1]);
+                    pos[i + 1..=j].reverse();
+                    let _ = tx.send(ProgressMessage::PathUpdate(Route::new(&io.ids(&pos)), new_distance));
+                    k += 1;
+                }
+            }
+            if let Some(None) = moves.get(k) {
+                k += 1; // a new sweep begins
+            }
+        }
+        debug_assert_eq!(k, moves.len());
     }
 }
 

@@ -20,7 +20,7 @@ use std::ffi::{c_char, c_int, CStr};
 use std::fmt;
 use std::ptr;
 
-pub const TL_ABI_VERSION: c_int = 2;
+pub const TL_ABI_VERSION: c_int = 3;
 
 #[repr(C)]
 pub struct TlCtx {
@@ -65,6 +65,8 @@ unsafe extern "C" {
     fn tl_tour_length(ctx: *mut TlCtx, xy: *const f32, dm_packed: *const f32, n: u32, perm: *const u32, out_cost: *mut f32) -> c_int;
     fn tl_two_opt(ctx: *mut TlCtx, xy: *const f32, n: u32, dm_packed: *const f32, init_pos: *const u32, mode: c_int,
                   out_pos: *mut u32, out_cost: *mut f32, stats: *mut Stats) -> c_int;
+    fn tl_two_opt_trace(ctx: *mut TlCtx, xy: *const f32, n: u32, init_pos: *const u32, out_pos: *mut u32, out_cost: *mut f32,
+                        stats: *mut Stats, move_log: *mut u32, log_cap: u32, log_len: *mut u32) -> c_int;
     fn tl_three_opt(ctx: *mut TlCtx, xy: *const f32, n: u32, dm_packed: *const f32, init_pos: *const u32,
                     out_pos: *mut u32, out_cost: *mut f32, stats: *mut Stats) -> c_int;
     fn tl_or_opt(ctx: *mut TlCtx, xy: *const f32, n: u32, dm_packed: *const f32, init_pos: *const u32,
@@ -219,6 +221,31 @@ impl Context {
         // SAFETY: every buffer has the length the C ABI documents (n, 2n, n(n-1)/2), checked above.
         let rc = unsafe { tl_two_opt(self.raw, xy.as_ptr(), n, opt_ptr(dm_packed), opt_ptr(init_pos), mode, t.pos.as_mut_ptr(), &mut t.cost, &mut t.stats) };
         self.check(rc).map(|_| t)
+    }
+
+    /// `two_opt::solve` on coordinates together with the moves it applied, `(i, j)` in the reference's order (`swap_2opt(path, i+1, j)`,
+    /// two_opt.rs:50): what `gpu::two_opt::solve` replays the reference's per-move progress messages from.  `Err(Unsupported)`
+    /// beyond the LDS-resident descent.
+    /// The list holds `Some((i, j))` per move and `None` where a new sweep begins (`TL_TRACE_SWEEP`).
+    pub fn two_opt_trace(&self, xy: &[f32], init_pos: Option<&[u32]>) -> Result<(Tour, Vec<Option<(u32, u32)>>), Error> {
+        let n = Self::n_of(xy);
+        Self::check_inputs(n, None, init_pos);
+        let mut t = Tour { pos: vec![0u32; n as usize], cost: 0.0, stats: Stats::default() };
+        let mut cap = (16 * n).max(64);
+        loop {
+            let mut log = vec![0u32; cap as usize];
+            let mut len = 0u32;
+            // SAFETY: every buffer has the length the C ABI documents (n, 2n, log_cap), checked above.
+            let rc = unsafe {
+                tl_two_opt_trace(self.raw, xy.as_ptr(), n, opt_ptr(init_pos), t.pos.as_mut_ptr(), &mut t.cost, &mut t.stats, log.as_mut_ptr(), cap, &mut len)
+            };
+            self.check(rc)?;
+            if len <= cap {
+                log.truncate(len as usize);
+                return Ok((t, log.into_iter().map(|w| if w == 0xFFFF_FFFF { None } else { Some((w >> 16, w & 0xFFFF)) }).collect()));
+            }
+            cap = len; // the descent is deterministic: once more with room for every move
+        }
     }
 
     /// `three_opt::solve` (three_opt.rs:16-51).

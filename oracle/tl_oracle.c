@@ -269,6 +269,47 @@ int tlo_two_opt(const float *xy, const float *packed, uint32_t n, const uint32_t
     return TLO_OK;
 }
 
+/* two_opt.rs:26-61 once more, recording what the progress channel of the reference carries (:30-32, :53-56): for every applied
+ * move its (i, j), the new_distance the PathUpdate message is sent with and the sweep it happened in.  log_ij holds 2 words per
+ * move; *len counts every move, the logs hold the first `cap`. */
+int tlo_two_opt_trace(const float *xy, const float *packed, uint32_t n, const uint32_t *init, uint32_t *out, float *out_cost,
+                      tlo_stats *st, uint32_t *log_ij, float *log_dist, uint32_t *log_sweep, uint64_t cap, uint64_t *len)
+{
+    if ((!xy && !packed) || !out || !len) return TLO_ERR_BADARG;
+    if (n < 3) return TLO_ERR_REF_PANICS;
+    dsrc s = {xy, packed};
+    for (uint32_t i = 0; i < n; ++i) out[i] = init ? init[i] : i; /* :18-20 */
+    uint64_t sweeps = 0, cands = 0, moves = 0, reversed = 0;
+    const uint32_t n_indices = n - 1;
+    int improved = 1;
+    while (improved) {
+        improved = 0;
+        ++sweeps;
+        for (uint32_t i = 0; i + 2 < n_indices; ++i) {
+            for (uint32_t j = i + 2; j < n_indices; ++j) {
+                const float cur = D(&s, out[i], out[i + 1]) + D(&s, out[j], out[j + 1]);
+                const float neu = D(&s, out[i], out[j]) + D(&s, out[i + 1], out[j + 1]);
+                ++cands;
+                if (neu < cur) {
+                    tlo_swap_2opt(out, i + 1, j);
+                    improved = 1;
+                    if (moves < cap) {
+                        if (log_ij) { log_ij[2 * moves] = i; log_ij[2 * moves + 1] = j; }
+                        if (log_dist) log_dist[moves] = neu; /* :55 PathUpdate(Route::new(&path), new_distance) */
+                        if (log_sweep) log_sweep[moves] = (uint32_t)sweeps; /* 1-based pass of the `while improved` loop (:26) */
+                    }
+                    ++moves;
+                    reversed += (uint64_t)(j - i);
+                }
+            }
+        }
+    }
+    *len = moves;
+    if (st) { st->sweeps = sweeps; st->candidates = cands; st->moves = moves; st->reversed = reversed; }
+    if (out_cost) *out_cost = tlo_tour_length(xy, s.packed, n, out);
+    return TLO_OK;
+}
+
 /* BEST-SWEEP 2-opt — this build's own throughput mode (not in the reference). */
 int tlo_two_opt_best(const float *xy, const float *packed, uint32_t n, const uint32_t *init,
                      uint32_t *out, float *out_cost, tlo_stats *st, uint64_t max_moves)

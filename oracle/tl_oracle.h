@@ -75,6 +75,9 @@ void tlo_swap_2opt(uint32_t *path, uint32_t from, uint32_t to);
 /* BEST-SWEEP 2-opt (this build's own specification, NOT the reference's algorithm): per sweep
  * evaluate every (i,j) of the same open-path candidate set, pick the minimum f32 delta
  * (new - cur) < 0 with the lowest linear index on ties, apply, repeat. */
+/* two_opt::solve + the moves it applied: (i, j) and the PathUpdate distance of each (two_opt.rs:53-56) */
+int tlo_two_opt_trace(const float *xy, const float *packed, uint32_t n, const uint32_t *init, uint32_t *out, float *out_cost,
+                      tlo_stats *st, uint32_t *log_ij, float *log_dist, uint32_t *log_sweep, uint64_t cap, uint64_t *len);
 int tlo_two_opt_best(const float *xy, const float *packed, uint32_t n, const uint32_t *init,
                      uint32_t *out_perm, float *out_cost, tlo_stats *stats, uint64_t max_moves);
 

@@ -24,6 +24,6 @@ order = np.argsort(-cyc)[:5]
 print("slowest:", [(int(r), int(sw[r]), round(cyc[r] / 1e6, 1)) for r in order])
 if st[:, 13].max() > 0:  # role-split kernel diagnostics
     nd, npr, nfd = st[:, 13], st[:, 14], st[:, 15]
-    print(f"descriptors mean {nd.mean():.0f} max {nd.max()}; pruned steps mean {npr.mean():.0f}; dense steps mean {(steps - npr).mean():.0f}; flush-at-descriptor mean {nfd.mean():.1f}")
+    print(f"descriptors mean {nd.mean():.0f} max {nd.max()}; pruned steps mean {npr.mean():.0f}; dense steps mean {(steps - npr).mean():.0f}; move-log words offered mean {nfd.mean():.1f}")
     for r in list(order) + list(np.argsort(cyc)[:3]):
         print(f"  restart {int(r)}: {cyc[r]/1e6:.1f} M cycles, sweeps {int(sw[r])}, steps {int(steps[r])} (pruned {int(npr[r])}), descriptors {int(nd[r])}, moves {int(mv[r])}")

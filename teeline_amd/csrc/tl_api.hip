@@ -300,7 +300,8 @@ extern "C" int tl_tour_length(tl_ctx *c, const float *xy, const float *dm_packed
 // ------------------------------------------------------------------------------------------------
 static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uint32_t n, const uint32_t *d_init,
                            uint32_t init_mode, uint64_t seed, uint32_t first, uint32_t count, int mode,
-                           uint32_t *d_out_pos, float *d_out_cost, uint64_t *d_out_stats, hipStream_t s)
+                           uint32_t *d_out_pos, float *d_out_cost, uint64_t *d_out_stats, hipStream_t s,
+                           uint32_t *d_move_log = nullptr, uint32_t log_cap = 0)
 {
     if (mode != TL_MODE_REF_ORDER) return fail(c, TL_ERR_UNSUPPORTED, "batch 2-opt supports TL_MODE_REF_ORDER only");
     if (n < 3) return fail(c, TL_ERR_REF_PANICS, "two_opt: n=%u < 3 — the reference underflows `n_indices - 2` (two_opt.rs:17,29)", n);
@@ -317,6 +318,9 @@ static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uin
     A.n = n;
     A.max_sweeps = TL_MAX_SWEEPS;
     A.init_mode = init_mode;
+    A.move_log = d_move_log;
+    A.log_cap = log_cap;
+    if (d_move_log && d_dm) return fail(c, TL_ERR_UNSUPPORTED, "two_opt: the move log is written by the coordinate kernel only (dm_packed must be NULL)");
     // every size / mode check comes before the first event record: a rejected call must leave the event pair of the
     // previous kernel sequence intact
     if (d_dm) {
@@ -513,6 +517,51 @@ extern "C" int tl_two_opt(tl_ctx *c, const float *xy, uint32_t n, const float *d
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (raw[3] == 2) return fail(c, TL_ERR_BADARG, "two_opt: the initial tour holds a position >= n");
     if (raw[3] != 0) return fail(c, TL_ERR_NO_CONVERGE, "two_opt: sweep cap reached");
+    if (out_cost) *out_cost = cost;
+    double kms = 0;
+    tl_last_kernel_ms(c, &kms);
+    fill_stats(stats, n, raw, 1, kms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    return TL_OK;
+}
+
+// tl_two_opt on coordinates + the list of the moves it applied, in the reference's order: what a caller that was handed a
+// progress channel (two_opt.rs:9-10; only teeline-qt passes one) replays CityChange / PathUpdate from.  The control wave of the
+// descent's workgroup writes the list (row << 16 | column per move); nothing else about the descent changes.
+extern "C" int tl_two_opt_trace(tl_ctx *c, const float *xy, uint32_t n, const uint32_t *init_pos, uint32_t *out_pos, float *out_cost,
+                                tl_stats *stats, uint32_t *move_log, uint32_t log_cap, uint32_t *log_len)
+{
+    if (!c || !xy || !out_pos || !move_log || !log_len) return fail(c, TL_ERR_BADARG, "tl_two_opt_trace: NULL argument");
+    if (n < 3) return fail(c, TL_ERR_REF_PANICS, "two_opt: n=%u < 3 — the reference underflows `n_indices - 2` (two_opt.rs:17,29)", n);
+    if (init_pos && !is_permutation(init_pos, n)) return fail(c, TL_ERR_BADARG, "tl_two_opt_trace: init tour is not a permutation of 0..n-1");
+    if (n > lds_max_n(c->lds_bytes) || n > 65535u)
+        return fail(c, TL_ERR_UNSUPPORTED, "tl_two_opt_trace: n=%u exceeds the LDS-resident descent (%u): no move log beyond it", n, lds_max_n(c->lds_bytes));
+    const auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->out_pos, (size_t)n * 4)) || (rc = ensure(c, c->out_cost, 4)) || (rc = ensure(c, c->out_stats, TL_STATS_STRIDE * 8)) ||
+        (rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->work, (size_t)(log_cap ? log_cap : 1) * 4)))
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    const uint32_t *dinit = nullptr;
+    if (init_pos) {
+        if ((rc = ensure(c, c->init, (size_t)n * 4))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->init.p, init_pos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        dinit = (const uint32_t *)c->init.p;
+    }
+    if ((rc = two_opt_enqueue(c, (const float2 *)c->xy.p, nullptr, n, dinit, dinit ? TL_INIT_ARRAY : TL_INIT_IDENTITY, 0, 0, 1, TL_MODE_REF_ORDER,
+                              (uint32_t *)c->out_pos.p, (float *)c->out_cost.p, (uint64_t *)c->out_stats.p, c->stream, (uint32_t *)c->work.p, log_cap)))
+        return rc;
+    uint64_t raw[TL_STATS_STRIDE];
+    float cost = 0.f;
+    HIPCHK(c, hipMemcpyAsync(out_pos, c->out_pos.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&cost, c->out_cost.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(raw, c->out_stats.p, TL_STATS_STRIDE * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (raw[3] == 2) return fail(c, TL_ERR_BADARG, "two_opt: the initial tour holds a position >= n");
+    if (raw[3] != 0) return fail(c, TL_ERR_NO_CONVERGE, "two_opt: sweep cap reached");
+    *log_len = (uint32_t)raw[15];  // words: moves applied + one mark per sweep after the first; more than log_cap: the log holds the first log_cap
+    const uint32_t have = *log_len < log_cap ? *log_len : log_cap;
+    if (have) HIPCHK(c, hipMemcpy(move_log, c->work.p, (size_t)have * 4, hipMemcpyDeviceToHost));
     if (out_cost) *out_cost = cost;
     double kms = 0;
     tl_last_kernel_ms(c, &kms);

@@ -55,6 +55,9 @@ struct TwoOptBatchArgs {
     uint32_t max_sweeps;
     uint32_t init_mode;
     uint32_t *work;          // per-descent global workspace (global-memory variants)
+    uint32_t *move_log;      // LDS kernel, optional: [count][log_cap] words — (row << 16 | column) of every applied move in the reference's
+    uint32_t log_cap;        // order (two_opt.rs:50), 0xFFFFFFFF where a new sweep begins — what a caller replays the reference's per-move
+                             // progress messages from; NULL = off
     const uint2 *fx_xy;      // LDS kernel, grid-coordinate form: per city {x (20 bits) | y low 12 bits << 20, y high 8 bits} (k_fx_encode)
     double fx_inv;           // ... fl64(1 / S) of its decimal grid, 0 = plain float2 form
 };

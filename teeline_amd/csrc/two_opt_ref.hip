@@ -216,6 +216,8 @@ struct Acct {
     uint64_t moves, reversed, rev_lane;  // rev_lane: per-lane share of `reversed` from the flushes (summed over lanes at the end)
     float gap_est, since;                // candidates between moves (block-shape heuristic only)
     bool improved;
+    uint32_t *log;                       // optional move log of this descent (row << 16 | column per applied move, in order; 0xFFFFFFFF
+    uint32_t log_cap, log_n;             // where a new sweep begins), its capacity and the number of words so far (counted on beyond it)
 };
 
 // The deferred reversals of row c.i0, composed (flush_deferred), by every wave.  `sync_first`: the hits were filed in this very
@@ -228,7 +230,14 @@ __device__ __forceinline__ void flush_pending(Cursor &c, Acct &a, const PT &P, u
     g = (uint32_t)lane < c.np ? g : 0xFFFFFFFFu;
     const uint32_t ghi = readlane_u(g, c.np - 1u);
     const uint32_t r = flush_deferred<NT, SLOTS>(P, perm, g, c.i0 + 1u, c.np, lane, wave);
-    if (CONTROL) a.rev_lane += r;
+    if (CONTROL) {
+        a.rev_lane += r;
+        if (a.log) {  // the row's hits, in column order = the order the reference applies them in
+            const uint32_t at = a.log_n + (uint32_t)lane;
+            if ((uint32_t)lane < c.np && at < a.log_cap) a.log[at] = (c.i0 << 16) | g;
+            a.log_n += c.np;
+        }
+    }
     const uint32_t t0 = c.i0 >> 6, t1 = ghi >> 6;  // L0 metadata of tiles with a changed position or tour-edge
     c.dirty_lo = t0 < c.dirty_lo ? t0 : c.dirty_lo;
     c.dirty_hi = t1 > c.dirty_hi ? t1 : c.dirty_hi;
@@ -298,6 +307,10 @@ __device__ __forceinline__ bool step_boundary(Cursor &c, Acct &a, const PT &P, u
         reverse_segment<NT>(P, perm, is + 1u, js, tid);  // two_opt.rs:50,69-79  swap_2opt(path, i+1, j)
         TL_SYNC();
         if (CONTROL) {
+            if (a.log) {
+                if (lane == 0 && a.log_n < a.log_cap) a.log[a.log_n] = key;  // row << 16 | column
+                a.log_n += 1u;
+            }
             a.since += (float)(is - c.i0) * rowlen;
             a.moves += 1u;
             a.reversed += (uint64_t)(js - is);
@@ -474,9 +487,9 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     if (n >= 4 && wave == 0) {
         // ------------------------------------------------------------ control wave
         Cursor c{0u, 2u, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, false};
-        Acct acct{0ull, 0ull, 0ull, 0.0f, 0.0f, false};
+        Acct acct{0ull, 0ull, 0ull, 0.0f, 0.0f, false, A.move_log ? A.move_log + (size_t)d * A.log_cap : nullptr, A.log_cap, 0u};
         bool need_desc = true;
-        uint32_t n_desc = 0, n_pruned_steps = 0, n_flush_desc = 0;  // diagnostics (stats words 13..15)
+        uint32_t n_desc = 0, n_pruned_steps = 0;  // diagnostics (stats words 13, 14)
 #ifdef TL_PROFILE2
         uint64_t q2[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         uint64_t t_it = __builtin_amdgcn_s_memtime();
@@ -484,7 +497,6 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         for (;;) {
             if (need_desc) {
                 ++n_desc;
-                n_flush_desc += c.np ? 1u : 0u;
                 bool done = false;
                 if (c.i0 >= nrows) {  // sweep finished (two_opt.rs:26-28)
                     if (!acct.improved) {
@@ -497,6 +509,10 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                         ++sweeps;
                         c.i0 = 0;
                         c.j0 = 2;
+                        if (acct.log) {  // a new sweep begins here (the same row can hold moves of two consecutive sweeps back to back)
+                            if (lane == 0 && acct.log_n < acct.log_cap) acct.log[acct.log_n] = 0xFFFFFFFFu;
+                            acct.log_n += 1u;
+                        }
                     }
                 }
                 // block shape: dense (moves every few rows: one row, every tile) or pruned (up to kRMax rows, L0)
@@ -557,7 +573,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             uint64_t *st = A.out_stats + (size_t)d * TL_STATS_STRIDE;
             st[13] = n_desc;          // descriptors published (sweep ends + block-shape changes)
             st[14] = n_pruned_steps;  // steps in pruned shape
-            st[15] = n_flush_desc;    // descriptors that forced a flush
+            st[15] = acct.log_n;      // words offered to the move log: moves + sweep marks (more than its capacity: the log is a prefix)
         }
 #endif
 #ifdef TL_PROFILE2
@@ -578,7 +594,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #define TL_STAMP3(k) do { } while (0)
 #endif
         Cursor c{0u, 2u, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, false};
-        Acct acct{0ull, 0ull, 0ull, 0.0f, 0.0f, false};  // unused by a worker
+        Acct acct{0ull, 0ull, 0ull, 0.0f, 0.0f, false, nullptr, 0u, 0u};  // unused by a worker
         bool need_desc = true, reload = true;
         float ax = 0.f, ay = 0.f, bx = 0.f, by = 0.f;
         for (;;) {

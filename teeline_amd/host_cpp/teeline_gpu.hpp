@@ -204,6 +204,52 @@ inline Solution solve(Context &ctx, const TspProblem &problem, const HeuristicOp
     if (init_tour) init = problem.positions_of(*init_tour);
     float cost = 0.f;
     tl_stats st{};
+    // With a progress callback the descent also lists its moves (tl_two_opt_trace) and the reference's exact message sequence —
+    // CityChange(path[i]) per outer i of every sweep, PathUpdate(path, new_distance) per move (two_opt.rs:30-32,53-56) — is
+    // replayed from them once the kernel is back.  Coordinates only; otherwise the final PathUpdate (detail::finish).
+    if (progress_tx && *progress_tx && !problem.explicit_packed() && mode == TL_MODE_REF_ORDER && n >= 3 && n <= 65535u &&
+        n <= tl_two_opt_lds_max_n(ctx.get())) {
+        std::vector<size_t> route;
+        std::vector<uint32_t> pos(n);
+        for (uint32_t q = 0; q < n; ++q) pos[q] = init_tour ? init[q] : q;
+        for (uint32_t q : pos) route.push_back(problem.cities[q].id);
+        (*progress_tx)(ProgressKind::PathUpdate, route, 0.0f);  // :22-24
+        uint32_t cap = std::max<uint32_t>(64u, 16u * n), len = 0;
+        std::vector<uint32_t> log;
+        for (;;) {
+            log.assign(cap, 0u);
+            ctx.check(tl_two_opt_trace(ctx.get(), xy.data(), n, init_tour ? init.data() : nullptr, out.data(), &cost, &st, log.data(), cap, &len));
+            if (len <= cap) break;
+            cap = len;  // the descent is deterministic: once more with room for every move
+        }
+        auto d = [&](uint32_t p, uint32_t q) -> float {  // KDPoint::distance (kdtree.rs:291-295): separate roundings, correctly rounded sqrt
+            const volatile float dx = xy[2 * p] - xy[2 * q], dy = xy[2 * p + 1] - xy[2 * q + 1];
+            const volatile float sx = dx * dx, sy = dy * dy;
+            const volatile float ss = sx + sy;
+            return std::sqrt((float)ss);
+        };
+        size_t k = 0;
+        std::vector<size_t> one(1);
+        for (uint64_t sw = 0; sw < st.sweeps; ++sw, k += (k < len && log[k] == TL_TRACE_SWEEP) ? 1 : 0)
+            for (uint32_t i = 0; i + 3 < n; ++i) {
+                one[0] = problem.cities[pos[i]].id;
+                (*progress_tx)(ProgressKind::CityChange, one, 0.0f);
+                while (k < len && log[k] != TL_TRACE_SWEEP && (log[k] >> 16) == i) {
+                    const uint32_t j = log[k] & 0xFFFFu;
+                    const float new_distance = d(pos[i], pos[j]) + d(pos[i + 1], pos[j + 1]);
+                    std::reverse(pos.begin() + i + 1, pos.begin() + j + 1);
+                    for (uint32_t q = 0; q < n; ++q) route[q] = problem.cities[pos[q]].id;
+                    (*progress_tx)(ProgressKind::PathUpdate, route, new_distance);
+                    ++k;
+                }
+            }
+        Solution s;
+        s.total = cost;
+        s.stats = st;
+        for (uint32_t q : out) s.route_.push_back(problem.cities[q].id);
+        (*progress_tx)(ProgressKind::Done, s.route_, cost);
+        return s;
+    }
     ctx.check(tl_two_opt(ctx.get(), xy.data(), n, problem.explicit_packed(), init_tour ? init.data() : nullptr, mode, out.data(), &cost, &st));
     return detail::finish(problem, out, cost, st, progress_tx);
 }

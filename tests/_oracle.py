@@ -100,6 +100,35 @@ def two_opt(xy, packed, n, init=None, flavor=0, max_candidates=0, best=False, ma
     return rc, out, np.float32(cost.value), st.as_dict()
 
 
+def two_opt_trace(xy, packed, n, init=None, cap=1 << 20):
+    """two_opt + the applied moves: returns (rc, route, cost, stats, ij [m, 2] uint32, dist [m] float32, sweep [m] uint32) — dist[m] is
+    the new_distance the reference sends with move m's PathUpdate (two_opt.rs:53-56), sweep[m] the 1-based pass it happened in."""
+    xy = _xy(xy)
+    init = _perm(init, n)
+    out = np.empty(n, dtype=np.uint32)
+    cost = C.c_float()
+    st = Stats()
+    ij = np.empty((cap, 2), dtype=np.uint32)
+    dist = np.empty(cap, dtype=np.float32)
+    sw = np.empty(cap, dtype=np.uint32)
+    ln = C.c_uint64()
+    rc = lib().tlo_two_opt_trace(_p(xy), _p(packed), C.c_uint32(n), _p(init), _p(out), C.byref(cost), C.byref(st), _p(ij), _p(dist), _p(sw),
+                                 C.c_uint64(cap), C.byref(ln))
+    m = min(int(ln.value), cap)
+    return rc, out, np.float32(cost.value), st.as_dict(), ij[:m].copy(), dist[:m].copy(), sw[:m].copy()
+
+
+def trace_words(ij, sweep):
+    """The word list tl_two_opt_trace returns for these moves: (i << 16) | j, and 0xFFFFFFFF where a new sweep begins."""
+    words, cur = [], 1
+    for (i, j), s in zip(ij.tolist(), sweep.tolist()):
+        while cur < s:
+            words.append(0xFFFFFFFF)
+            cur += 1
+        words.append((i << 16) | j)
+    return words, cur
+
+
 def swap_2opt(path, a, b):
     path = np.ascontiguousarray(path, dtype=np.uint32).copy()
     lib().tlo_swap_2opt(_p(path), C.c_uint32(a), C.c_uint32(b))

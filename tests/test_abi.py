@@ -54,7 +54,7 @@ def test_flags_modes_and_error_codes_agree_with_the_binding():
 def test_library_exports_every_declared_symbol(lib):
     for name in header_symbols():
         assert hasattr(lib, name), f"libteeline_gpu.so does not export {name}"
-    assert lib.tl_abi_version() == 2
+    assert lib.tl_abi_version() == 3
     assert b"gfx950" in lib.tl_version()
 
 

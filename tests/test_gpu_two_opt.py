@@ -467,3 +467,72 @@ def test_pr1002_like_lattice_ties(ctx):
             assert_same(gpu_two_opt(ctx, None, packed, n, init), want, n)
         with TA.Context(0, TA.TL_FLAG_NO_PRUNE) as c2:
             assert_same(gpu_two_opt(c2, pts, None, n, None), O.two_opt(pts, None, n), n)
+
+
+def _expected_messages(xy, ids, init):
+    # two_opt.rs:22-65 restated as its message stream (f32 distances exactly as KDPoint::distance computes them)
+    n = len(xy)
+    path = list(range(n)) if init is None else [int(v) for v in init]
+
+    def D(p, q):
+        dx, dy = xy[p, 0] - xy[q, 0], xy[p, 1] - xy[q, 1]
+        return np.sqrt(np.float32(dx * dx) + np.float32(dy * dy), dtype=np.float32)
+
+    msgs = [("PathUpdate", ([int(ids[v]) for v in path], 0.0))]
+    improved = True
+    while improved:
+        improved = False
+        for i in range(0, n - 3):
+            msgs.append(("CityChange", int(ids[path[i]])))
+            for j in range(i + 2, n - 1):
+                cur = np.float32(D(path[i], path[i + 1]) + D(path[j], path[j + 1]))
+                neu = np.float32(D(path[i], path[j]) + D(path[i + 1], path[j + 1]))
+                if neu < cur:
+                    path[i + 1:j + 1] = path[i + 1:j + 1][::-1]
+                    improved = True
+                    msgs.append(("PathUpdate", ([int(ids[v]) for v in path], float(neu))))
+    msgs.append(("Done", None))
+    return msgs, path
+
+
+def test_progress_channel_replays_the_reference_messages(ctx, tsplib_dir):
+    # VERDICT r02 "missing" 4: per-move progress.  With a progress callback two_opt::solve goes through tl_two_opt_trace and replays
+    # PathUpdate(start) / CityChange per outer i / PathUpdate(path, new_distance) per move / Done exactly as two_opt.rs:22-65 sends them.
+    import teeline_amd as TA
+    d = T.parse_tsplib(os.path.join(tsplib_dir, "berlin52.tsp"))
+    xy, n, ids = d["xy"], d["n"], d["ids"]
+    rc, nn, _ = O.nearest_neighbor(xy, None, n, 3)
+    for init in (None, nn, O.restart_perm(n, 3, 0)):
+        got = []
+        prob = TA.TspProblem(ids, xy)
+        sol = TA.two_opt.solve(prob, None, lambda kind, payload: got.append((kind, payload)),
+                               None if init is None else [int(ids[v]) for v in init], ctx=ctx)
+        want, path = _expected_messages(xy, ids, init)
+        assert got == want
+        assert list(sol.route()) == [int(ids[v]) for v in path]
+
+
+def test_move_list_matches_the_oracle(ctx):
+    # tl_two_opt_trace: the applied moves (i, j) in the reference's order with a mark where a new sweep begins, against the oracle's
+    # record of the same loop; a short log buffer holds the prefix and reports the full count
+    import ctypes as C
+    import teeline_amd as TA
+    from teeline_amd import _capi
+    for n, seed in ((5, 1), (64, 2), (700, 3), (3000, 4), (10000, 5)):
+        xy = O.synth_xy(n, seed=seed if n < 10000 else 0)
+        init = O.restart_perm(n, 12345, 0)
+        rc, route, cost, st, ij, dist, sw = O.two_opt_trace(xy, None, n, init=init)
+        words, last = O.trace_words(ij, sw)
+        words += [0xFFFFFFFF] * (st["sweeps"] - last)   # the final sweeps without a move are marked too
+        want = np.asarray(words, dtype=np.uint32)
+        out = np.empty(n, dtype=np.uint32)
+        c, stt, ln = C.c_float(), _capi.TlStats(), C.c_uint32()
+        for cap in (len(want) + 7, max(len(want) // 3, 1)):
+            log = np.full(cap, 0x12345678, dtype=np.uint32)
+            ctx.check(ctx.lib.tl_two_opt_trace(ctx.handle, xy.ctypes.data_as(C.c_void_p), n, init.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                               C.byref(c), C.byref(stt), log.ctypes.data_as(C.c_void_p), cap, C.byref(ln)))
+            assert ln.value == len(want) == stt.moves + stt.sweeps - 1 and out.tolist() == route.tolist()
+            m = min(cap, len(want))
+            assert log[:m].tolist() == want[:m].tolist()
+            assert (log[m:] == 0x12345678).all()
+        assert np.float32(c.value).tobytes() == np.float32(cost).tobytes()
