@@ -1,4 +1,4 @@
-// two_opt_common.h — device helpers shared by the 2-opt kernels: wave min/max reductions (DPP), the per-tile
+// two_opt_common.h — device helpers shared by the 2-opt kernels: wave reductions on integer keys (DPP), the per-tile
 // bounding-box metadata of the exact L0 bound and the f32 lower bound itself (DESIGN.md "Exact decision cascade").
 #pragma once
 #include "tl_device.h"
@@ -6,29 +6,6 @@
 #pragma clang fp contract(off)
 
 namespace tl {
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_shr(float v)
-{
-    // row_shr within rows of 16 lanes; lanes without a source keep their own value (old = v)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float wave_min(float v)
-{
-    v = fminf(v, dpp_shr<0x111>(v));
-    v = fminf(v, dpp_shr<0x112>(v));
-    v = fminf(v, dpp_shr<0x114>(v));
-    v = fminf(v, dpp_shr<0x118>(v));  // lane 15 of each row: min of the row (min is idempotent)
-    return fminf(fminf(readlane_f(v, 15), readlane_f(v, 31)), fminf(readlane_f(v, 47), readlane_f(v, 63)));
-}
-__device__ __forceinline__ float wave_max(float v)
-{
-    v = fmaxf(v, dpp_shr<0x111>(v));
-    v = fmaxf(v, dpp_shr<0x112>(v));
-    v = fmaxf(v, dpp_shr<0x114>(v));
-    v = fmaxf(v, dpp_shr<0x118>(v));
-    return fmaxf(fmaxf(readlane_f(v, 15), readlane_f(v, 31)), fmaxf(readlane_f(v, 47), readlane_f(v, 63)));
-}
 
 // ---- tour-ordered points.  The kernels take them either as plain float2 (8 B per city) or, for the LDS descent kernel, as
 // grid coordinates (5 B per city): TSPLIB-style inputs lie on a decimal grid — x = k / S with an integer k < 2^20 — and the f32
