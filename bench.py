@@ -144,6 +144,18 @@ def cpu_baseline(n, seed, xy):
     }
 
 
+def instance_xy(name, n, TA):
+    """The real TSPLIB instance where somebody has supplied it — <name>.tsp under $TEELINE_TSPLIB_DIR, data/ or tests/golden/tsplib/ (the
+    reference fetches pr1002 / usa13509 with download_data.sh; they are not in its tree and there is no network here) — else the
+    labelled synthetic stand-in of equal n.  Returns (xy in file order, label)."""
+    for d in (os.environ.get("TEELINE_TSPLIB_DIR"), os.path.join(ROOT, "data"), os.path.join(ROOT, "tests", "golden", "tsplib")):
+        if d and os.path.exists(os.path.join(d, name + ".tsp")):
+            t = TA.tsplib.read_from_file(os.path.join(d, name + ".tsp"))
+            if len(t.xy) == n:
+                return np.ascontiguousarray(t.xy, dtype=np.float32), f"{name}.tsp ({os.path.join(d, name + '.tsp')})"
+    return TA.synth.synth_xy(n), f"synthetic EUC_2D n={n} stand-in for {name}.tsp (the file is not in the reference tree)"
+
+
 def latest_profile(pattern):
     import glob
     f = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
@@ -568,7 +580,7 @@ def main():
             # BASELINE configs[1]: pr1002-sized instance (the file is not in the reference tree -> synthetic n = 1002, labelled),
             # full REF_ORDER sweep to the local optimum with every distance gathered from the fp32 matrix in HBM
             n2 = 1002
-            xy2 = TA.synth.synth_xy(n2)
+            xy2, label2 = instance_xy("pr1002", n2, TA)
             dm2 = TA.distance_matrix.build(np.arange(n2), xy2, ctx=ctx)
             pm2 = TA.TspProblem(np.arange(n2), xy2, TA.distance_matrix.DistanceMatrix(n2, dm2.items, np.arange(n2), "explicit"))
             nn2 = [int(v) for v in TA.nearest_neighbor.solve(TA.TspProblem(np.arange(n2), xy2), ctx=ctx).route()]
@@ -580,6 +592,7 @@ def main():
                 cfg1[name] = {"kernel_ms": sm.stats["kernel_ms"], "candidates_per_s": cps, "cost": float(sm.total),
                               "sweeps": sm.stats["sweeps"], "moves": sm.stats["moves"],
                               "algorithmic_GBps_at_16B_per_candidate": cps * 16.0 / 1e9}
+            cfg1["instance"] = label2
             cfg1["note"] = ("one descent = one workgroup on ONE CU; latency-bound (a step per move), the 4 MB full matrix stays in L2/MALL; "
                             "kernel_ms includes the packed -> full expansion")
             # the same kernel with the chip full: a population of 256 tours (the seeded restart permutations 0..255), one descent
@@ -637,7 +650,8 @@ def main():
                                                                "sample": f"the same scan (one find_best_move, n = {n5}, NN tour) by the oracle on one core; wall {wc:.2f} s; same move as the GPU's (asserted)"}
             # BASELINE configs[4] size: Lin-Kernighan ILS at n = 13 509 (synthetic points), candidate lists through the kd-tree
             n13 = 13509
-            p13 = TA.TspProblem(np.arange(n13), TA.synth.synth_xy(n13))
+            xy13, label13 = instance_xy("usa13509", n13, TA)
+            p13 = TA.TspProblem(np.arange(n13), xy13)
             lk_opts = TA.LKOptions(TA.HeuristicOptions(epochs=20, platoo_epochs=10, n_nearest=5), 5)
             TA.lin_kernighan.solve(p13, lk_opts, ctx=ctx, seed=1)
             slk = TA.lin_kernighan.solve(p13, lk_opts, ctx=ctx, seed=1)
@@ -647,7 +661,7 @@ def main():
             # scan, the longest walk's dependent L2 look-ups (max_depth 5 levels x 3 look-ups x ~200 cycles at the live clock).
             lk_floor_us = 2 * 1.45 + 15 * 200.0 / max(clock_hz, 1.0) * 1e6
             extras["lin_kernighan_n13509_20_epochs"] = {"kernel_ms": lk_ms, "total_ms": slk.stats["total_ms"], "cost": float(slk.total),
-                                                        "scans": lk_rounds, "moves": lk_moves, "moves_per_s": lk_moves / (lk_ms * 1e-3),
+                                                        "instance": label13, "scans": lk_rounds, "moves": lk_moves, "moves_per_s": lk_moves / (lk_ms * 1e-3),
                                                         "us_per_round": lk_ms * 1e3 / max(lk_rounds, 1),
                                                         "roofline": {"bound": "dependent_latency", "achieved": lk_rounds / (lk_ms * 1e-3), "peak": 1e6 / lk_floor_us,
                                                                      "unit": "rounds/s", "frac": lk_floor_us / (lk_ms * 1e3 / max(lk_rounds, 1)), "traffic": None,
