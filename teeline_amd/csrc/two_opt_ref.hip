@@ -10,9 +10,12 @@
 //     perm (u16) live in that CU's LDS for the whole descent (10 B/city: n <= ~15 K) — zero HBM
 //     traffic inside the loop; 256 CUs = 256 concurrent restarts (north-star config 4);
 //   - a step speculatively decides a block of R rows (i0..i0+R) x all j under "no move yet" and
-//     reduces the lexicographically first improving (i,j) with one ds_min_u32 on a packed key
-//     (i<<16 | j); the workgroup then applies that reversal cooperatively in LDS and resumes at
-//     (i, j+1), exactly where the reference's inner loop continues.
+//     reduces the lexicographically first improving (i,j) with one ds_min_u32 on a packed key; the
+//     workgroup then applies that reversal cooperatively in LDS (dense rows: deferred, composed) and
+//     resumes at (i, j+1), exactly where the reference's inner loop continues;
+//   - wave 0 ("control") keeps the descent's accounting and does not scan; the other waves
+//     ("workers") carry only a cursor and advance it themselves at a step's end from words all of
+//     them read behind the same barrier (see "Role split" in the kernel body).
 //
 // Every candidate is decided exactly as the reference decides it, by a cascade of exact tests
 // (DESIGN.md "Exact decision cascade"; f32 add, mul, sqrt are monotone, so each bound holds in
@@ -43,10 +46,10 @@ constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 #define TL_DENSE_ROWS 8.0f
 #endif
 constexpr int kRMax = TL_RMAX;        // rows per speculative block in pruned mode (<= 63: lane-resident row table)
-constexpr uint32_t kQCap = 32;        // u32 words per chained-hit list: 2 + kMaxChainHits used.  32 lists = (tile index mod 16) x
-                                      // (step parity): a list is read after its step's barrier with no barrier behind the read,
-                                      // so the next step writes the other parity.  The 4 KB are also the cost-sum scratch.
-constexpr uint32_t kPendMax = 64;     // deferred reversals of one row: lane m of every wave keeps hit m (= the flush's segment table)
+constexpr uint32_t kQCap = 32;        // u32 words per hit list (4 used: count, resume column, the row's new b).  32 lists = 16 waves x
+                                      // (step parity): a list is read after its step's barrier while its owner may already write
+                                      // the next step's, so the parities alternate.  The 4 KB are also the cost-sum scratch.
+constexpr uint32_t kPendMax = 64;     // deferred reversals of one row (ctl->pend): lane m of a flush reads hit m (= the flush's segment table)
 constexpr int kFlushSlots = 15;       // elements per thread a flush can hold: 15 x 1024 covers every n that fits the LDS
 constexpr int kFlushSlotsFx = 20;     // grid-coordinate form on 8 waves: 20 x 512 covers n = 10^4 (two tours per CU)
 constexpr int kMaxGroups = 4;         // 64-tile groups: n_pad <= 4 * 64 * 64 = 16384
@@ -190,18 +193,6 @@ __device__ __forceinline__ void reverse_segment(const PT &P, uint16_t *perm, uin
             perm[hi - t2] = u2;
         }
     }
-}
-
-// a = P[i], b = P[bidx] of a dense row as wave-uniform values, sq(a, b) with them
-template <typename PT>
-__device__ __forceinline__ void load_row_ab(const PT &P, uint32_t i, uint32_t bidx, int lane, float &ax, float &ay, float &bx, float &by, float &sqab)
-{
-    const float2 ab = pt_get(P, lane == 0 ? i : bidx);
-    ax = readlane_f(ab.x, 0);
-    ay = readlane_f(ab.y, 0);
-    bx = readlane_f(ab.x, 1);
-    by = readlane_f(ab.y, 1);
-    sqab = sqdist(make_float2(ax, ay), make_float2(bx, by));
 }
 
 // ---- role-split kernel: the scan cursor every wave carries, the accounting only the control wave keeps, and the step boundary
@@ -373,8 +364,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     float4 *tbox = reinterpret_cast<float4 *>(tailp);                        // kMaxGroups*64 entries
     float *tmsq = reinterpret_cast<float *>(tailp + kMaxGroups * 64 * 16);     // kMaxGroups*64
     Ctl *ctl = reinterpret_cast<Ctl *>(tailp + kMaxGroups * 64 * 20);
-    // chained-hit lists (kQCap words per (tile index mod 16, step parity)) during the descent; reused as NT floats for the
-    // cost sum
+    // hit lists (kQCap words per (wave, step parity)) during the descent; reused as NT floats for the cost sum
     uint32_t *queues = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(ctl) + kCtlBytes);
     float *scratch = reinterpret_cast<float *>(queues);
 
