@@ -56,13 +56,13 @@ constexpr int kMaxGroups = 4;         // 64-tile groups: n_pad <= 4 * 64 * 64 = 
 
 
 struct Ctl {                     // kCtlBytes of LDS
-    uint32_t keys[4];
+    uint2 kr[4];                // per key slot (step % 3): .x the step's first-hit key (ds_min_u32), .y the control wave's request for its
+                                // descriptor at that step's end (block-shape change) — one 8-byte read gives a wave both
     uint32_t desc[4];           // the descriptor the control wave publishes before barrier B0 (sweep start / exit / block shape)
     unsigned long long cnt[6];  // cascade work of the descent (TileCounts summed over the waves; counting instantiation)
     unsigned long long clk0, rt0;  // s_memtime / s_memrealtime at the start of the descent (kept here, not in SGPRs)
     uint32_t bad_init;
-    uint32_t req[2];            // the control wave asks for its descriptor (block-shape change), by step parity
-    uint32_t pad_[5];
+    uint32_t pad_[3];
     uint32_t pend[64];          // deferred hit columns of the current dense row (lane m of a flush reads hit m)
 };
 constexpr size_t kCtlBytes = 384;
@@ -243,8 +243,9 @@ template <bool CONTROL, int NT, int SLOTS, typename PT>
 __device__ __forceinline__ bool step_boundary(Cursor &c, Acct &a, const PT &P, uint16_t *perm, Ctl *ctl, const uint32_t *queues, uint32_t n, uint32_t nrows,
                                               uint32_t R, int lane, int wave, int tid, uint32_t my_hits, float &bx, float &by, bool &reload)
 {
-    const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->keys[c.slot]);
-    const uint32_t req = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->req[c.par]);
+    const uint2 kr = ctl->kr[c.slot];
+    const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)kr.x);
+    const uint32_t req = (uint32_t)__builtin_amdgcn_readfirstlane((int)kr.y);
     const float rowlen = (float)(n - 2u - c.i0);
     reload = false;
     if (!c.pruned) {
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             }
         }
     }
-    if (tid < 4) ctl->keys[tid] = kNoKey;
+    if (tid < 4) ctl->kr[tid] = make_uint2(kNoKey, 0u);
     if (tid < 6) ctl->cnt[tid] = 0ull;
     if (tid == 0) {
         ctl->clk0 = __builtin_amdgcn_s_memtime();
@@ -463,11 +464,13 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     //    same function (it must meet every barrier) and does its accounting beside the workers' next scan.
     //  * The control wave steps in — an 8-byte descriptor (op | pruned << 2, i0 | j0 << 16) before barrier B0 — only where a
     //    decision is its own: a sweep has ended (next sweep or exit) or the block shape should change (requested through
-    //    req[parity] one boundary ahead: either shape gives the same results, so the request may lag).
+    //    the request word beside the next step's key slot, i.e. one boundary ahead: either shape gives the same results, so
+    //    the request may lag).
     //  * Barriers per step, met by every wave:  (B0 | flush: 2) | dense: B1 (lead round / rest), B2 | pruned: (tile
     //    metadata: 1), B2 | boundary: (flush behind a hit step: 1 + 2; flush: 2; pruned hit: 1).
     // Dense keys are (column << 16) | posting wave (the row is implied; the tag finds the owner's hit list), pruned keys
-    // (row << 16) | column.  Key slots rotate with step % 3 — the control wave resets the next step's slot before B2 — and
+    // (row << 16) | column.  Key slots rotate with step % 3 — the control wave resets the next step's slot before B2; the slot's
+    // second word is the request, so a wave reads both with one 8-byte LDS read — and
     // every wave has two hit lists, used by the step's parity (a list is read after B2 while its owner may already write the
     // next step's).  The owner of a step's hits files them in ctl->pend itself (it still holds them in a register).
     enum : uint32_t { OP_GO = 0u, OP_EXIT = 2u };
@@ -511,14 +514,15 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                     *reinterpret_cast<uint2 *>(ctl->desc) = make_uint2((done ? OP_EXIT : OP_GO) | (c.pruned ? 4u : 0u), c.i0 | (c.j0 << 16));
                 TL_SYNC();  // B0
                 if (lane == 0) {  // behind B0: a slow worker may have been reading its request word until it got here
-                    ctl->req[0] = 0u;
-                    ctl->req[1] = 0u;
+                    ctl->kr[0].y = 0u;
+                    ctl->kr[1].y = 0u;
+                    ctl->kr[2].y = 0u;
                 }
                 if (c.np) flush_pending<true, NT, kSlots>(c, acct, P, perm, ctl, lane, wave, false);
                 if (done) break;
             }
             const uint32_t slot_next = c.slot == 2u ? 0u : c.slot + 1u;
-            if (lane == 0) ctl->keys[slot_next] = kNoKey;  // slot of the next step (its last readers are two barriers behind)
+            if (lane == 0) ctl->kr[slot_next].x = kNoKey;  // slot of the next step (its last readers are two barriers behind)
             ++step;
             n_pruned_steps += c.pruned ? 1u : 0u;
             const uint32_t R = c.pruned ? ((uint32_t)kRMax < nrows - c.i0 ? (uint32_t)kRMax : nrows - c.i0) : 1u;
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             // the block shape the gap estimate asks for; a change is requested for the next boundary
             if (PRUNE && c.i0 < nrows) {
                 const bool want = fmaxf(acct.gap_est, acct.since) > TL_DENSE_ROWS * (float)(n - 2u - c.i0);
-                if (lane == 0) ctl->req[c.par] = want != c.pruned ? 1u : 0u;
+                if (lane == 0) ctl->kr[c.slot].y = want != c.pruned ? 1u : 0u;  // (c.slot is the next step's slot by now)
             }
 #ifdef TL_PROFILE2
             {
@@ -599,7 +603,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 c.j0 = w1 >> 16;
                 reload = true;
             }
-            uint32_t *keyslot = &ctl->keys[c.slot];
+            uint32_t *keyslot = &ctl->kr[c.slot].x;
             uint32_t my_hits = 0;
             const uint32_t R = c.pruned ? ((uint32_t)kRMax < nrows - c.i0 ? (uint32_t)kRMax : nrows - c.i0) : 1u;
             if (!c.pruned) {
