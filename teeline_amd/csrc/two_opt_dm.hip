@@ -31,6 +31,10 @@ constexpr int kDmTiles = TL_DM_TILES;  // 64-column tiles whose gathers are in f
 #define TL_DM_CHAIN 16
 #endif
 constexpr uint32_t kDmChain = TL_DM_CHAIN;  // improving moves one wave may chain inside its tile of a dense row
+#ifndef TL_DM_WARM_MB
+#define TL_DM_WARM_MB 32
+#endif
+constexpr size_t kDmWarmBytes = (size_t)TL_DM_WARM_MB << 20;  // matrices up to this size are read once at the start of a descent (L2 / MALL warm-up)
 }
 
 // packed strict lower triangle (idx(r > c) = r(r-1)/2 + c) -> full symmetric row-major n x n, zero diagonal
@@ -91,6 +95,19 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
     if (tid < 4) keys[tid] = kNoKey;
     TL_SYNC();
     for (uint32_t k = tid; k + 1u < n; k += kDmNT) edge[k] = dm[(size_t)perm[k] * n + perm[k + 1u]];
+    if ((size_t)n * n * 4u <= kDmWarmBytes) {
+        // The descent touches a matrix row for the first time almost every step of its first sweep (row a of every i, the row of
+        // every move's new b), and a first touch is a miss of this XCD's L2 — k_dm_expand_full ran on all of them — i.e. a round
+        // trip to the Infinity Cache / HBM in front of a step.  So stream the matrix through once (4 MB at n = 1002: ~30 us).
+        const float4 *__restrict__ m4 = reinterpret_cast<const float4 *>(dm);
+        const size_t n4 = (size_t)n * n / 4u;
+        float acc = 0.0f;
+        for (size_t k = tid; k < n4; k += kDmNT) {
+            const float4 v = m4[k];
+            acc += (v.x + v.y) + (v.z + v.w);
+        }
+        if (acc == -1.0f) keys[3] = 0u;  // distances are >= 0: never taken, keeps the loads
+    }
     TL_SYNC();
 
     const uint32_t nrows = n - 3;
@@ -102,6 +119,13 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
     uint32_t since_rows = 0;  // rows scanned since the last move
     uint32_t gap_rows = 0;    // ... and its running average over the recent moves: the block shape follows the larger of the two
 
+#ifdef TL_DM_PROFILE
+    uint64_t qd[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // wave 0's cycles in dense steps: row set-up, first decision, chain, barrier wait, boundary + reversals, [5] steps; wide steps from [8]: staging, -, scan, ...
+    uint64_t tq = __builtin_amdgcn_s_memtime();
+#define TL_DSTAMP(k) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); qd[(wide ? 8 : 0) + (k)] += t_ - tq; tq = t_; } while (0)
+#else
+#define TL_DSTAMP(k) do { } while (0)
+#endif
     while (n >= 4) {
         const uint32_t slot = step % 3u;
         if (tid == 0) keys[(step + 1u) % 3u] = kNoKey;
@@ -141,6 +165,7 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
                         }
                     }
                 }
+                TL_DSTAMP(0);
                 const uint32_t jmin = wave == 0u ? j0 : i + 2u;
                 bool done = false;
                 for (uint32_t jb = jmin - (jmin & 63u); jb <= n - 2u && !done; jb += 64u * kDmTiles) {
@@ -184,6 +209,7 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
             const float dab = edge[i];
             const float *__restrict__ rowa = dm + (size_t)a * n;
             const float *__restrict__ rowb = dm + (size_t)b * n;
+            TL_DSTAMP(0);
             for (uint32_t jb = jbase + (wave << 6); jb <= n - 2u; jb += kDmNT) {
                 const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)keys[slot]);
                 if (kb != kNoKey && (kb & 0xFFFFu) < jb) break;
@@ -195,6 +221,7 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
                 float dabc = dab;
                 bool imp = (j >= j0) & (j <= n - 2u) & (dac + dbe < dabc + dce);
                 uint64_t m = __builtin_amdgcn_ballot_w64(imp);
+                TL_DSTAMP(1);
                 if (m) {
                     // Chain every improving move of the reference's scan inside this tile: after a hit at lane l the row's b is
                     // the old perm[j] (two_opt.rs:50 reverses p[i+1..=j]), positions > j are untouched, so the lanes > l are
@@ -227,7 +254,9 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
                 }
             }
         }
+        TL_DSTAMP(2);
         TL_SYNC();
+        TL_DSTAMP(3);
         const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)keys[slot]);
         if (key == kNoKey) {
             i0 += R;
@@ -274,6 +303,10 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
                 j0 = i0 + 2u;
             }
         }
+        TL_DSTAMP(4);
+#ifdef TL_DM_PROFILE
+        qd[(wide ? 8 : 0) + 5] += 1;
+#endif
         if (i0 >= nrows) {
             if (!improved) break;
             if (sweeps >= A.max_sweeps) {
@@ -306,6 +339,9 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
 #endif
         st[3] = status;
         st[4] = step;
+#ifdef TL_DM_PROFILE
+        printf("dmprof dense: setup %lu first %lu chain %lu wait %lu boundary %lu steps %lu | wide: staging %lu scan %lu wait %lu boundary %lu steps %lu\n", qd[0], qd[1], qd[2], qd[3], qd[4], qd[5], qd[8], qd[10], qd[11], qd[12], qd[13]);
+#endif
     }
 }
 
