@@ -1,4 +1,4 @@
-"""Cycle stamps of one random-restart descent (n = 10^4, restart 0) from the -DTL_PROFILE2 (control wave: per step type) / -DTL_PROFILE3 (a lead and a non-lead worker: per segment of a dense step) builds."""
+"""Cycle stamps of one random-restart descent (n = 10^4, restart FIRST) from the -DTL_PROFILE2 (control wave: per step type) / -DTL_PROFILE3 (a lead and a non-lead worker: per segment of a dense step) / -DTL_PROFILE4 (per sweep, printed by the device) builds: TEELINE_GPU_LIB=<that build> R=1 FIRST=152 python scripts/descent_profile.py"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -487,6 +487,13 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         uint64_t q2[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         uint64_t t_it = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef TL_PROFILE4
+        // per sweep (printed for descent 0 of the launch): steps and cycles by block shape and outcome; for dense steps without a
+        // hit (the step that ends a row: the rest of the row + the row's flush) also the tiles they scanned and how many of those
+        // lay outside the stale-box range (where an L0 bound would have been valid)
+        uint64_t q4[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t t4 = __builtin_amdgcn_s_memtime();
+#endif
         for (;;) {
             if (need_desc) {
                 ++n_desc;
@@ -498,6 +505,12 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                         status = 1;
                         done = true;
                     } else {
+#ifdef TL_PROFILE4
+                        if (d == 0 && lane == 0)
+                            printf("sweep %u: dense hit %lu steps %lu cyc | dense none %lu steps %lu cyc, tiles %lu of which with valid boxes %lu | pruned hit %lu steps %lu cyc | pruned none %lu steps %lu cyc\n",
+                                   sweeps, q4[0], q4[1], q4[2], q4[3], q4[8], q4[9], q4[4], q4[5], q4[6], q4[7]);
+                        for (int q = 0; q < 10; ++q) q4[q] = 0;
+#endif
                         acct.improved = false;
                         ++sweeps;
                         c.i0 = 0;
@@ -541,6 +554,11 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             const bool was_pruned = c.pruned;
             const uint64_t moves_before = acct.moves;
 #endif
+#ifdef TL_PROFILE4
+            const bool was_pruned4 = c.pruned;
+            const uint64_t moves_before4 = acct.moves;
+            const uint32_t t0_4 = c.j0 >> 6, dlo4 = c.dirty_lo, dhi4 = c.dirty_hi;
+#endif
             float bx_ = 0.f, by_ = 0.f;
             bool reload_ = false;
             need_desc = step_boundary<true, NT, kSlots>(c, acct, P, perm, ctl, queues, n, nrows, R, lane, wave, tid, 0u, bx_, by_, reload_);
@@ -549,6 +567,22 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 const bool want = fmaxf(acct.gap_est, acct.since) > TL_DENSE_ROWS * (float)(n - 2u - c.i0);
                 if (lane == 0) ctl->kr[c.slot].y = want != c.pruned ? 1u : 0u;  // (c.slot is the next step's slot by now)
             }
+#ifdef TL_PROFILE4
+            {
+                const uint64_t t2 = __builtin_amdgcn_s_memtime();
+                const bool none = acct.moves == moves_before4;
+                const int b = (was_pruned4 ? 4 : 0) + (none ? 2 : 0);
+                q4[b] += 1;
+                q4[b + 1] += t2 - t4;
+                t4 = t2;
+                if (!was_pruned4 && none) {
+                    uint32_t valid = 0;
+                    for (uint32_t t = t0_4; t <= last_tile; ++t) valid += (dlo4 > dhi4 || t < dlo4 || t > dhi4) ? 1u : 0u;
+                    q4[8] += last_tile - t0_4 + 1u;
+                    q4[9] += valid;
+                }
+            }
+#endif
 #ifdef TL_PROFILE2
             {
                 const uint64_t t2 = __builtin_amdgcn_s_memtime();
@@ -562,6 +596,11 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         moves = acct.moves;
         reversed = acct.reversed;
         rev_lane = acct.rev_lane;
+#ifdef TL_PROFILE4
+        if (d == 0 && lane == 0)
+            printf("sweep %u: dense hit %lu steps %lu cyc | dense none %lu steps %lu cyc, tiles %lu of which with valid boxes %lu | pruned hit %lu steps %lu cyc | pruned none %lu steps %lu cyc\n",
+                   sweeps, q4[0], q4[1], q4[2], q4[3], q4[8], q4[9], q4[4], q4[5], q4[6], q4[7]);
+#endif
 #if !defined(TL_PROFILE2) && !defined(TL_PROFILE3)
         if (tid == 0) {
             uint64_t *st = A.out_stats + (size_t)d * TL_STATS_STRIDE;
