@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define TL_ABI_VERSION 3
+#define TL_ABI_VERSION 4
 
 typedef struct tl_ctx tl_ctx;
 
@@ -197,18 +197,36 @@ int tl_or_opt(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed, 
 int tl_or_opt_find_best_move(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *path,
                              int *found, float *delta, uint32_t *i, uint32_t *j, uint32_t *seg_len, int *reversed);
 
-/* ---- two_opt::solve with the applied moves listed (the reference's progress side channel) ----- */
-/* two_opt.rs:22-24,30-32,53-56,63-65 sends PathUpdate(start), CityChange(path[i]) per outer i of every sweep, PathUpdate(path,
- * new_distance) per improving move and Done — to the one caller that passes a channel (teeline-qt).  The descent runs as one
- * kernel launch, so the messages cannot be sent while it runs; this entry returns, beside tl_two_opt's results (REF_ORDER,
- * coordinates), the list of the moves in the order the reference applies them — move_log[m] = (i << 16) | j for
- * swap_2opt(path, i+1, j), and the word TL_TRACE_SWEEP (0xFFFFFFFF) where a new sweep begins (a row can hold moves of two
- * consecutive sweeps back to back) — from which the caller replays the reference's exact message sequence (every path, every
- * new_distance = d(p[i],p[j]) + d(p[i+1],p[j+1])) after the fact.  *log_len = words = stats->moves + stats->sweeps - 1; if it exceeds
- * log_cap the log holds the first log_cap words.  n beyond the LDS-resident descent (tl_two_opt_lds_max_n) or > 65535: TL_ERR_UNSUPPORTED. */
+/* ---- the solvers with what their progress channel carries listed (ABI v4) ---------------------- */
+/* The reference's solve() functions take Option<&Sender<ProgressMessage>> (two_opt.rs:10, three_opt.rs:19, lin_kernighan.rs:38;
+ * only teeline-qt passes one).  A descent here is one kernel launch (or a device-side state machine), so nothing can be sent
+ * while it runs; the *_trace entries return, beside the plain entry's results, the record from which the caller replays the
+ * reference's exact message sequence after the fact (teeline_amd/host/*.py, teeline_gpu.hpp, integration/teeline-gpu/gpu.rs do).
+ *
+ * tl_two_opt_trace — two_opt.rs:22-24,30-32,53-56,63-65 sends PathUpdate(start), CityChange(path[i]) per outer i of every sweep,
+ * PathUpdate(path, new_distance) per improving move and Done.  move_log[m] = (i << 16) | j for swap_2opt(path, i+1, j) in the
+ * order the reference applies them, and the word TL_TRACE_SWEEP (0xFFFFFFFF) where a new sweep begins (a row can hold moves of
+ * two consecutive sweeps back to back); new_distance = d(p[i],p[j]) + d(p[i+1],p[j+1]) on the path before the move.
+ * *log_len = words = stats->moves + stats->sweeps - 1; if it exceeds log_cap the log holds the first log_cap words.  REF_ORDER;
+ * coordinates (dm_packed NULL; n beyond tl_two_opt_lds_max_n or > 65535: TL_ERR_UNSUPPORTED) or the matrix form (dm_packed,
+ * as tl_two_opt). */
 #define TL_TRACE_SWEEP 0xFFFFFFFFu
-int tl_two_opt_trace(tl_ctx *ctx, const float *xy, uint32_t n, const uint32_t *init_pos, uint32_t *out_pos, float *out_cost,
-                     tl_stats *stats, uint32_t *move_log, uint32_t log_cap, uint32_t *log_len);
+int tl_two_opt_trace(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
+                     uint32_t *out_pos, float *out_cost, tl_stats *stats, uint32_t *move_log, uint32_t log_cap,
+                     uint32_t *log_len);
+/* tl_three_opt_trace — three_opt.rs:34,42,47-49 sends PathUpdate(path, 0.0) for the start path and after every apply_3opt, then
+ * Done.  move_log holds 4 words per applied move, in order: i, j, k, case (three_opt.rs:36-45, apply_3opt :186-218);
+ * *log_len = moves (= stats->moves); the log holds the first log_cap of them. */
+int tl_three_opt_trace(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
+                       uint32_t *out_pos, float *out_cost, tl_stats *stats, uint32_t *move_log, uint32_t log_cap,
+                       uint32_t *log_len);
+/* tl_lk_trace — lin_kernighan.rs:71,90 sends PathUpdate(best_tour, best_dist) after the first lk_pass and after every epoch that
+ * improves on it (no Done).  snap_pos holds those tours (snap_cap x n positions, in order), snap_dist their best_dist (the
+ * Euclidean tour_distance of :118-122, whatever problem.distances holds); *snap_len counts them all, the buffers hold the first
+ * snap_cap.  n < 4: none (:57-59).  Not with TL_FLAG_LK_ONE_WORKGROUP (TL_ERR_UNSUPPORTED). */
+int tl_lk_trace(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
+                const tl_lk_opts *opts, uint64_t seed, uint32_t *out_pos, float *out_cost, tl_stats *stats,
+                uint32_t *snap_pos, float *snap_dist, uint32_t snap_cap, uint32_t *snap_len);
 
 /* ---- LK candidate lists: replaces lin_kernighan::build_candidates (lin_kernighan.rs:12-27) -- */
 /* out: n x min(k, n-1) u32 — the k-NN buffer of the reference's kd-tree query per city (kdtree.rs:193-212, mod.rs:1839-1889):

@@ -12,9 +12,10 @@
 //! computed by `DistanceMatrix::tour_length` itself.
 //!
 //! Behaviour that differs from the CPU functions, all of it documented in INTEGRATION.md:
-//!   * progress: two_opt replays the reference's exact messages (CityChange per outer i, PathUpdate per move) from the move list of
-//!     `tl_two_opt_trace` after the kernel returns; elsewhere `PathUpdate` at the start, one `PathUpdate` with the final tour, `Done` (3-opt/or-opt), instead
-//!     of one message per outer index / move — only the Qt front-end passes a sender;
+//!   * progress: two_opt, three_opt and lin_kernighan send the reference's exact message sequence — CityChange per outer i and
+//!     PathUpdate per move (2-opt), PathUpdate per applied move (3-opt), PathUpdate per best tour (LK) — replayed from the records of
+//!     `tl_two_opt_trace` / `tl_three_opt_trace` / `tl_lk_trace` AFTER the kernels return, not while they run; or_opt and
+//!     nearest_neighbor send `PathUpdate` at the start, one `PathUpdate` with the final tour and `Done` — only the Qt front-end passes a sender;
 //!   * a library error (no gfx950 device, HIP failure) panics with the library's message, like the `.expect(..)`s of the CPU
 //!     code do on bad input: the solver functions are infallible by signature;
 //!   * Lin-Kernighan kicks: the seed of the device-side splitmix64 stream is drawn from `rand::rng()` per call (the CPU
@@ -105,11 +106,13 @@ pub mod two_opt {
         }
         // With a progress channel (only teeline-qt passes one) the descent also lists its moves, and the reference's exact
         // message sequence is replayed from them once the kernel is back (the descent is ONE launch: nothing can be sent
-        // while it runs).  Coordinates only; matrix problems and tours beyond the LDS-resident descent fall back to the
-        // final PathUpdate.
+        // while it runs).  Coordinate tours beyond the LDS-resident descent fall back to the final PathUpdate.
         if let Some(tx) = progress_tx {
-            let traced = ffi::with_context(|ctx| if io.matrix(ctx)?.is_none() { ctx.two_opt_trace(&io.xy, init.as_deref()).map(Some) } else { Ok(None) });
-            if let Ok(Some((t, moves))) = traced {
+            let traced = ffi::with_context(|ctx| {
+                let dm = io.matrix(ctx)?;
+                ctx.two_opt_trace(&io.xy, dm, init.as_deref())
+            });
+            if let Ok((t, moves)) = traced {
                 replay_progress(problem, &io, init.as_deref(), &moves, t.stats.sweeps, tx);
                 let route = io.ids(&t.pos);
                 let sol = Solution::new(&route, problem);
@@ -168,14 +171,53 @@ pub mod three_opt {
         tracing::info!(cities = problem.cities.len(), "3-opt (gpu) starting");
         let io = Boundary::new(problem);
         let init = init_tour.map(|t| io.positions(t, "three_opt: invalid city pair"));
-        if let Some(tx) = progress_tx {
-            let _ = tx.send(ProgressMessage::PathUpdate(Route::new(&start_tour(problem, init_tour)), 0.0));
+        let n = problem.cities.len();
+        // With a progress channel the solve also lists its moves, and the reference's message sequence — the start path, the path
+        // after every apply_3opt (each with 0.0), Done (three_opt.rs:34,42,47-49; nothing when n < 4, :25-28) — is replayed from them.
+        if let (Some(tx), true) = (progress_tx, n >= 4) {
+            let (t, moves) = unwrap_gpu("three_opt (gpu)", ffi::with_context(|ctx| {
+                let dm = io.matrix(ctx)?;
+                ctx.three_opt_trace(&io.xy, dm, init.as_deref())
+            }));
+            let mut pos: Vec<u32> = init.clone().unwrap_or_else(|| (0..n as u32).collect());
+            let _ = tx.send(ProgressMessage::PathUpdate(Route::new(&io.ids(&pos)), 0.0));
+            for m in &moves {
+                apply_3opt(&mut pos, m[0] as usize, m[1] as usize, m[2] as usize, m[3]);
+                let _ = tx.send(ProgressMessage::PathUpdate(Route::new(&io.ids(&pos)), 0.0));
+            }
+            let _ = tx.send(ProgressMessage::Done);
+            return finish(problem, &io, &t, None, false);
         }
         let t = unwrap_gpu("three_opt (gpu)", ffi::with_context(|ctx| {
             let dm = io.matrix(ctx)?;
             ctx.three_opt(&io.xy, dm, init.as_deref())
         }));
-        finish(problem, &io, &t, progress_tx, true)
+        finish(problem, &io, &t, None, false)
+    }
+
+    /// three_opt.rs:186-218 on positions: cases 1-3 reverse segments, 4-7 swap path[i+1..=j] and path[j+1..=k] with either reversed.
+    fn apply_3opt(path: &mut [u32], i: usize, j: usize, k: usize, case: u32) {
+        match case {
+            1 => path[i + 1..=j].reverse(),
+            2 => path[j + 1..=k].reverse(),
+            3 => {
+                path[i + 1..=j].reverse();
+                path[j + 1..=k].reverse();
+            }
+            4..=7 => {
+                let mut seg1 = path[i + 1..=j].to_vec();
+                let mut seg2 = path[j + 1..=k].to_vec();
+                if case == 5 || case == 7 {
+                    seg1.reverse();
+                }
+                if case == 6 || case == 7 {
+                    seg2.reverse();
+                }
+                seg2.extend_from_slice(&seg1);
+                path[i + 1..=k].copy_from_slice(&seg2);
+            }
+            _ => unreachable!("apply_3opt: case must be 1-7, got {case}"),
+        }
     }
 }
 
@@ -241,12 +283,23 @@ pub mod lin_kernighan {
             .ok()
             .and_then(|v| v.parse::<u64>().ok())
             .unwrap_or_else(|| rand::rng().random::<u64>());
+        // lin_kernighan.rs sends PathUpdate(best_tour, best_dist) after the first lk_pass and for every improving epoch, never Done
+        // (:71,:90; nothing when n < 4, :57-59): with a channel the device-side state machine lists exactly those.
+        if let (Some(tx), true) = (progress_tx, problem.cities.len() >= 4) {
+            let (t, snaps) = unwrap_gpu("lin_kernighan (gpu)", ffi::with_context(|ctx| {
+                let dm = io.matrix(ctx)?;
+                ctx.lin_kernighan_trace(&io.xy, dm, init.as_deref(), lk, seed)
+            }));
+            for (pos, dist) in &snaps {
+                let _ = tx.send(ProgressMessage::PathUpdate(Route::new(&io.ids(pos)), *dist));
+            }
+            return finish(problem, &io, &t, None, false);
+        }
         let t = unwrap_gpu("lin_kernighan (gpu)", ffi::with_context(|ctx| {
             // problem.distances feeds the NN seed and the total only; the search is Euclidean (lin_kernighan.rs:41,47-55,99)
             let dm = io.matrix(ctx)?;
             ctx.lin_kernighan(&io.xy, dm, init.as_deref(), lk, seed)
         }));
-        // lin_kernighan.rs sends PathUpdate for every improvement and never Done (:71,:90)
-        finish(problem, &io, &t, progress_tx, false)
+        finish(problem, &io, &t, None, false)
     }
 }

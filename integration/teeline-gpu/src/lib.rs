@@ -20,7 +20,7 @@ use std::ffi::{c_char, c_int, CStr};
 use std::fmt;
 use std::ptr;
 
-pub const TL_ABI_VERSION: c_int = 3;
+pub const TL_ABI_VERSION: c_int = 4;
 
 #[repr(C)]
 pub struct TlCtx {
@@ -65,8 +65,13 @@ unsafe extern "C" {
     fn tl_tour_length(ctx: *mut TlCtx, xy: *const f32, dm_packed: *const f32, n: u32, perm: *const u32, out_cost: *mut f32) -> c_int;
     fn tl_two_opt(ctx: *mut TlCtx, xy: *const f32, n: u32, dm_packed: *const f32, init_pos: *const u32, mode: c_int,
                   out_pos: *mut u32, out_cost: *mut f32, stats: *mut Stats) -> c_int;
-    fn tl_two_opt_trace(ctx: *mut TlCtx, xy: *const f32, n: u32, init_pos: *const u32, out_pos: *mut u32, out_cost: *mut f32,
-                        stats: *mut Stats, move_log: *mut u32, log_cap: u32, log_len: *mut u32) -> c_int;
+    fn tl_two_opt_trace(ctx: *mut TlCtx, xy: *const f32, n: u32, dm_packed: *const f32, init_pos: *const u32, out_pos: *mut u32,
+                        out_cost: *mut f32, stats: *mut Stats, move_log: *mut u32, log_cap: u32, log_len: *mut u32) -> c_int;
+    fn tl_three_opt_trace(ctx: *mut TlCtx, xy: *const f32, n: u32, dm_packed: *const f32, init_pos: *const u32, out_pos: *mut u32,
+                          out_cost: *mut f32, stats: *mut Stats, move_log: *mut u32, log_cap: u32, log_len: *mut u32) -> c_int;
+    fn tl_lk_trace(ctx: *mut TlCtx, xy: *const f32, n: u32, dm_packed: *const f32, init_pos: *const u32, opts: *const LkOpts, seed: u64,
+                   out_pos: *mut u32, out_cost: *mut f32, stats: *mut Stats, snap_pos: *mut u32, snap_dist: *mut f32, snap_cap: u32,
+                   snap_len: *mut u32) -> c_int;
     fn tl_three_opt(ctx: *mut TlCtx, xy: *const f32, n: u32, dm_packed: *const f32, init_pos: *const u32,
                     out_pos: *mut u32, out_cost: *mut f32, stats: *mut Stats) -> c_int;
     fn tl_or_opt(ctx: *mut TlCtx, xy: *const f32, n: u32, dm_packed: *const f32, init_pos: *const u32,
@@ -223,21 +228,22 @@ impl Context {
         self.check(rc).map(|_| t)
     }
 
-    /// `two_opt::solve` on coordinates together with the moves it applied, `(i, j)` in the reference's order (`swap_2opt(path, i+1, j)`,
-    /// two_opt.rs:50): what `gpu::two_opt::solve` replays the reference's per-move progress messages from.  `Err(Unsupported)`
-    /// beyond the LDS-resident descent.
+    /// `two_opt::solve` together with the moves it applied, `(i, j)` in the reference's order (`swap_2opt(path, i+1, j)`,
+    /// two_opt.rs:50): what `gpu::two_opt::solve` replays the reference's per-move progress messages from.  Coordinates
+    /// (`dm_packed` None; `Err(Unsupported)` beyond the LDS-resident descent) or the matrix form.
     /// The list holds `Some((i, j))` per move and `None` where a new sweep begins (`TL_TRACE_SWEEP`).
-    pub fn two_opt_trace(&self, xy: &[f32], init_pos: Option<&[u32]>) -> Result<(Tour, Vec<Option<(u32, u32)>>), Error> {
+    pub fn two_opt_trace(&self, xy: &[f32], dm_packed: Option<&[f32]>, init_pos: Option<&[u32]>) -> Result<(Tour, Vec<Option<(u32, u32)>>), Error> {
         let n = Self::n_of(xy);
-        Self::check_inputs(n, None, init_pos);
+        Self::check_inputs(n, dm_packed, init_pos);
         let mut t = Tour { pos: vec![0u32; n as usize], cost: 0.0, stats: Stats::default() };
         let mut cap = (16 * n).max(64);
         loop {
             let mut log = vec![0u32; cap as usize];
             let mut len = 0u32;
-            // SAFETY: every buffer has the length the C ABI documents (n, 2n, log_cap), checked above.
+            // SAFETY: every buffer has the length the C ABI documents (n, 2n, n(n-1)/2, log_cap), checked above.
             let rc = unsafe {
-                tl_two_opt_trace(self.raw, xy.as_ptr(), n, opt_ptr(init_pos), t.pos.as_mut_ptr(), &mut t.cost, &mut t.stats, log.as_mut_ptr(), cap, &mut len)
+                tl_two_opt_trace(self.raw, xy.as_ptr(), n, opt_ptr(dm_packed), opt_ptr(init_pos), t.pos.as_mut_ptr(), &mut t.cost, &mut t.stats,
+                                 log.as_mut_ptr(), cap, &mut len)
             };
             self.check(rc)?;
             if len <= cap {
@@ -245,6 +251,55 @@ impl Context {
                 return Ok((t, log.into_iter().map(|w| if w == 0xFFFF_FFFF { None } else { Some((w >> 16, w & 0xFFFF)) }).collect()));
             }
             cap = len; // the descent is deterministic: once more with room for every move
+        }
+    }
+
+    /// `three_opt::solve` together with the moves it applied, `(i, j, k, case)` in order (three_opt.rs:36-45): what
+    /// `gpu::three_opt::solve` replays the reference's per-move `PathUpdate`s from.
+    pub fn three_opt_trace(&self, xy: &[f32], dm_packed: Option<&[f32]>, init_pos: Option<&[u32]>) -> Result<(Tour, Vec<[u32; 4]>), Error> {
+        let n = Self::n_of(xy);
+        Self::check_inputs(n, dm_packed, init_pos);
+        let mut t = Tour { pos: vec![0u32; n as usize], cost: 0.0, stats: Stats::default() };
+        let mut cap = (4 * n).max(64);
+        loop {
+            let mut log = vec![0u32; 4 * cap as usize];
+            let mut len = 0u32;
+            // SAFETY: as in two_opt_trace; the log holds 4 words per move.
+            let rc = unsafe {
+                tl_three_opt_trace(self.raw, xy.as_ptr(), n, opt_ptr(dm_packed), opt_ptr(init_pos), t.pos.as_mut_ptr(), &mut t.cost, &mut t.stats,
+                                   log.as_mut_ptr(), cap, &mut len)
+            };
+            self.check(rc)?;
+            if len <= cap {
+                return Ok((t, log.chunks_exact(4).take(len as usize).map(|m| [m[0], m[1], m[2], m[3]]).collect()));
+            }
+            cap = len;
+        }
+    }
+
+    /// `lin_kernighan::solve` together with every best tour it settles on and its `best_dist`, in order (lin_kernighan.rs:71,90):
+    /// what `gpu::lin_kernighan::solve` sends as `PathUpdate`s.
+    pub fn lin_kernighan_trace(&self, xy: &[f32], dm_packed: Option<&[f32]>, init_pos: Option<&[u32]>, opts: LkOpts, seed: u64)
+                               -> Result<(Tour, Vec<(Vec<u32>, f32)>), Error> {
+        let n = Self::n_of(xy);
+        Self::check_inputs(n, dm_packed, init_pos);
+        let mut t = Tour { pos: vec![0u32; n as usize], cost: 0.0, stats: Stats::default() };
+        let mut cap = (opts.epochs + 1).min(64).max(1);
+        loop {
+            let mut snaps = vec![0u32; cap as usize * n as usize];
+            let mut dists = vec![0f32; cap as usize];
+            let mut len = 0u32;
+            // SAFETY: as in two_opt_trace; snap_pos holds snap_cap x n positions, snap_dist snap_cap values.
+            let rc = unsafe {
+                tl_lk_trace(self.raw, xy.as_ptr(), n, opt_ptr(dm_packed), opt_ptr(init_pos), &opts, seed, t.pos.as_mut_ptr(), &mut t.cost, &mut t.stats,
+                            snaps.as_mut_ptr(), dists.as_mut_ptr(), cap, &mut len)
+            };
+            self.check(rc)?;
+            if len <= cap {
+                let list = snaps.chunks_exact(n as usize).take(len as usize).zip(dists).map(|(p, d)| (p.to_vec(), d)).collect();
+                return Ok((t, list));
+            }
+            cap = len; // deterministic for a seed: once more with room for every snapshot
         }
     }
 

@@ -141,6 +141,11 @@ int tlo_lin_kernighan(const float *xy, uint32_t n, const uint32_t *init, uint32_
 int tlo_lin_kernighan_cand(const float *xy, const float *packed, uint32_t n, const uint32_t *init, uint32_t epochs,
                            uint32_t platoo_epochs, uint32_t n_nearest, uint32_t max_depth, uint64_t seed,
                            const uint32_t *cand, uint32_t *out_perm, float *out_cost, tlo_stats *stats);
+/* the same solve (kd-tree candidate lists) with the progress messages of lin_kernighan.rs:71,90 recorded: every best tour the
+ * search settles on (positions) and its best_dist, in order; at most cap tours are stored, *count counts them all */
+int tlo_lin_kernighan_trace(const float *xy, const float *packed, uint32_t n, const uint32_t *init, uint32_t epochs,
+                            uint32_t platoo_epochs, uint32_t n_nearest, uint32_t max_depth, uint64_t seed,
+                            uint32_t *out, float *out_cost, tlo_stats *st, uint32_t *snaps, float *snap_dist, uint32_t cap, uint32_t *count);
 /* lin_kernighan.rs:134-145 */
 void tlo_flat_to_next_prev(const uint32_t *tour, uint32_t n, uint32_t *next, uint32_t *prev);
 /* lin_kernighan.rs:345-389 on a flat tour (city_ids = the tour, as the reference's unit tests call it); out_chain needs

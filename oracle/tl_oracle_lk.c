@@ -346,10 +346,15 @@ static inline uint64_t sm64(uint64_t *state)
 }
 
 /* lin_kernighan.rs:35-100; cand_in = precomputed candidate lists (n x min(n_nearest, n-1)) or NULL (brute force) */
-int tlo_lin_kernighan_cand(const float *xy, const float *packed, uint32_t n, const uint32_t *init, uint32_t epochs,
-                           uint32_t platoo_epochs, uint32_t n_nearest, uint32_t max_depth, uint64_t seed,
-                           const uint32_t *cand_in, uint32_t *out, float *out_cost, tlo_stats *st)
+/* snaps / snap_dist (optional): what the reference sends as PathUpdate(best_tour, best_dist) (:71, :90), in order — at most cap
+ * tours of n positions; *count counts them all */
+static int lk_solve_impl(const float *xy, const float *packed, uint32_t n, const uint32_t *init, uint32_t epochs,
+                         uint32_t platoo_epochs, uint32_t n_nearest, uint32_t max_depth, uint64_t seed,
+                         const uint32_t *cand_in, uint32_t *out, float *out_cost, tlo_stats *st,
+                         uint32_t *snaps, float *snap_dist, uint32_t cap, uint32_t *count)
 {
+    uint32_t nsnap = 0;
+    if (count) *count = 0;
     if (!xy || !out || n == 0) return TLO_ERR_BADARG;
     if (st) memset(st, 0, sizeof(*st));
     uint32_t k = n_nearest;
@@ -367,6 +372,10 @@ int tlo_lin_kernighan_cand(const float *xy, const float *packed, uint32_t n, con
     if (n >= 4) { /* :57-59 */
         tlo_lk_pass(xy, n, out, cand, k, max_depth, st); /* :61-68 */
         float best_dist = lk_tour_distance(xy, out, n);   /* :70 */
+        if (snaps) { /* :71 send_progress */
+            if (nsnap < cap) { memcpy(snaps + (size_t)nsnap * n, out, (size_t)n * sizeof(uint32_t)); snap_dist[nsnap] = best_dist; }
+            ++nsnap;
+        }
         uint64_t rng = seed;
         uint32_t platoo = 0;
         for (uint32_t e = 0; e < epochs; ++e) { /* :75 */
@@ -380,6 +389,10 @@ int tlo_lin_kernighan_cand(const float *xy, const float *packed, uint32_t n, con
                 memcpy(out, candidate, (size_t)n * sizeof(uint32_t));
                 best_dist = dist;
                 platoo = 0;
+                if (snaps) { /* :90 send_progress */
+                    if (nsnap < cap) { memcpy(snaps + (size_t)nsnap * n, out, (size_t)n * sizeof(uint32_t)); snap_dist[nsnap] = best_dist; }
+                    ++nsnap;
+                }
             } else {
                 if (++platoo >= platoo_epochs) break; /* :92-95 */
             }
@@ -390,7 +403,24 @@ int tlo_lin_kernighan_cand(const float *xy, const float *packed, uint32_t n, con
     /* :99 Solution::new -> total through problem.distances.tour_length (the search above used the Euclidean matrix
      * rebuilt from the coordinates, :41) */
     if (out_cost) *out_cost = tlo_tour_length(packed ? NULL : xy, packed, n, out);
+    if (count) *count = nsnap;
     return TLO_OK;
+}
+
+int tlo_lin_kernighan_cand(const float *xy, const float *packed, uint32_t n, const uint32_t *init, uint32_t epochs,
+                           uint32_t platoo_epochs, uint32_t n_nearest, uint32_t max_depth, uint64_t seed,
+                           const uint32_t *cand_in, uint32_t *out, float *out_cost, tlo_stats *st)
+{
+    return lk_solve_impl(xy, packed, n, init, epochs, platoo_epochs, n_nearest, max_depth, seed, cand_in, out, out_cost, st, NULL, NULL, 0, NULL);
+}
+
+/* the same solve with the progress messages of lin_kernighan.rs:71,90 recorded (tours as positions, best_dist) */
+int tlo_lin_kernighan_trace(const float *xy, const float *packed, uint32_t n, const uint32_t *init, uint32_t epochs,
+                            uint32_t platoo_epochs, uint32_t n_nearest, uint32_t max_depth, uint64_t seed,
+                            uint32_t *out, float *out_cost, tlo_stats *st, uint32_t *snaps, float *snap_dist, uint32_t cap, uint32_t *count)
+{
+    if (!snaps || !snap_dist || !count) return TLO_ERR_BADARG;
+    return lk_solve_impl(xy, packed, n, init, epochs, platoo_epochs, n_nearest, max_depth, seed, NULL, out, out_cost, st, snaps, snap_dist, cap, count);
 }
 
 int tlo_lin_kernighan(const float *xy, uint32_t n, const uint32_t *init, uint32_t epochs,

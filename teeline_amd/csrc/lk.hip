@@ -1269,6 +1269,19 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
         return r;
     };
 
+    // lin_kernighan.rs:71,90 send_progress(best_tour, best_dist): the tour just copied into `best` and its length, appended to
+    // the caller's snapshot list (tl_lk_trace)
+    auto snapshot = [&](const uint32_t *t, float d) {
+        if (!G.snap) return;
+        const uint32_t sidx = S->snaps;
+        TL_SYNC();  // every thread has read the count
+        if (sidx < G.snap_cap) {
+            for (uint32_t r = tid; r < n; r += kLkNT) G.snap[(size_t)sidx * n + r] = t[r];
+            if (tid == 0) G.snap_dist[sidx] = d;
+        }
+        if (tid == 0) S->snaps = sidx + 1u;
+    };
+
     const uint32_t key = CHIP ? S->key2[G.parity] : S->key;
     if (!CHIP && tid == 0) S->applied = 0u;  // set again below if this round applies a move (k_lk_rebuild runs after every control)
     TL_SYNC();
@@ -1403,6 +1416,7 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
             S->epoch = 0;
             S->platoo = 0;
         }
+        snapshot(tour, bd);
         kick = G.epochs > 0;
     } else {                                    // an epoch's pass done (:85-96)
         const float dcur = tour_distance(tour);
@@ -1411,6 +1425,7 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
         bool stop = false;
         if (better) {
             for (uint32_t r = tid; r < n; r += kLkNT) best[r] = tour[r];
+            snapshot(tour, dcur);
         }
         uint32_t platoo = S->platoo, epoch = S->epoch;
         TL_SYNC();
@@ -1486,6 +1501,7 @@ __global__ __launch_bounds__(kLkNT) void k_lk_begin(LkArgs G)
     }
     if (tid == 0) {
         LkState *S = G.state;
+        S->snaps = 0u;
         S->key = 0xFFFFFFFFu;
         S->key2[0] = S->key2[1] = 0xFFFFFFFFu;
         S->flip = S->flip_next = 0u;

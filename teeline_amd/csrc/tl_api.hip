@@ -320,7 +320,6 @@ static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uin
     A.init_mode = init_mode;
     A.move_log = d_move_log;
     A.log_cap = log_cap;
-    if (d_move_log && d_dm) return fail(c, TL_ERR_UNSUPPORTED, "two_opt: the move log is written by the coordinate kernel only (dm_packed must be NULL)");
     // every size / mode check comes before the first event record: a rejected call must leave the event pair of the
     // previous kernel sequence intact
     if (d_dm) {
@@ -524,31 +523,45 @@ extern "C" int tl_two_opt(tl_ctx *c, const float *xy, uint32_t n, const float *d
     return TL_OK;
 }
 
-// tl_two_opt on coordinates + the list of the moves it applied, in the reference's order: what a caller that was handed a
-// progress channel (two_opt.rs:9-10; only teeline-qt passes one) replays CityChange / PathUpdate from.  The control wave of the
-// descent's workgroup writes the list (row << 16 | column per move); nothing else about the descent changes.
-extern "C" int tl_two_opt_trace(tl_ctx *c, const float *xy, uint32_t n, const uint32_t *init_pos, uint32_t *out_pos, float *out_cost,
-                                tl_stats *stats, uint32_t *move_log, uint32_t log_cap, uint32_t *log_len)
+// tl_two_opt + the list of the moves it applied, in the reference's order: what a caller that was handed a progress channel
+// (two_opt.rs:9-10; only teeline-qt passes one) replays CityChange / PathUpdate from.  The control wave of the descent's
+// workgroup (coordinates) or thread 0 (matrix form) writes the list (row << 16 | column per move, 0xFFFFFFFF where a sweep
+// begins); nothing else about the descent changes.
+extern "C" int tl_two_opt_trace(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos, uint32_t *out_pos,
+                                float *out_cost, tl_stats *stats, uint32_t *move_log, uint32_t log_cap, uint32_t *log_len)
 {
-    if (!c || !xy || !out_pos || !move_log || !log_len) return fail(c, TL_ERR_BADARG, "tl_two_opt_trace: NULL argument");
+    if (!c || (!xy && !dm_packed) || !out_pos || !move_log || !log_len) return fail(c, TL_ERR_BADARG, "tl_two_opt_trace: NULL argument");
     if (n < 3) return fail(c, TL_ERR_REF_PANICS, "two_opt: n=%u < 3 — the reference underflows `n_indices - 2` (two_opt.rs:17,29)", n);
     if (init_pos && !is_permutation(init_pos, n)) return fail(c, TL_ERR_BADARG, "tl_two_opt_trace: init tour is not a permutation of 0..n-1");
-    if (n > lds_max_n(c->lds_bytes) || n > 65535u)
+    if (!dm_packed && (n > lds_max_n(c->lds_bytes) || n > 65535u))
         return fail(c, TL_ERR_UNSUPPORTED, "tl_two_opt_trace: n=%u exceeds the LDS-resident descent (%u): no move log beyond it", n, lds_max_n(c->lds_bytes));
     const auto t0 = std::chrono::steady_clock::now();
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
     if ((rc = ensure(c, c->out_pos, (size_t)n * 4)) || (rc = ensure(c, c->out_cost, 4)) || (rc = ensure(c, c->out_stats, TL_STATS_STRIDE * 8)) ||
-        (rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->work, (size_t)(log_cap ? log_cap : 1) * 4)))
+        (rc = ensure(c, c->work, (size_t)(log_cap ? log_cap : 1) * 4)))
         return rc;
-    HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    const float2 *dxy = nullptr;
+    const float *ddm = nullptr;
+    if (dm_packed) {
+        const size_t b = (size_t)n * (n - 1) / 2 * 4;
+        if ((rc = ensure(c, c->dm, b))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->dm.p, dm_packed, b, hipMemcpyHostToDevice, c->stream));
+        ddm = (const float *)c->dm.p;
+    }
+    if (xy) {
+        if ((rc = ensure(c, c->xy, (size_t)n * 8))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+        dxy = (const float2 *)c->xy.p;
+    }
     const uint32_t *dinit = nullptr;
     if (init_pos) {
         if ((rc = ensure(c, c->init, (size_t)n * 4))) return rc;
         HIPCHK(c, hipMemcpyAsync(c->init.p, init_pos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
         dinit = (const uint32_t *)c->init.p;
     }
-    if ((rc = two_opt_enqueue(c, (const float2 *)c->xy.p, nullptr, n, dinit, dinit ? TL_INIT_ARRAY : TL_INIT_IDENTITY, 0, 0, 1, TL_MODE_REF_ORDER,
+    HIPCHK(c, hipMemsetAsync(c->out_stats.p, 0, TL_STATS_STRIDE * 8, c->stream));
+    if ((rc = two_opt_enqueue(c, dxy, ddm, n, dinit, dinit ? TL_INIT_ARRAY : TL_INIT_IDENTITY, 0, 0, 1, TL_MODE_REF_ORDER,
                               (uint32_t *)c->out_pos.p, (float *)c->out_cost.p, (uint64_t *)c->out_stats.p, c->stream, (uint32_t *)c->work.p, log_cap)))
         return rc;
     uint64_t raw[TL_STATS_STRIDE];
@@ -907,9 +920,11 @@ extern "C" int tl_three_opt_find_best_move(tl_ctx *c, const float *xy, uint32_t 
     return TL_OK;
 }
 
-extern "C" int tl_three_opt(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
-                            uint32_t *out_pos, float *out_cost, tl_stats *stats)
+// move_log (optional): 4 words per applied move — i, j, k, case of three_opt.rs:36-45 in order — at most log_cap moves; *log_len = moves
+static int three_opt_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
+                         uint32_t *out_pos, float *out_cost, tl_stats *stats, uint32_t *move_log, uint32_t log_cap, uint32_t *log_len)
 {
+    if (log_len) *log_len = 0;
     if (!c || (!xy && !dm_packed) || !out_pos) return fail(c, TL_ERR_BADARG, "tl_three_opt: NULL argument");
     const auto t0 = std::chrono::steady_clock::now();
     if (stats) memset(stats, 0, sizeof(*stats));
@@ -939,6 +954,13 @@ extern "C" int tl_three_opt(tl_ctx *c, const float *xy, uint32_t n, const float 
         HIPCHK(c, hipStreamSynchronize(c->stream));
         ++passes;
         if (!b.found) break;  // three_opt.rs:36-45
+        if (move_log && moves < log_cap) {
+            uint32_t *w = move_log + 4 * moves;
+            w[0] = b.ij >> 16;
+            w[1] = b.ij & 0xFFFFu;
+            w[2] = b.kc >> 3;
+            w[3] = b.kc & 7u;
+        }
         ++moves;
         if (passes > cap) return fail(c, TL_ERR_NO_CONVERGE, "three_opt: pass cap reached");
     }
@@ -963,7 +985,23 @@ extern "C" int tl_three_opt(tl_ctx *c, const float *xy, uint32_t n, const float 
         stats->kernel_ms = kms;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
+    if (log_len) *log_len = (uint32_t)moves;
     return TL_OK;
+}
+
+extern "C" int tl_three_opt(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
+                            uint32_t *out_pos, float *out_cost, tl_stats *stats)
+{
+    return three_opt_run(c, xy, n, dm_packed, init_pos, out_pos, out_cost, stats, nullptr, 0, nullptr);
+}
+
+// three_opt::solve with its moves listed: the reference sends the path after every apply_3opt (three_opt.rs:34,42,47-49); the
+// host loop here already reads every move back (one word pair per pass), so the list costs nothing.
+extern "C" int tl_three_opt_trace(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
+                                  uint32_t *out_pos, float *out_cost, tl_stats *stats, uint32_t *move_log, uint32_t log_cap, uint32_t *log_len)
+{
+    if (!move_log || !log_len) return fail(c, TL_ERR_BADARG, "tl_three_opt_trace: NULL argument");
+    return three_opt_run(c, xy, n, dm_packed, init_pos, out_pos, out_cost, stats, move_log, log_cap, log_len);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1229,9 +1267,13 @@ extern "C" int tl_nearest_neighbor(tl_ctx *c, const float *xy, const float *dm_p
     return TL_OK;
 }
 
-extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos, const tl_lk_opts *opts,
-                     uint64_t seed, uint32_t *out_pos, float *out_cost, tl_stats *stats)
+// snap_pos / snap_dist (optional): every best tour the search settles on, in order, and its best_dist — what the reference sends
+// as PathUpdate(best_tour, best_dist) (lin_kernighan.rs:71,90); *snap_len counts them all, the buffers hold the first snap_cap
+static int lk_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos, const tl_lk_opts *opts,
+                  uint64_t seed, uint32_t *out_pos, float *out_cost, tl_stats *stats, uint32_t *snap_pos, float *snap_dist, uint32_t snap_cap,
+                  uint32_t *snap_len)
 {
+    if (snap_len) *snap_len = 0;
     if (!c || !xy || !out_pos) return fail(c, TL_ERR_BADARG, "tl_lk: NULL argument");
     if (n == 0) return fail(c, TL_ERR_BADARG, "tl_lk: n == 0");
     tl_lk_opts o{100, 10, 5, 5};  // LKOptions::default(), mod.rs:1255-1267
@@ -1340,6 +1382,13 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const float *dm_pac
     G.split_levels = levels;
     G.fused_pick = fused_pick ? 1u : 0u;
     G.chip_step = (fused_pick && levels == 3u && n >= 1500u && !(tf & TL_FLAG_LK_SEPARATE_STEP)) ? 1u : 0u;
+    if (snap_pos) {
+        if (!multi_cu) return fail(c, TL_ERR_UNSUPPORTED, "tl_lk_trace: the single-workgroup forms record no snapshots");
+        if ((rc = ensure(c, c->out_pos, (size_t)(snap_cap ? snap_cap : 1) * n * 4)) || (rc = ensure(c, c->out_stats, (size_t)(snap_cap ? snap_cap : 1) * 4))) return rc;
+        G.snap = (uint32_t *)c->out_pos.p;
+        G.snap_dist = (float *)c->out_stats.p;
+        G.snap_cap = snap_cap;
+    }
     if (split_scan) HIPCHK(c, hipMemsetAsync(G.pairmin, 0xFF, (size_t)2 * n * 4, c->stream));
     uint64_t cnt[4] = {0, 0, 0, 0};
     if (!multi_cu) {
@@ -1386,6 +1435,14 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const float *dm_pac
         cnt[1] = hs.searches;
         cnt[2] = hs.moves;
         cnt[3] = hs.exchanged;
+        if (snap_pos) {
+            if (snap_len) *snap_len = hs.snaps;
+            const uint32_t have = hs.snaps < snap_cap ? hs.snaps : snap_cap;
+            if (have) {
+                HIPCHK(c, hipMemcpyAsync(snap_pos, G.snap, (size_t)have * n * 4, hipMemcpyDeviceToHost, c->stream));
+                if (snap_dist) HIPCHK(c, hipMemcpyAsync(snap_dist, G.snap_dist, (size_t)have * 4, hipMemcpyDeviceToHost, c->stream));
+            }
+        }
     }
     // lin_kernighan.rs:99 Solution::new -> total through problem.distances.tour_length (closing edge first)
     HIPCHK(c, launch_tour_length(ddm ? nullptr : G.xy, ddm, n, G.best, (float *)c->out_cost.p, c->stream));
@@ -1408,4 +1465,21 @@ extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const float *dm_pac
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     return TL_OK;
+}
+
+extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos, const tl_lk_opts *opts,
+                     uint64_t seed, uint32_t *out_pos, float *out_cost, tl_stats *stats)
+{
+    return lk_run(c, xy, n, dm_packed, init_pos, opts, seed, out_pos, out_cost, stats, nullptr, nullptr, 0, nullptr);
+}
+
+// lin_kernighan::solve with the best tours it passes through listed (the reference's progress side channel: one
+// PathUpdate(best_tour, best_dist) after the first lk_pass and one per improving epoch, lin_kernighan.rs:71,90) — the device-side
+// state machine copies each into the caller's list as it settles on it.
+extern "C" int tl_lk_trace(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos, const tl_lk_opts *opts,
+                           uint64_t seed, uint32_t *out_pos, float *out_cost, tl_stats *stats, uint32_t *snap_pos, float *snap_dist,
+                           uint32_t snap_cap, uint32_t *snap_len)
+{
+    if (!snap_pos || !snap_dist || !snap_len) return fail(c, TL_ERR_BADARG, "tl_lk_trace: NULL argument");
+    return lk_run(c, xy, n, dm_packed, init_pos, opts, seed, out_pos, out_cost, stats, snap_pos, snap_dist, snap_cap, snap_len);
 }

@@ -163,6 +163,7 @@ struct LkState {             // device-side state machine of the multi-CU LK var
     uint32_t applied;        // k_lk_control applied a move into `alt`: k_lk_rebuild copies it back and rebuilds pos / next / prev
     uint32_t key2[2];        // chip-wide step: the scan's key, double-buffered by round parity
     uint32_t flip, flip_next;  // chip-wide step: which tour buffer is current (0: tour, 1: alt); handed over by the next scan
+    uint32_t snaps;          // best tours recorded so far (LkArgs::snap; counted on beyond snap_cap)
 };
 struct LkArgs {
     const float2 *xy;
@@ -189,6 +190,9 @@ struct LkArgs {
     uint32_t parity;        // round & 1 (set per launch)
     uint32_t fused_pick;    // split scan, one workgroup per pair: the workgroup picks its first chain and validates it itself
                             // (no k_lk_scan_pick launch, no pairmin / subchains traffic)
+    uint32_t *snap;         // optional [snap_cap][n]: every best tour the search settles on, in order — what the reference sends as
+    float *snap_dist;       // PathUpdate(best_tour, best_dist) (lin_kernighan.rs:71,90) — and its best_dist; nullptr = not recorded
+    uint32_t snap_cap;
 };
 // form: 0 = default (16 lanes per city up to n = 32 K, 4 beyond), 4 = four lanes per city, 1 = one lane per city
 hipError_t launch_knn(const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, hipStream_t s, int form = 0);

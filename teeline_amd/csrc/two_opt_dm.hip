@@ -116,6 +116,9 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
     uint64_t moves = 0, reversed = 0;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     constexpr uint32_t NWv = kDmNT / 64;
+    // optional move log (tl_two_opt_trace): (i << 16) | j per applied move in the reference's order, 0xFFFFFFFF where a new sweep begins
+    uint32_t *mlog = A.move_log ? A.move_log + (size_t)d * A.log_cap : nullptr;
+    uint32_t log_n = 0;
     uint32_t since_rows = 0;  // rows scanned since the last move
     uint32_t gap_rows = 0;    // ... and its running average over the recent moves: the block shape follows the larger of the two
 
@@ -292,8 +295,10 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
                     edge[hi] = hl_b[ww * kDmChain + h];
                 }
                 reversed += (uint64_t)(hi - is);
+                if (mlog && tid == 0 && log_n + h < A.log_cap) mlog[log_n + h] = (is << 16) | hi;
                 TL_SYNC();
             }
+            log_n += nh;
             improved = true;
             moves += nh;
             i0 = is;
@@ -317,6 +322,8 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
             ++sweeps;
             i0 = 0;
             j0 = 2;
+            if (mlog && tid == 0 && log_n < A.log_cap) mlog[log_n] = 0xFFFFFFFFu;
+            log_n += 1u;
         }
     }
 
@@ -339,6 +346,7 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
 #endif
         st[3] = status;
         st[4] = step;
+        st[15] = log_n;  // words offered to the move log (moves + sweep marks)
 #ifdef TL_DM_PROFILE
         printf("dmprof dense: setup %lu first %lu chain %lu wait %lu boundary %lu steps %lu | wide: staging %lu scan %lu wait %lu boundary %lu steps %lu\n", qd[0], qd[1], qd[2], qd[3], qd[4], qd[5], qd[8], qd[10], qd[11], qd[12], qd[13]);
 #endif

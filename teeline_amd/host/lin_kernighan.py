@@ -5,6 +5,10 @@ import numpy as np
 
 
 def solve(problem, opts=None, progress_tx=None, init_tour=None, *, ctx=None, seed=1):
+    """progress_tx: optional callable(kind, payload) — the reference's mpsc::Sender<ProgressMessage>.  The reference sends
+    PathUpdate(best_tour, best_dist) after the first lk_pass and after every epoch that improves on it, and no Done
+    (lin_kernighan.rs:71,90; nothing when n < 4, :57-59).  With a channel the solve goes through tl_lk_trace, whose device-side
+    state machine lists exactly those tours and distances, and they are sent in order once it is back."""
     from . import LKOptions, Solution, default_context
     from .. import _capi
     ctx = ctx or default_context()
@@ -19,14 +23,25 @@ def solve(problem, opts=None, progress_tx=None, init_tour=None, *, ctx=None, see
     # GEO / EXPLICIT problems: the search is Euclidean over the city coordinates (lin_kernighan.rs:41 rebuilds its own
     # matrix), but the NN seed (:47-55) and the reported total (:99) go through problem.distances
     packed = problem.explicit_packed()
-    ctx.check(ctx.lib.tl_lk(ctx.handle, problem.xy.ctypes.data_as(C.c_void_p), n,
-                            None if packed is None else packed.ctypes.data_as(C.c_void_p),
-                            None if init_pos is None else init_pos.ctypes.data_as(C.c_void_p), C.byref(o), int(seed),
-                            out.ctypes.data_as(C.c_void_p), C.byref(cost), C.byref(st)))
-    route = problem.ids[out]
-    if progress_tx is not None:
-        progress_tx("PathUpdate", ([int(v) for v in route], float(cost.value)))
-    return Solution(cost.value, route, problem, st.as_dict())
+    args = (ctx.handle, problem.xy.ctypes.data_as(C.c_void_p), n,
+            None if packed is None else packed.ctypes.data_as(C.c_void_p),
+            None if init_pos is None else init_pos.ctypes.data_as(C.c_void_p), C.byref(o), int(seed),
+            out.ctypes.data_as(C.c_void_p), C.byref(cost), C.byref(st))
+    if progress_tx is None or n < 4:
+        ctx.check(ctx.lib.tl_lk(*args))
+    else:
+        cap = min(int(opts.heuristic.epochs) + 1, 64)  # at most one per epoch + the first pass; rarely more than a few
+        while True:
+            snaps = np.empty((cap, n), dtype=np.uint32)
+            dists = np.empty(cap, dtype=np.float32)
+            ln = C.c_uint32()
+            ctx.check(ctx.lib.tl_lk_trace(*args, snaps.ctypes.data_as(C.c_void_p), dists.ctypes.data_as(C.c_void_p), cap, C.byref(ln)))
+            if ln.value <= cap:
+                break
+            cap = int(ln.value)  # the search is deterministic for a seed: once more with room for every snapshot
+        for m in range(ln.value):
+            progress_tx("PathUpdate", ([int(v) for v in problem.ids[snaps[m]]], float(dists[m])))
+    return Solution(cost.value, problem.ids[out], problem, st.as_dict())
 
 
 def build_candidates(problem, k, *, ctx=None):

@@ -14,8 +14,9 @@ def solve(problem, opts=None, progress_tx=None, init_tour=None, *, ctx=None, mod
     per improving move and Done (two_opt.rs:22-24,30-32,53-56,63-65).  The descent is one kernel launch, so nothing can be sent
     while it runs; with a channel the descent goes through tl_two_opt_trace, which also returns the applied moves in the
     reference's order, and the SAME message sequence — every path, every new_distance — is replayed from it afterwards.
-    Where no move list is available (matrix problems, n beyond the LDS-resident descent, BEST_SWEEP) the messages are the
-    initial PathUpdate, one final PathUpdate and Done.
+    Matrix problems (EXPLICIT / GEO) go through the same entry with problem.distances.  Where no move list is available
+    (coordinates with n beyond the LDS-resident descent, BEST_SWEEP) the messages are the initial PathUpdate, one final
+    PathUpdate and Done.
     """
     from . import Solution, default_context
     ctx = ctx or default_context()
@@ -28,14 +29,15 @@ def solve(problem, opts=None, progress_tx=None, init_tour=None, *, ctx=None, mod
     start_pos = np.arange(n, dtype=np.uint32) if init_pos is None else np.asarray(init_pos, dtype=np.uint32)
     if progress_tx is not None:
         progress_tx("PathUpdate", ([int(v) for v in problem.ids[start_pos]], 0.0))
-    traced = (progress_tx is not None and packed is None and mode == _capi.TL_MODE_REF_ORDER and
-              3 <= n <= min(ctx.two_opt_lds_max_n(), 65535))
+    traced = (progress_tx is not None and mode == _capi.TL_MODE_REF_ORDER and
+              3 <= n <= (65535 if packed is not None else min(ctx.two_opt_lds_max_n(), 65535)))
     if traced:
         cap = max(64, 16 * n)
         while True:
             log = np.empty(cap, dtype=np.uint32)
             ln = C.c_uint32()
             ctx.check(ctx.lib.tl_two_opt_trace(ctx.handle, problem.xy.ctypes.data_as(C.c_void_p), n,
+                                               None if packed is None else packed.ctypes.data_as(C.c_void_p),
                                                None if init_pos is None else init_pos.ctypes.data_as(C.c_void_p),
                                                out.ctypes.data_as(C.c_void_p), C.byref(cost), C.byref(st),
                                                log.ctypes.data_as(C.c_void_p), cap, C.byref(ln)))

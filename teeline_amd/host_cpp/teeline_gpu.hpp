@@ -206,9 +206,11 @@ inline Solution solve(Context &ctx, const TspProblem &problem, const HeuristicOp
     tl_stats st{};
     // With a progress callback the descent also lists its moves (tl_two_opt_trace) and the reference's exact message sequence —
     // CityChange(path[i]) per outer i of every sweep, PathUpdate(path, new_distance) per move (two_opt.rs:30-32,53-56) — is
-    // replayed from them once the kernel is back.  Coordinates only; otherwise the final PathUpdate (detail::finish).
-    if (progress_tx && *progress_tx && !problem.explicit_packed() && mode == TL_MODE_REF_ORDER && n >= 3 && n <= 65535u &&
-        n <= tl_two_opt_lds_max_n(ctx.get())) {
+    // replayed from them once the kernel is back (coordinates within the LDS-resident descent, or problem.distances of a GEO /
+    // EXPLICIT problem); otherwise the final PathUpdate (detail::finish).
+    const float *packed = problem.explicit_packed();
+    if (progress_tx && *progress_tx && mode == TL_MODE_REF_ORDER && n >= 3 && n <= 65535u &&
+        (packed || n <= tl_two_opt_lds_max_n(ctx.get()))) {
         std::vector<size_t> route;
         std::vector<uint32_t> pos(n);
         for (uint32_t q = 0; q < n; ++q) pos[q] = init_tour ? init[q] : q;
@@ -218,11 +220,12 @@ inline Solution solve(Context &ctx, const TspProblem &problem, const HeuristicOp
         std::vector<uint32_t> log;
         for (;;) {
             log.assign(cap, 0u);
-            ctx.check(tl_two_opt_trace(ctx.get(), xy.data(), n, init_tour ? init.data() : nullptr, out.data(), &cost, &st, log.data(), cap, &len));
+            ctx.check(tl_two_opt_trace(ctx.get(), xy.data(), n, packed, init_tour ? init.data() : nullptr, out.data(), &cost, &st, log.data(), cap, &len));
             if (len <= cap) break;
             cap = len;  // the descent is deterministic: once more with room for every move
         }
-        auto d = [&](uint32_t p, uint32_t q) -> float {  // KDPoint::distance (kdtree.rs:291-295): separate roundings, correctly rounded sqrt
+        auto d = [&](uint32_t p, uint32_t q) -> float {  // problem.distances, or KDPoint::distance (kdtree.rs:291-295): separate roundings, correctly rounded sqrt
+            if (packed) return problem.distances.distance_by_pos(p, q);
             const volatile float dx = xy[2 * p] - xy[2 * q], dy = xy[2 * p + 1] - xy[2 * q + 1];
             const volatile float sx = dx * dx, sy = dy * dy;
             const volatile float ss = sx + sy;
@@ -278,6 +281,26 @@ inline std::vector<Solution> solve_population(Context &ctx, const TspProblem &pr
 }  // namespace two_opt
 
 namespace three_opt {  // three_opt.rs:16-51
+// three_opt.rs:186-218 apply_3opt: cases 1-3 reverse segments in place, 4-7 swap path[i+1..=j] and path[j+1..=k] with either reversed
+inline void apply_3opt(std::vector<uint32_t> &path, uint32_t i, uint32_t j, uint32_t k, uint32_t kase)
+{
+    auto b1 = path.begin() + i + 1, e1 = path.begin() + j + 1, e2 = path.begin() + k + 1;
+    switch (kase) {
+    case 1: std::reverse(b1, e1); break;
+    case 2: std::reverse(e1, e2); break;
+    case 3: std::reverse(b1, e1); std::reverse(e1, e2); break;
+    case 4: case 5: case 6: case 7: {
+        std::vector<uint32_t> s1(b1, e1), s2(e1, e2);
+        if (kase == 5 || kase == 7) std::reverse(s1.begin(), s1.end());
+        if (kase == 6 || kase == 7) std::reverse(s2.begin(), s2.end());
+        std::copy(s2.begin(), s2.end(), b1);
+        std::copy(s1.begin(), s1.end(), b1 + (std::ptrdiff_t)s2.size());
+        break;
+    }
+    default: throw std::runtime_error("apply_3opt: case must be 1-7");
+    }
+}
+
 inline Solution solve(Context &ctx, const TspProblem &problem, const HeuristicOptions &, const ProgressFn *progress_tx,
                       const std::vector<size_t> *init_tour)
 {
@@ -287,8 +310,37 @@ inline Solution solve(Context &ctx, const TspProblem &problem, const HeuristicOp
     if (init_tour) init = problem.positions_of(*init_tour);
     float cost = 0.f;
     tl_stats st{};
-    ctx.check(tl_three_opt(ctx.get(), xy.data(), n, problem.explicit_packed(), init_tour ? init.data() : nullptr, out.data(), &cost, &st));
-    return detail::finish(problem, out, cost, st, progress_tx);
+    if (!(progress_tx && *progress_tx) || n < 4) {  // (n < 4: the reference returns before its first message, three_opt.rs:25-28)
+        ctx.check(tl_three_opt(ctx.get(), xy.data(), n, problem.explicit_packed(), init_tour ? init.data() : nullptr, out.data(), &cost, &st));
+        return detail::finish(problem, out, cost, st, nullptr);
+    }
+    // With a progress callback the solve also lists its moves (tl_three_opt_trace) and the reference's message sequence — the
+    // start path, the path after every apply_3opt (each with 0.0), Done (three_opt.rs:34,42,47-49) — is replayed from them.
+    uint32_t cap = std::max<uint32_t>(64u, 4u * n), len = 0;
+    std::vector<uint32_t> log;
+    for (;;) {
+        log.assign((size_t)cap * 4, 0u);
+        ctx.check(tl_three_opt_trace(ctx.get(), xy.data(), n, problem.explicit_packed(), init_tour ? init.data() : nullptr, out.data(), &cost, &st,
+                                     log.data(), cap, &len));
+        if (len <= cap) break;
+        cap = len;  // deterministic: once more with room for every move
+    }
+    std::vector<uint32_t> pos(n);
+    for (uint32_t q = 0; q < n; ++q) pos[q] = init_tour ? init[q] : q;
+    std::vector<size_t> route(n);
+    auto send = [&]() {
+        for (uint32_t q = 0; q < n; ++q) route[q] = problem.cities[pos[q]].id;
+        (*progress_tx)(ProgressKind::PathUpdate, route, 0.0f);
+    };
+    send();
+    for (uint32_t m = 0; m < len; ++m) {
+        const uint32_t i = log[4 * m], j = log[4 * m + 1], k = log[4 * m + 2], kase = log[4 * m + 3];
+        apply_3opt(pos, i, j, k, kase);
+        send();
+    }
+    Solution s = detail::finish(problem, out, cost, st, nullptr);
+    (*progress_tx)(ProgressKind::Done, s.route_, cost);
+    return s;
 }
 }  // namespace three_opt
 
@@ -336,8 +388,29 @@ inline Solution solve(Context &ctx, const TspProblem &problem, const LKOptions &
     float cost = 0.f;
     tl_stats st{};
     // problem.distances (GEO / EXPLICIT) feeds the NN seed and the reported total only; the search is Euclidean (lin_kernighan.rs:41,47-55,99)
-    ctx.check(tl_lk(ctx.get(), xy.data(), n, problem.explicit_packed(), init_tour ? init.data() : nullptr, &o, seed, out.data(), &cost, &st));
-    return detail::finish(problem, out, cost, st, progress_tx);
+    if (!(progress_tx && *progress_tx) || n < 4) {  // (n < 4: the reference returns before its first message, lin_kernighan.rs:57-59)
+        ctx.check(tl_lk(ctx.get(), xy.data(), n, problem.explicit_packed(), init_tour ? init.data() : nullptr, &o, seed, out.data(), &cost, &st));
+        return detail::finish(problem, out, cost, st, nullptr);
+    }
+    // With a progress callback: the best tours the search settles on, in order (tl_lk_trace), sent as the reference sends them —
+    // PathUpdate(best_tour, best_dist) after the first lk_pass and per improving epoch, no Done (lin_kernighan.rs:71,90).
+    uint32_t cap = std::min<uint32_t>((uint32_t)opts.heuristic.epochs + 1u, 64u), len = 0;
+    std::vector<uint32_t> snaps;
+    std::vector<float> dists;
+    for (;;) {
+        snaps.assign((size_t)cap * n, 0u);
+        dists.assign(cap, 0.f);
+        ctx.check(tl_lk_trace(ctx.get(), xy.data(), n, problem.explicit_packed(), init_tour ? init.data() : nullptr, &o, seed, out.data(), &cost, &st,
+                              snaps.data(), dists.data(), cap, &len));
+        if (len <= cap) break;
+        cap = len;  // deterministic for a seed: once more with room for every snapshot
+    }
+    std::vector<size_t> route(n);
+    for (uint32_t m = 0; m < len; ++m) {
+        for (uint32_t q = 0; q < n; ++q) route[q] = problem.cities[snaps[(size_t)m * n + q]].id;
+        (*progress_tx)(ProgressKind::PathUpdate, route, dists[m]);
+    }
+    return detail::finish(problem, out, cost, st, nullptr);
 }
 }  // namespace lin_kernighan
 

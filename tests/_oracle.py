@@ -274,6 +274,24 @@ def lin_kernighan(xy, init=None, epochs=100, platoo_epochs=10, n_nearest=5, max_
     return rc, out, np.float32(cost.value), st.as_dict()
 
 
+def lin_kernighan_trace(xy, init=None, epochs=100, platoo_epochs=10, n_nearest=5, max_depth=5, seed=1, packed=None, cap=256):
+    """lin_kernighan (kd-tree candidate lists) + the reference's progress messages (lin_kernighan.rs:71,90): list of (tour positions, best_dist)."""
+    xy = _xy(xy)
+    n = xy.shape[0]
+    init = _perm(init, n)
+    out = np.empty(n, dtype=np.uint32)
+    cost = C.c_float()
+    st = Stats()
+    snaps = np.zeros((cap, n), dtype=np.uint32)
+    dists = np.zeros(cap, dtype=np.float32)
+    cnt = C.c_uint32()
+    rc = lib().tlo_lin_kernighan_trace(_p(xy), _p(packed), C.c_uint32(n), _p(init), C.c_uint32(epochs), C.c_uint32(platoo_epochs),
+                                       C.c_uint32(n_nearest), C.c_uint32(max_depth), C.c_uint64(seed), _p(out), C.byref(cost), C.byref(st),
+                                       _p(snaps), _p(dists), C.c_uint32(cap), C.byref(cnt))
+    assert cnt.value <= cap
+    return rc, out, np.float32(cost.value), st.as_dict(), [(snaps[m].copy(), np.float32(dists[m])) for m in range(cnt.value)]
+
+
 def build_candidates_kdtree(xy, k):
     """(lists, tie_free): lin_kernighan.rs:12-27 through the restated kd-tree."""
     xy = _xy(xy)

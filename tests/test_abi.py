@@ -54,7 +54,7 @@ def test_flags_modes_and_error_codes_agree_with_the_binding():
 def test_library_exports_every_declared_symbol(lib):
     for name in header_symbols():
         assert hasattr(lib, name), f"libteeline_gpu.so does not export {name}"
-    assert lib.tl_abi_version() == 3
+    assert lib.tl_abi_version() == 4
     assert b"gfx950" in lib.tl_version()
 
 
@@ -175,3 +175,11 @@ def test_reference_patch_applies_cleanly():
     gpu_rs = open(os.path.join(ROOT, "integration", "teeline-gpu", "gpu.rs")).read()
     for sig in ("progress_tx: Option<&mpsc::Sender<ProgressMessage>>", "init_tour: Option<&[usize]>", ") -> Solution {"):
         assert gpu_rs.count(sig) >= 4
+
+
+def test_reference_patch_carries_the_current_gpu_rs():
+    """The new-file hunk `src/tsp/gpu.rs` of the reference patch is integration/teeline-gpu/gpu.rs, line for line
+    (scripts/refresh_patch.py rebuilds it)."""
+    import subprocess
+    import sys
+    assert subprocess.call([sys.executable, os.path.join(ROOT, "scripts", "refresh_patch.py"), "--check"]) == 0

@@ -277,3 +277,52 @@ def test_lk_forms_at_the_chip_step_size():
         for k, depth, epochs in ((1, 5, 3), (2, 3, 3), (3, 6, 4), (5, 4, 4), (5, 2, 3), (5, 1, 2), (9, 3, 2), (10, 3, 2)):
             assert_same(gpu_lk(ctx, xy, seed=7, epochs=epochs, max_depth=depth, n_nearest=k),
                         O.lin_kernighan(xy, seed=7, epochs=epochs, max_depth=depth, n_nearest=k))
+
+
+def test_progress_channel_carries_the_reference_messages(ctx, tsplib_dir):
+    # lin_kernighan.rs:71,90: PathUpdate(best_tour, best_dist) after the first lk_pass and after every epoch that improves on it, no
+    # Done.  With a progress callback lin_kernighan::solve goes through tl_lk_trace: the device-side state machine lists exactly
+    # those tours and distances (oracle: tlo_lin_kernighan_trace, the same loop with the messages recorded).
+    import ctypes as C
+    import teeline_amd as TA
+    from teeline_amd import _capi
+    b = T.parse_tsplib(os.path.join(tsplib_dir, "berlin52.tsp"))
+    cases = [(b["xy"], b["ids"], None, dict(epochs=60, seed=1)), (b["xy"], b["ids"], None, dict(epochs=60, seed=7)),
+             (O.synth_xy(400, seed=9), np.arange(400), O.restart_perm(400, 5, 0), dict(epochs=12, seed=3)),
+             (O.synth_xy(2000, seed=4), np.arange(2000), None, dict(epochs=6, seed=2)),   # chip-wide step (n >= 1500)
+             (lattice(8, 3), np.arange(64), None, dict(epochs=20, seed=5, n_nearest=6, max_depth=4))]
+    for xy, ids, init, kw in cases:
+        n = len(ids)
+        rc, oroute, ocost, ost, osnaps = O.lin_kernighan_trace(xy, init=init, epochs=kw["epochs"], platoo_epochs=10, n_nearest=kw.get("n_nearest", 5),
+                                                               max_depth=kw.get("max_depth", 5), seed=kw["seed"])
+        assert rc == 0 and len(osnaps) >= 1
+        got = []
+        h = TA.HeuristicOptions(epochs=kw["epochs"], platoo_epochs=10, n_nearest=kw.get("n_nearest", 5))
+        sol = TA.lin_kernighan.solve(TA.TspProblem(ids, xy), TA.LKOptions(h, kw.get("max_depth", 5)), lambda kind, payload: got.append((kind, payload)),
+                                     None if init is None else [int(ids[v]) for v in init], ctx=ctx, seed=kw["seed"])
+        assert [k for k, _ in got] == ["PathUpdate"] * len(osnaps)
+        for (kind, (route, dist)), (spos, sdist) in zip(got, osnaps):
+            assert route == [int(ids[v]) for v in spos] and np.float32(dist).tobytes() == np.float32(sdist).tobytes()
+        assert list(sol.route()) == [int(ids[v]) for v in oroute] and np.float32(sol.total).tobytes() == np.float32(ocost).tobytes()
+        assert got[-1][1][0] == list(sol.route())  # the last message carries the returned tour
+    # a short buffer holds the first snapshots and reports the full count
+    xy, ids = b["xy"], b["ids"]
+    n = len(ids)
+    rc, oroute, ocost, ost, osnaps = O.lin_kernighan_trace(xy, epochs=60, seed=7)
+    if len(osnaps) > 1:
+        out = np.empty(n, dtype=np.uint32)
+        snaps = np.full((1, n), 0xFFFFFFFF, dtype=np.uint32)
+        dists = np.zeros(1, dtype=np.float32)
+        c, st, ln = C.c_float(), _capi.TlStats(), C.c_uint32()
+        o = _capi.TlLkOpts(60, 10, 5, 5)
+        ctx.check(ctx.lib.tl_lk_trace(ctx.handle, xy.ctypes.data_as(C.c_void_p), n, None, None, C.byref(o), 7, out.ctypes.data_as(C.c_void_p), C.byref(c),
+                                      C.byref(st), snaps.ctypes.data_as(C.c_void_p), dists.ctypes.data_as(C.c_void_p), 1, C.byref(ln)))
+        assert ln.value == len(osnaps) and snaps[0].tolist() == osnaps[0][0].tolist() and out.tolist() == oroute.tolist()
+
+
+def test_no_progress_messages_below_four_cities(ctx):
+    # lin_kernighan.rs:57-59 returns before its first send_progress
+    import teeline_amd as TA
+    got = []
+    sol = TA.lin_kernighan.solve(prob(O.synth_xy(3, seed=2)), TA.LKOptions(TA.HeuristicOptions(epochs=5), 5), lambda k, p: got.append((k, p)), None, ctx=ctx)
+    assert got == [] and len(sol.route()) == 3

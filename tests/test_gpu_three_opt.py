@@ -160,3 +160,71 @@ def test_synthetic_300_full_descent_from_a_random_permutation(ctx, goldens3):
     assert rp[:8].tolist() == goldens3["synth300_perm_seed4_three_opt"]["perm_head"]
     _check_descent(gpu_three_opt(ctx, xy, None, n, rp), goldens3["synth300_perm_seed4_three_opt"])
     _check_descent(gpu_three_opt(ctx, None, O.dm_build_packed(xy), n, rp), goldens3["synth300_perm_seed4_three_opt_matrix"])
+
+
+def _three_opt_messages(xy, packed, ids, init):
+    # three_opt.rs:30-49 restated as its message stream, with the oracle's find_best_move / apply_3opt
+    n = len(ids)
+    path = np.arange(n, dtype=np.uint32) if init is None else np.asarray(init, dtype=np.uint32).copy()
+    msgs = [("PathUpdate", ([int(ids[v]) for v in path], 0.0))]
+    moves = []
+    while True:
+        mv = O.three_opt_find_best_move(xy, packed, path)
+        if mv is None:
+            break
+        i, j, k, case, _ = mv
+        rc, path = O.apply_3opt(path, i, j, k, case)
+        moves.append((i, j, k, case))
+        msgs.append(("PathUpdate", ([int(ids[v]) for v in path], 0.0)))
+    msgs.append(("Done", None))
+    return msgs, moves, path
+
+
+def test_progress_channel_replays_the_reference_messages(ctx, tsplib_dir):
+    # three_opt.rs:34,42,47-49: PathUpdate(path, 0.0) for the start path and after every apply_3opt, then Done.  With a progress
+    # callback three_opt::solve goes through tl_three_opt_trace (moves i, j, k, case in order) and replays exactly that.
+    import ctypes as C
+    import teeline_amd as TA
+    from teeline_amd import _capi
+    cases = []
+    d = T.parse_tsplib(os.path.join(tsplib_dir, "berlin52.tsp"))
+    cases.append((d["xy"], None, d["ids"], None))
+    cases.append((d["xy"], None, d["ids"], O.restart_perm(d["n"], 11, 0)))
+    g = T.parse_tsplib(os.path.join(tsplib_dir, "gr17.tsp"))
+    cases.append((g["xy"], g["packed"], g["ids"], None))
+    xs = O.synth_xy(90, seed=5)
+    cases.append((xs, None, np.arange(90), O.restart_perm(90, 3, 1)))
+    for xy, packed, ids, init in cases:
+        n = len(ids)
+        want, moves, path = _three_opt_messages(xy, packed, ids, init)
+        got = []
+        dmx = None if packed is None else TA.distance_matrix.DistanceMatrix(n, np.ascontiguousarray(packed, dtype=np.float32), ids, "explicit")
+        prob = TA.TspProblem(ids, xy, dmx)
+        sol = TA.three_opt.solve(prob, None, lambda kind, payload: got.append((kind, payload)),
+                                 None if init is None else [int(ids[v]) for v in init], ctx=ctx)
+        assert got == want
+        assert list(sol.route()) == [int(ids[v]) for v in path] and sol.stats["moves"] == len(moves)
+        # the raw list, and a short buffer: the prefix + the full count
+        out = np.empty(n, dtype=np.uint32)
+        c, st, ln = C.c_float(), _capi.TlStats(), C.c_uint32()
+        cap = max(len(moves) // 2, 1)
+        log = np.full((cap, 4), 0x12345678, dtype=np.uint32)
+        xyc = np.ascontiguousarray(xy, dtype=np.float32)
+        pk = None if packed is None else np.ascontiguousarray(packed, dtype=np.float32)
+        ip = None if init is None else np.ascontiguousarray(init, dtype=np.uint32)
+        ctx.check(ctx.lib.tl_three_opt_trace(ctx.handle, xyc.ctypes.data_as(C.c_void_p), n, None if pk is None else pk.ctypes.data_as(C.c_void_p),
+                                             None if ip is None else ip.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.byref(c), C.byref(st),
+                                             log.ctypes.data_as(C.c_void_p), cap, C.byref(ln)))
+        assert ln.value == len(moves) == st.moves
+        m = min(cap, len(moves))
+        assert log[:m].tolist() == [list(v) for v in moves[:m]]
+        assert (log[m:] == 0x12345678).all() and out.tolist() == path.tolist()
+
+
+def test_no_messages_below_four_cities(ctx):
+    # three_opt.rs:25-28 returns before its first message
+    import teeline_amd as TA
+    xy = O.synth_xy(3, seed=2)
+    got = []
+    sol = TA.three_opt.solve(TA.TspProblem(np.arange(3), xy), None, lambda k, p: got.append((k, p)), None, ctx=ctx)
+    assert got == [] and list(sol.route()) == [0, 1, 2]

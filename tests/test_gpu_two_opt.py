@@ -529,10 +529,54 @@ def test_move_list_matches_the_oracle(ctx):
         c, stt, ln = C.c_float(), _capi.TlStats(), C.c_uint32()
         for cap in (len(want) + 7, max(len(want) // 3, 1)):
             log = np.full(cap, 0x12345678, dtype=np.uint32)
-            ctx.check(ctx.lib.tl_two_opt_trace(ctx.handle, xy.ctypes.data_as(C.c_void_p), n, init.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+            ctx.check(ctx.lib.tl_two_opt_trace(ctx.handle, xy.ctypes.data_as(C.c_void_p), n, None, init.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
                                                C.byref(c), C.byref(stt), log.ctypes.data_as(C.c_void_p), cap, C.byref(ln)))
             assert ln.value == len(want) == stt.moves + stt.sweeps - 1 and out.tolist() == route.tolist()
             m = min(cap, len(want))
             assert log[:m].tolist() == want[:m].tolist()
             assert (log[m:] == 0x12345678).all()
         assert np.float32(c.value).tobytes() == np.float32(cost).tobytes()
+
+
+def test_move_list_and_progress_of_the_matrix_form(ctx, tsplib_dir):
+    # tl_two_opt_trace with dm_packed: the matrix-form kernel writes the same move list (EXPLICIT / GEO problems and a synthetic matrix
+    # at pr1002's size), and two_opt::solve replays the reference's messages with new_distance read from problem.distances
+    import ctypes as C
+    import teeline_amd as TA
+    from teeline_amd import _capi
+    cases = []
+    for name in ("gr17.tsp", "bays29.tsp", "burma14.tsp"):
+        d = T.parse_tsplib(os.path.join(tsplib_dir, name))
+        packed = d["packed"] if d["packed"] is not None else O.dm_build_packed(d["xy"], geo=True)  # burma14: GEO
+        cases.append((name, d["xy"], d["n"], packed, d["ids"]))
+    n = 1002
+    xy = O.synth_xy(n)
+    cases.append(("synthetic1002", xy, n, O.dm_build_packed(xy), np.arange(n)))
+    for name, xy, n, packed, ids in cases:
+        packed = np.ascontiguousarray(packed, dtype=np.float32)
+        for init in (None, O.restart_perm(n, 7, 0)):
+            rc, route, cost, st, ij, dist, sw = O.two_opt_trace(xy, packed, n, init=init)
+            words, last = O.trace_words(ij, sw)
+            words += [0xFFFFFFFF] * (st["sweeps"] - last)
+            want = np.asarray(words, dtype=np.uint32)
+            out = np.empty(n, dtype=np.uint32)
+            c, stt, ln = C.c_float(), _capi.TlStats(), C.c_uint32()
+            cap = len(want) + 5
+            log = np.full(cap, 0x12345678, dtype=np.uint32)
+            xyc = np.ascontiguousarray(xy, dtype=np.float32)
+            ctx.check(ctx.lib.tl_two_opt_trace(ctx.handle, xyc.ctypes.data_as(C.c_void_p), n, packed.ctypes.data_as(C.c_void_p),
+                                               None if init is None else init.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                               C.byref(c), C.byref(stt), log.ctypes.data_as(C.c_void_p), cap, C.byref(ln)))
+            assert ln.value == len(want) == stt.moves + stt.sweeps - 1, name
+            assert out.tolist() == route.tolist() and log[:len(want)].tolist() == want.tolist(), name
+            assert np.float32(c.value).tobytes() == np.float32(cost).tobytes()
+            if n <= 64:  # the replayed message stream: every PathUpdate's new_distance is the oracle's record of the compared sum
+                got = []
+                prob = TA.TspProblem(ids, xyc, TA.distance_matrix.DistanceMatrix(n, packed, ids, "explicit"))
+                sol = TA.two_opt.solve(prob, None, lambda kind, payload: got.append((kind, payload)),
+                                       None if init is None else [int(ids[v]) for v in init], ctx=ctx)
+                upd = [m for m in got if m[0] == "PathUpdate"]
+                assert got[0][0] == "PathUpdate" and got[-1] == ("Done", None) and len(upd) == 1 + len(ij)
+                assert [np.float32(m[1][1]).tobytes() for m in upd[1:]] == [np.float32(v).tobytes() for v in dist]
+                assert upd[-1][1][0] == [int(ids[v]) for v in route] if len(ij) else True
+                assert sum(1 for m in got if m[0] == "CityChange") == st["sweeps"] * (n - 3)
