@@ -202,6 +202,8 @@ int tl_or_opt_find_best_move(tl_ctx *ctx, const float *xy, uint32_t n, const flo
  * only teeline-qt passes one).  A descent here is one kernel launch (or a device-side state machine), so nothing can be sent
  * while it runs; the *_trace entries return, beside the plain entry's results, the record from which the caller replays the
  * reference's exact message sequence after the fact (teeline_amd/host/*.py, teeline_gpu.hpp, integration/teeline-gpu/gpu.rs do).
+ * (nearest_neighbor::solve needs no such entry: its messages — the growing path prefix and the current city per step,
+ * nearest_neighbor.rs:32-34,40-42,67-69,72-74 — follow from the finished tour.)
  *
  * tl_two_opt_trace — two_opt.rs:22-24,30-32,53-56,63-65 sends PathUpdate(start), CityChange(path[i]) per outer i of every sweep,
  * PathUpdate(path, new_distance) per improving move and Done.  move_log[m] = (i << 16) | j for swap_2opt(path, i+1, j) in the
@@ -220,6 +222,12 @@ int tl_two_opt_trace(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_p
 int tl_three_opt_trace(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
                        uint32_t *out_pos, float *out_cost, tl_stats *stats, uint32_t *move_log, uint32_t log_cap,
                        uint32_t *log_len);
+/* tl_or_opt_trace — or_opt.rs:40-42,62-67,70-72 sends PathUpdate(path, 0.0) for the start path, PathUpdate(path,
+ * distances.tour_length(path)) after every apply_relocation, then Done.  move_log holds 4 words per applied move, in order:
+ * i (segment start), j (insert after), seg_len, reversed (or_opt.rs:45-51, apply_relocation :172-184); *log_len = moves. */
+int tl_or_opt_trace(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
+                    uint32_t *out_pos, float *out_cost, tl_stats *stats, uint32_t *move_log, uint32_t log_cap,
+                    uint32_t *log_len);
 /* tl_lk_trace — lin_kernighan.rs:71,90 sends PathUpdate(best_tour, best_dist) after the first lk_pass and after every epoch that
  * improves on it (no Done).  snap_pos holds those tours (snap_cap x n positions, in order), snap_dist their best_dist (the
  * Euclidean tour_distance of :118-122, whatever problem.distances holds); *snap_len counts them all, the buffers hold the first

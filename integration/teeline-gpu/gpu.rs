@@ -12,10 +12,10 @@
 //! computed by `DistanceMatrix::tour_length` itself.
 //!
 //! Behaviour that differs from the CPU functions, all of it documented in INTEGRATION.md:
-//!   * progress: two_opt, three_opt and lin_kernighan send the reference's exact message sequence — CityChange per outer i and
-//!     PathUpdate per move (2-opt), PathUpdate per applied move (3-opt), PathUpdate per best tour (LK) — replayed from the records of
-//!     `tl_two_opt_trace` / `tl_three_opt_trace` / `tl_lk_trace` AFTER the kernels return, not while they run; or_opt and
-//!     nearest_neighbor send `PathUpdate` at the start, one `PathUpdate` with the final tour and `Done` — only the Qt front-end passes a sender;
+//!   * progress: every solver sends the reference's exact message sequence — CityChange per outer i and PathUpdate per move
+//!     (2-opt), PathUpdate per applied move (3-opt, or-opt), PathUpdate per best tour (LK), CityChange + growing path per step (NN) —
+//!     replayed from the records of `tl_two_opt_trace` / `tl_three_opt_trace` / `tl_or_opt_trace` / `tl_lk_trace` (NN: from the
+//!     finished walk) AFTER the kernels return, not while they run — only the Qt front-end passes a sender;
 //!   * a library error (no gfx950 device, HIP failure) panics with the library's message, like the `.expect(..)`s of the CPU
 //!     code do on bad input: the solver functions are infallible by signature;
 //!   * Lin-Kernighan kicks: the seed of the device-side splitmix64 stream is drawn from `rand::rng()` per call (the CPU
@@ -232,14 +232,42 @@ pub mod or_opt {
     ) -> Solution {
         let io = Boundary::new(problem);
         let init = init_tour.map(|t| io.positions(t, "or_opt: invalid city pair"));
-        if let Some(tx) = progress_tx {
-            let _ = tx.send(ProgressMessage::PathUpdate(Route::new(&start_tour(problem, init_tour)), 0.0));
+        let n = problem.cities.len();
+        // With a progress channel the solve also lists its moves, and the reference's message sequence — the start path (0.0), the
+        // path and its tour_length after every apply_relocation, Done (or_opt.rs:40-42,62-67,70-72; nothing when n < 4, :31-34) —
+        // is replayed from them.
+        if let (Some(tx), true) = (progress_tx, n >= 4) {
+            let (t, moves) = unwrap_gpu("or_opt (gpu)", ffi::with_context(|ctx| {
+                let dm = io.matrix(ctx)?;
+                ctx.or_opt_trace(&io.xy, dm, init.as_deref())
+            }));
+            let mut pos: Vec<u32> = init.clone().unwrap_or_else(|| (0..n as u32).collect());
+            let _ = tx.send(ProgressMessage::PathUpdate(Route::new(&io.ids(&pos)), 0.0));
+            for m in &moves {
+                apply_relocation(&mut pos, m[0] as usize, m[2] as usize, m[1] as usize, m[3] != 0);
+                let route = io.ids(&pos);
+                let len = problem.distances.tour_length(&route);
+                let _ = tx.send(ProgressMessage::PathUpdate(Route::new(&route), len));
+            }
+            let _ = tx.send(ProgressMessage::Done);
+            return finish(problem, &io, &t, None, false);
         }
         let t = unwrap_gpu("or_opt (gpu)", ffi::with_context(|ctx| {
             let dm = io.matrix(ctx)?;
             ctx.or_opt(&io.xy, dm, init.as_deref())
         }));
-        finish(problem, &io, &t, progress_tx, true)
+        finish(problem, &io, &t, None, false)
+    }
+
+    /// or_opt.rs:172-184 on positions.
+    fn apply_relocation(tour: &mut Vec<u32>, i: usize, seg_len: usize, j: usize, reversed: bool) {
+        let seg: Vec<u32> = tour.drain(i..i + seg_len).collect();
+        let insert_at = if j >= i + seg_len { j - seg_len + 1 } else { j + 1 };
+        if reversed {
+            tour.splice(insert_at..insert_at, seg.into_iter().rev());
+        } else {
+            tour.splice(insert_at..insert_at, seg);
+        }
     }
 }
 
@@ -257,7 +285,20 @@ pub mod nearest_neighbor {
             let dm = io.matrix(ctx)?;
             ctx.nearest_neighbor(&io.xy, dm, opts.n_nearest as u32)
         }));
-        finish(problem, &io, &t, progress_tx, true)
+        // the reference's messages follow from the finished walk (nearest_neighbor.rs:32-34,40-42,67-69,72-74): the start city,
+        // then per step CityChange(current city) and the path so far, then Done
+        if let Some(tx) = progress_tx {
+            let route = io.ids(&t.pos);
+            if !route.is_empty() {
+                let _ = tx.send(ProgressMessage::PathUpdate(Route::new(&route[..1]), 0.0));
+                for k in 1..route.len() {
+                    let _ = tx.send(ProgressMessage::CityChange(route[k - 1]));
+                    let _ = tx.send(ProgressMessage::PathUpdate(Route::new(&route[..=k]), 0.0));
+                }
+                let _ = tx.send(ProgressMessage::Done);
+            }
+        }
+        finish(problem, &io, &t, None, false)
     }
 }
 

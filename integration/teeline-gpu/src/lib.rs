@@ -69,6 +69,8 @@ unsafe extern "C" {
                         out_cost: *mut f32, stats: *mut Stats, move_log: *mut u32, log_cap: u32, log_len: *mut u32) -> c_int;
     fn tl_three_opt_trace(ctx: *mut TlCtx, xy: *const f32, n: u32, dm_packed: *const f32, init_pos: *const u32, out_pos: *mut u32,
                           out_cost: *mut f32, stats: *mut Stats, move_log: *mut u32, log_cap: u32, log_len: *mut u32) -> c_int;
+    fn tl_or_opt_trace(ctx: *mut TlCtx, xy: *const f32, n: u32, dm_packed: *const f32, init_pos: *const u32, out_pos: *mut u32,
+                       out_cost: *mut f32, stats: *mut Stats, move_log: *mut u32, log_cap: u32, log_len: *mut u32) -> c_int;
     fn tl_lk_trace(ctx: *mut TlCtx, xy: *const f32, n: u32, dm_packed: *const f32, init_pos: *const u32, opts: *const LkOpts, seed: u64,
                    out_pos: *mut u32, out_cost: *mut f32, stats: *mut Stats, snap_pos: *mut u32, snap_dist: *mut f32, snap_cap: u32,
                    snap_len: *mut u32) -> c_int;
@@ -268,6 +270,29 @@ impl Context {
             let rc = unsafe {
                 tl_three_opt_trace(self.raw, xy.as_ptr(), n, opt_ptr(dm_packed), opt_ptr(init_pos), t.pos.as_mut_ptr(), &mut t.cost, &mut t.stats,
                                    log.as_mut_ptr(), cap, &mut len)
+            };
+            self.check(rc)?;
+            if len <= cap {
+                return Ok((t, log.chunks_exact(4).take(len as usize).map(|m| [m[0], m[1], m[2], m[3]]).collect()));
+            }
+            cap = len;
+        }
+    }
+
+    /// `or_opt::solve` together with the moves it applied, `(i, j, seg_len, reversed)` in order (or_opt.rs:45-51): what
+    /// `gpu::or_opt::solve` replays the reference's per-move `PathUpdate`s from.
+    pub fn or_opt_trace(&self, xy: &[f32], dm_packed: Option<&[f32]>, init_pos: Option<&[u32]>) -> Result<(Tour, Vec<[u32; 4]>), Error> {
+        let n = Self::n_of(xy);
+        Self::check_inputs(n, dm_packed, init_pos);
+        let mut t = Tour { pos: vec![0u32; n as usize], cost: 0.0, stats: Stats::default() };
+        let mut cap = (4 * n).max(64);
+        loop {
+            let mut log = vec![0u32; 4 * cap as usize];
+            let mut len = 0u32;
+            // SAFETY: as in two_opt_trace; the log holds 4 words per move.
+            let rc = unsafe {
+                tl_or_opt_trace(self.raw, xy.as_ptr(), n, opt_ptr(dm_packed), opt_ptr(init_pos), t.pos.as_mut_ptr(), &mut t.cost, &mut t.stats,
+                                log.as_mut_ptr(), cap, &mut len)
             };
             self.check(rc)?;
             if len <= cap {

@@ -37,7 +37,7 @@ SYMBOLS = [
     "tl_three_opt_find_best_move", "tl_lk", "tl_two_opt_multistart", "tl_pack_cost_key",
     "tl_two_opt_batch_dev", "tl_last_kernel_ms", "tl_dm_build_dev", "tl_build_candidates", "tl_nearest_neighbor",
     "tl_or_opt", "tl_or_opt_find_best_move", "tl_selftest_sqrt", "tl_two_opt_population", "tl_dm_is_euc2d",
-    "tl_two_opt_multistart_devices", "tl_two_opt_trace", "tl_three_opt_trace", "tl_lk_trace",
+    "tl_two_opt_multistart_devices", "tl_two_opt_trace", "tl_three_opt_trace", "tl_lk_trace", "tl_or_opt_trace",
 ]
 
 
@@ -103,6 +103,7 @@ def load():
     L.tl_two_opt_population.argtypes = [vp, vp, u32, vp, vp, u32, vp, vp, C.POINTER(TlStats)]
     L.tl_two_opt_trace.argtypes = [vp, vp, u32, vp, vp, vp, f32p, C.POINTER(TlStats), vp, u32, C.POINTER(u32)]
     L.tl_three_opt_trace.argtypes = [vp, vp, u32, vp, vp, vp, f32p, C.POINTER(TlStats), vp, u32, C.POINTER(u32)]
+    L.tl_or_opt_trace.argtypes = [vp, vp, u32, vp, vp, vp, f32p, C.POINTER(TlStats), vp, u32, C.POINTER(u32)]
     L.tl_lk_trace.argtypes = [vp, vp, u32, vp, vp, C.POINTER(TlLkOpts), u64, vp, f32p, C.POINTER(TlStats), vp, vp, u32, C.POINTER(u32)]
     L.tl_pack_cost_key.argtypes = [C.c_float, u32]
     L.tl_pack_cost_key.restype = u64

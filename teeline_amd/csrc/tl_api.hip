@@ -1077,9 +1077,11 @@ extern "C" int tl_or_opt_find_best_move(tl_ctx *c, const float *xy, uint32_t n, 
     return TL_OK;
 }
 
-extern "C" int tl_or_opt(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
-                         uint32_t *out_pos, float *out_cost, tl_stats *stats)
+// move_log (optional): 4 words per applied move — i, j, seg_len, reversed of or_opt.rs:45-51 in order — at most log_cap moves; *log_len = moves
+static int or_opt_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
+                      uint32_t *out_pos, float *out_cost, tl_stats *stats, uint32_t *move_log, uint32_t log_cap, uint32_t *log_len)
 {
+    if (log_len) *log_len = 0;
     if (!c || (!xy && !dm_packed) || !out_pos) return fail(c, TL_ERR_BADARG, "tl_or_opt: NULL argument");
     const auto t0 = std::chrono::steady_clock::now();
     if (stats) memset(stats, 0, sizeof(*stats));
@@ -1110,6 +1112,13 @@ extern "C" int tl_or_opt(tl_ctx *c, const float *xy, uint32_t n, const float *dm
         HIPCHK(c, hipStreamSynchronize(c->stream));
         ++passes;
         if (!b.found) break;
+        if (move_log && moves < log_cap) {
+            uint32_t *w = move_log + 4 * moves;
+            w[0] = b.i;
+            w[1] = b.j;
+            w[2] = b.seg_len;
+            w[3] = b.reversed;
+        }
         ++moves;
         if (passes > cap) return fail(c, TL_ERR_NO_CONVERGE, "or_opt: pass cap reached");
     }
@@ -1138,7 +1147,23 @@ extern "C" int tl_or_opt(tl_ctx *c, const float *xy, uint32_t n, const float *dm
         stats->kernel_ms = kms;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
+    if (log_len) *log_len = (uint32_t)moves;
     return TL_OK;
+}
+
+extern "C" int tl_or_opt(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
+                         uint32_t *out_pos, float *out_cost, tl_stats *stats)
+{
+    return or_opt_run(c, xy, n, dm_packed, init_pos, out_pos, out_cost, stats, nullptr, 0, nullptr);
+}
+
+// or_opt::solve with its moves listed: the reference sends the path and its tour_length after every apply_relocation
+// (or_opt.rs:40-42,62-67,70-72); the host loop here already reads every move back.
+extern "C" int tl_or_opt_trace(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
+                               uint32_t *out_pos, float *out_cost, tl_stats *stats, uint32_t *move_log, uint32_t log_cap, uint32_t *log_len)
+{
+    if (!move_log || !log_len) return fail(c, TL_ERR_BADARG, "tl_or_opt_trace: NULL argument");
+    return or_opt_run(c, xy, n, dm_packed, init_pos, out_pos, out_cost, stats, move_log, log_cap, log_len);
 }
 
 static bool max_depth_ge2_split(uint32_t) { return true; }

@@ -5,7 +5,8 @@ import numpy as np
 
 
 def solve(problem, opts=None, progress_tx=None, init_tour=None, *, ctx=None):
-    """init_tour is ignored like the reference's `_init_tour` (nearest_neighbor.rs:12)."""
+    """init_tour is ignored like the reference's `_init_tour` (nearest_neighbor.rs:12).  progress_tx: optional
+    callable(kind, payload); the reference's messages are replayed from the finished walk (replay_progress)."""
     from . import HeuristicOptions, Solution, default_context
     from .. import _capi
     ctx = ctx or default_context()
@@ -18,4 +19,20 @@ def solve(problem, opts=None, progress_tx=None, init_tour=None, *, ctx=None):
     ctx.check(ctx.lib.tl_nearest_neighbor(ctx.handle, problem.xy.ctypes.data_as(C.c_void_p),
                                           None if packed is None else packed.ctypes.data_as(C.c_void_p), n, int(opts.n_nearest),
                                           out.ctypes.data_as(C.c_void_p), C.byref(cost)))
-    return Solution(cost.value, problem.ids[out], problem, {"kernel_ms": ctx.last_kernel_ms()})
+    route = problem.ids[out]
+    if progress_tx is not None:
+        replay_progress(route, progress_tx)
+    return Solution(cost.value, route, problem, {"kernel_ms": ctx.last_kernel_ms()})
+
+
+def replay_progress(route, progress_tx):
+    """The reference's message stream (nearest_neighbor.rs:32-34,40-42,67-69,72-74) — it follows from the finished walk:
+    PathUpdate([start], 0.0), then per step CityChange(current city) and PathUpdate(path so far, 0.0), then Done."""
+    path = [int(v) for v in route]
+    if not path:
+        return
+    progress_tx("PathUpdate", (path[:1], 0.0))
+    for t in range(1, len(path)):
+        progress_tx("CityChange", path[t - 1])
+        progress_tx("PathUpdate", (path[:t + 1], 0.0))
+    progress_tx("Done", None)

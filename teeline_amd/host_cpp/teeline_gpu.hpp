@@ -345,6 +345,35 @@ inline Solution solve(Context &ctx, const TspProblem &problem, const HeuristicOp
 }  // namespace three_opt
 
 namespace or_opt {  // or_opt.rs:18-74
+// or_opt.rs:172-184 apply_relocation: drain the segment, insert it after the old index j, forward or reversed
+inline void apply_relocation(std::vector<uint32_t> &tour, size_t i, size_t seg_len, size_t j, bool reversed)
+{
+    std::vector<uint32_t> seg(tour.begin() + i, tour.begin() + i + seg_len);
+    tour.erase(tour.begin() + i, tour.begin() + i + seg_len);
+    const size_t at = j >= i + seg_len ? j - seg_len + 1 : j + 1;
+    if (reversed) std::reverse(seg.begin(), seg.end());
+    tour.insert(tour.begin() + at, seg.begin(), seg.end());
+}
+
+// DistanceMatrix::tour_length (distance_matrix.rs:235-245) on positions, on the host, in the reference's f32 order: the closing
+// edge first, then every window — through problem.distances where the problem has a matrix, else KDPoint::distance
+inline float tour_length_f32(const TspProblem &problem, const std::vector<float> &xy, const std::vector<uint32_t> &pos)
+{
+    if (pos.size() < 2) return 0.0f;
+    const bool have_dm = problem.distances.num_cities() == pos.size();
+    auto d = [&](uint32_t p, uint32_t q) -> float {
+        if (have_dm) return problem.distances.distance_by_pos(p, q);
+        if (p == q) return 0.0f;
+        const volatile float dx = xy[2 * p] - xy[2 * q], dy = xy[2 * p + 1] - xy[2 * q + 1];
+        const volatile float sx = dx * dx, sy = dy * dy;
+        const volatile float ss = sx + sy;
+        return std::sqrt((float)ss);
+    };
+    volatile float total = d(pos.back(), pos.front());
+    for (size_t k = 0; k + 1 < pos.size(); ++k) total = total + d(pos[k], pos[k + 1]);
+    return total;
+}
+
 inline Solution solve(Context &ctx, const TspProblem &problem, const HeuristicOptions &, const ProgressFn *progress_tx,
                       const std::vector<size_t> *init_tour)
 {
@@ -354,8 +383,36 @@ inline Solution solve(Context &ctx, const TspProblem &problem, const HeuristicOp
     if (init_tour) init = problem.positions_of(*init_tour);
     float cost = 0.f;
     tl_stats st{};
-    ctx.check(tl_or_opt(ctx.get(), xy.data(), n, problem.explicit_packed(), init_tour ? init.data() : nullptr, out.data(), &cost, &st));
-    return detail::finish(problem, out, cost, st, progress_tx);
+    if (!(progress_tx && *progress_tx) || n < 4) {  // (n < 4: the reference returns before its first message, or_opt.rs:31-34)
+        ctx.check(tl_or_opt(ctx.get(), xy.data(), n, problem.explicit_packed(), init_tour ? init.data() : nullptr, out.data(), &cost, &st));
+        return detail::finish(problem, out, cost, st, nullptr);
+    }
+    // With a progress callback the solve also lists its moves (tl_or_opt_trace) and the reference's message sequence — the start
+    // path (0.0), the path and its tour_length after every apply_relocation, Done (or_opt.rs:40-42,62-67,70-72) — is replayed.
+    uint32_t cap = std::max<uint32_t>(64u, 4u * n), len = 0;
+    std::vector<uint32_t> log;
+    for (;;) {
+        log.assign((size_t)cap * 4, 0u);
+        ctx.check(tl_or_opt_trace(ctx.get(), xy.data(), n, problem.explicit_packed(), init_tour ? init.data() : nullptr, out.data(), &cost, &st,
+                                  log.data(), cap, &len));
+        if (len <= cap) break;
+        cap = len;  // deterministic: once more with room for every move
+    }
+    std::vector<uint32_t> pos(n);
+    for (uint32_t q = 0; q < n; ++q) pos[q] = init_tour ? init[q] : q;
+    std::vector<size_t> route(n);
+    auto send = [&](float d) {
+        for (uint32_t q = 0; q < n; ++q) route[q] = problem.cities[pos[q]].id;
+        (*progress_tx)(ProgressKind::PathUpdate, route, d);
+    };
+    send(0.0f);
+    for (uint32_t m = 0; m < len; ++m) {
+        apply_relocation(pos, log[4 * m], log[4 * m + 2], log[4 * m + 1], log[4 * m + 3] != 0u);
+        send(tour_length_f32(problem, xy, pos));
+    }
+    Solution s = detail::finish(problem, out, cost, st, nullptr);
+    (*progress_tx)(ProgressKind::Done, s.route_, cost);
+    return s;
 }
 }  // namespace or_opt
 
@@ -370,7 +427,21 @@ inline Solution solve(Context &ctx, const TspProblem &problem, const HeuristicOp
     float cost = 0.f;
     // GEO / EXPLICIT: the walk reads problem.distances (distance_matrix.rs:259-297)
     ctx.check(tl_nearest_neighbor(ctx.get(), xy.data(), problem.explicit_packed(), n, (uint32_t)opts.n_nearest, out.data(), &cost));
-    return detail::finish(problem, out, cost, tl_stats{}, progress_tx);
+    Solution s = detail::finish(problem, out, cost, tl_stats{}, nullptr);
+    if (progress_tx && *progress_tx && n > 0) {
+        // the reference's messages follow from the finished walk (nearest_neighbor.rs:32-34,40-42,67-69,72-74): the start city,
+        // then per step CityChange(current city) and the path so far, then Done
+        std::vector<size_t> path{s.route_[0]}, one(1);
+        (*progress_tx)(ProgressKind::PathUpdate, path, 0.0f);
+        for (uint32_t t = 1; t < n; ++t) {
+            one[0] = s.route_[t - 1];
+            (*progress_tx)(ProgressKind::CityChange, one, 0.0f);
+            path.push_back(s.route_[t]);
+            (*progress_tx)(ProgressKind::PathUpdate, path, 0.0f);
+        }
+        (*progress_tx)(ProgressKind::Done, s.route_, cost);
+    }
+    return s;
 }
 }  // namespace nearest_neighbor
 

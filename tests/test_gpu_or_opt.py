@@ -97,3 +97,75 @@ def test_ties_and_large_scan(ctx):
     mv = TA.or_opt.find_best_move(problem(xy, None, n), nn, ctx=ctx)
     omv = O.or_opt_find_best_move(xy, None, nn)
     assert mv[1:] == omv[1:] and mv[0].tobytes() == omv[0].tobytes()
+
+
+def _or_opt_messages(xy, packed, ids, init):
+    # or_opt.rs:36-72 restated as its message stream, with the oracle's find_best_move / apply_relocation / tour_length
+    n = len(ids)
+    tour = np.arange(n, dtype=np.uint32) if init is None else np.asarray(init, dtype=np.uint32).copy()
+    msgs = [("PathUpdate", ([int(ids[v]) for v in tour], 0.0))]
+    moves = []
+    while True:
+        mv = O.or_opt_find_best_move(xy, packed, tour)
+        if mv is None:
+            break
+        _, i, j, seg, rev = mv
+        rc, tour = O.apply_relocation(tour, i, seg, j, rev)
+        moves.append((i, j, seg, int(rev)))
+        msgs.append(("PathUpdate", ([int(ids[v]) for v in tour], float(O.tour_length(xy, packed, tour)))))
+    msgs.append(("Done", None))
+    return msgs, moves, tour
+
+
+def test_progress_channel_replays_the_reference_messages(ctx, tsplib_dir):
+    # or_opt.rs:40-42,62-67,70-72: PathUpdate(start, 0.0), PathUpdate(path, distances.tour_length(path)) after every
+    # apply_relocation, Done.  With a progress callback or_opt::solve goes through tl_or_opt_trace and replays exactly that.
+    import ctypes as C
+    import teeline_amd as TA
+    from teeline_amd import _capi
+    d = T.parse_tsplib(os.path.join(tsplib_dir, "berlin52.tsp"))
+    g = T.parse_tsplib(os.path.join(tsplib_dir, "gr17.tsp"))
+    xs = O.synth_xy(150, seed=5)
+    cases = [(d["xy"], None, d["ids"], None), (d["xy"], None, d["ids"], O.restart_perm(d["n"], 11, 0)), (g["xy"], g["packed"], g["ids"], None),
+             (xs, None, np.arange(150), O.restart_perm(150, 3, 1))]
+    for xy, packed, ids, init in cases:
+        n = len(ids)
+        want, moves, tour = _or_opt_messages(xy, packed, ids, init)
+        got = []
+        dmx = None if packed is None else TA.distance_matrix.DistanceMatrix(n, np.ascontiguousarray(packed, dtype=np.float32), ids, "explicit")
+        sol = TA.or_opt.solve(TA.TspProblem(ids, xy, dmx), None, lambda kind, payload: got.append((kind, payload)),
+                              None if init is None else [int(ids[v]) for v in init], ctx=ctx)
+        assert len(got) == len(want) and [m[0] for m in got] == [m[0] for m in want]
+        for a, b in zip(got, want):
+            if a[0] == "PathUpdate":
+                assert a[1][0] == b[1][0] and np.float32(a[1][1]).tobytes() == np.float32(b[1][1]).tobytes()
+        assert list(sol.route()) == [int(ids[v]) for v in tour] and sol.stats["moves"] == len(moves)
+        out = np.empty(n, dtype=np.uint32)
+        c, st, ln = C.c_float(), _capi.TlStats(), C.c_uint32()
+        cap = max(len(moves) // 2, 1)
+        log = np.full((cap, 4), 0x12345678, dtype=np.uint32)
+        xyc = np.ascontiguousarray(xy, dtype=np.float32)
+        pk = None if packed is None else np.ascontiguousarray(packed, dtype=np.float32)
+        ip = None if init is None else np.ascontiguousarray(init, dtype=np.uint32)
+        ctx.check(ctx.lib.tl_or_opt_trace(ctx.handle, xyc.ctypes.data_as(C.c_void_p), n, None if pk is None else pk.ctypes.data_as(C.c_void_p),
+                                          None if ip is None else ip.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.byref(c), C.byref(st),
+                                          log.ctypes.data_as(C.c_void_p), cap, C.byref(ln)))
+        assert ln.value == len(moves) == st.moves
+        m = min(cap, len(moves))
+        assert log[:m].tolist() == [list(v) for v in moves[:m]] and (log[m:] == 0x12345678).all() and out.tolist() == tour.tolist()
+
+
+def test_nearest_neighbor_progress_follows_from_the_walk(ctx, tsplib_dir):
+    # nearest_neighbor.rs:32-34,40-42,67-69,72-74: PathUpdate([start], 0.0); per step CityChange(current) + PathUpdate(path so far, 0.0); Done
+    import teeline_amd as TA
+    d = T.parse_tsplib(os.path.join(tsplib_dir, "berlin52.tsp"))
+    got = []
+    sol = TA.nearest_neighbor.solve(TA.TspProblem(d["ids"], d["xy"]), TA.HeuristicOptions(n_nearest=3), lambda k, p: got.append((k, p)), ctx=ctx)
+    route = [int(v) for v in sol.route()]
+    rc, oroute, oc = O.nearest_neighbor(d["xy"], None, d["n"], 3)
+    assert route == [int(d["ids"][v]) for v in oroute]
+    want = [("PathUpdate", (route[:1], 0.0))]
+    for t in range(1, len(route)):
+        want += [("CityChange", route[t - 1]), ("PathUpdate", (route[:t + 1], 0.0))]
+    want.append(("Done", None))
+    assert got == want
