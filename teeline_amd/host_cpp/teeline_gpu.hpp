@@ -766,6 +766,7 @@ struct StageOptions {
     LKOptions lk;
     int two_opt_mode = TL_MODE_REF_ORDER;
     uint64_t seed = 1;  // LK kicks, shuffle
+    const ProgressFn *progress = nullptr;  // handed to every stage's solve() (the reference's CLI passes None; teeline-qt a sender)
 };
 struct StageOutcome {  // :11-14
     Solvers solver;
@@ -801,11 +802,11 @@ inline std::vector<StageOutcome> run_pipeline_stages(Context &ctx, const TspProb
         const auto t0 = std::chrono::steady_clock::now();
         Solution sol;
         switch (s) {
-            case Solvers::NearestNeighbor: sol = nearest_neighbor::solve(ctx, problem, o.heuristic, nullptr, init); break;
-            case Solvers::TwoOpt: sol = two_opt::solve(ctx, problem, o.heuristic, nullptr, init, o.two_opt_mode); break;
-            case Solvers::ThreeOpt: sol = three_opt::solve(ctx, problem, o.heuristic, nullptr, init); break;
-            case Solvers::OrOpt: sol = or_opt::solve(ctx, problem, o.heuristic, nullptr, init); break;
-            case Solvers::LinKernighan: sol = lin_kernighan::solve(ctx, problem, o.lk, nullptr, init, o.seed); break;
+            case Solvers::NearestNeighbor: sol = nearest_neighbor::solve(ctx, problem, o.heuristic, o.progress, init); break;
+            case Solvers::TwoOpt: sol = two_opt::solve(ctx, problem, o.heuristic, o.progress, init, o.two_opt_mode); break;
+            case Solvers::ThreeOpt: sol = three_opt::solve(ctx, problem, o.heuristic, o.progress, init); break;
+            case Solvers::OrOpt: sol = or_opt::solve(ctx, problem, o.heuristic, o.progress, init); break;
+            case Solvers::LinKernighan: sol = lin_kernighan::solve(ctx, problem, o.lk, o.progress, init, o.seed); break;
             case Solvers::RandomShuffle: sol = random_shuffle::solve(ctx, problem, o.seed); break;
         }
         const uint64_t ms = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();

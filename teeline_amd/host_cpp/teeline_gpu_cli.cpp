@@ -23,7 +23,7 @@ namespace {
 
 struct Args {
     std::string cmd, solver, file, steps, optimal_tour, distance_type, output_format = "text";
-    bool no_seed = false, best = false, stats = false, short_list = false;
+    bool no_seed = false, best = false, stats = false, short_list = false, progress_digest = false;
     int device = 0;
     pipeline::StageOptions opt;
 };
@@ -35,6 +35,7 @@ struct Args {
                  "usage: teeline-gpu solve <nn|2opt|3opt|or_opt|lk|shuffle|fast> [-i FILE] [--no-seed] [--output-format text|json]\n"
                  "                         [--optimal-tour FILE] [--distance-type euc_2d|geo] [--epochs E] [--platoo_epochs P]\n"
                  "                         [--n_nearest K] [--max-depth D] [--seed S] [--best-sweep] [--device N] [--stats]\n"
+                 "                         [--progress-digest]\n"
                  "       teeline-gpu pipeline --steps=nn,2opt,... [-i FILE] [options as above]\n"
                  "       teeline-gpu solvers [--short]\n");
     std::exit(2);  // clap's usage-error exit code
@@ -97,6 +98,7 @@ Args parse(int argc, char **argv)
         else if (s == "--device") a.device = std::stoi(val());
         else if (s == "--stats") a.stats = true;
         else if (s == "--short") a.short_list = true;
+        else if (s == "--progress-digest") a.progress_digest = true;
         else usage_exit(("unexpected argument " + s).c_str());
     }
     if (a.output_format != "text" && a.output_format != "json") usage_exit("--output-format: text or json");
@@ -216,7 +218,30 @@ int main(int argc, char **argv)
                 std::fprintf(stderr, "--optimal-tour: %s\n", e.what());  // main.rs:486-493: reported, then ignored
             }
         }
+        // --progress-digest (a test hook, not in teeline-cli): every stage gets a progress callback, as teeline-qt's sender would be,
+        // and the message stream — which this mirror replays from the *_trace entries — is summarised on stderr: counts per kind and
+        // an FNV-1a digest over (kind, ids as u64, f32 bits) per message (Done: the kind only), comparable across the mirrors
+        struct Digest {
+            uint64_t h = 1469598103934665603ull, n[3] = {0, 0, 0};
+            void byte(uint8_t b) { h = (h ^ b) * 1099511628211ull; }
+            void word(uint64_t v, int bytes) { for (int k = 0; k < bytes; ++k) byte((uint8_t)(v >> (8 * k))); }
+        } dg;
+        ProgressFn on_progress = [&dg](ProgressKind kind, const std::vector<size_t> &ids, float v) {
+            const int k = kind == ProgressKind::PathUpdate ? 0 : kind == ProgressKind::CityChange ? 1 : 2;
+            dg.n[k] += 1;
+            dg.byte((uint8_t)k);
+            if (k == 2) return;
+            dg.word(ids.size(), 4);
+            for (size_t id : ids) dg.word(id, 8);
+            uint32_t bits;
+            std::memcpy(&bits, &v, 4);
+            dg.word(k == 0 ? bits : 0u, 4);
+        };
+        if (a.progress_digest) a.opt.progress = &on_progress;
         auto outcomes = pipeline::run_pipeline_stages(ctx, problem, stages, a.opt);
+        if (a.progress_digest)
+            std::fprintf(stderr, "progress: path_updates=%llu city_changes=%llu done=%llu digest=%016llx\n", (unsigned long long)dg.n[0],
+                         (unsigned long long)dg.n[1], (unsigned long long)dg.n[2], (unsigned long long)dg.h);
         const Solution &tour = outcomes.back().solution;
         if (!json_mode) std::fputs(cli::format_solution(tour, false).c_str(), stdout);
         cli::OptimalComparison cmp;
