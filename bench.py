@@ -592,6 +592,18 @@ def main():
                 cfg1[name] = {"kernel_ms": sm.stats["kernel_ms"], "candidates_per_s": cps, "cost": float(sm.total),
                               "sweeps": sm.stats["sweeps"], "moves": sm.stats["moves"],
                               "algorithmic_GBps_at_16B_per_candidate": cps * 16.0 / 1e9}
+            # what the drop-in does with this instance: pr1002 is EUC_2D, so the shim's tl_dm_is_euc2d check on problem.distances
+            # (integration/teeline-gpu/gpu.rs Boundary::matrix) sends it down the coordinate kernel — same tours, same costs (asserted)
+            pc2 = TA.TspProblem(np.arange(n2), xy2)
+            via = {}
+            for name, init in (("nn_start", nn2), ("identity_start", None)):
+                for _ in range(2):
+                    sc = TA.two_opt.solve(pc2, None, None, init, ctx=ctx)
+                sm = TA.two_opt.solve(pm2, None, None, init, ctx=ctx)
+                assert list(sc.route()) == list(sm.route()) and np.float32(sc.total).tobytes() == np.float32(sm.total).tobytes(), "matrix form != coordinate form"
+                via[name] = {"kernel_ms": sc.stats["kernel_ms"], "candidates_per_s": sc.stats["candidates"] / (sc.stats["kernel_ms"] * 1e-3)}
+            cfg1["drop_in_route_for_euc2d_problems"] = dict(via, note="the matrix of an EUC_2D problem equals the on-the-fly f32 distances bit for bit; "
+                                                                      "the shim checks that once per call (tl_dm_is_euc2d) and runs the coordinate kernel")
             cfg1["instance"] = label2
             cfg1["note"] = ("one descent = one workgroup on ONE CU; latency-bound (a step per move), the 4 MB full matrix stays in L2/MALL; "
                             "kernel_ms includes the packed -> full expansion")

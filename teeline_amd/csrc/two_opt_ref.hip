@@ -492,6 +492,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         // hit (the step that ends a row: the rest of the row + the row's flush) also the tiles they scanned and how many of those
         // lay outside the stale-box range (where an L0 bound would have been valid)
         uint64_t q4[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t q4l[4] = {0, 0, 0, 0};  // dense steps with a hit, split: first hit inside the lead tiles (steps, cycles) / behind them
         uint64_t t4 = __builtin_amdgcn_s_memtime();
 #endif
         for (;;) {
@@ -506,6 +507,9 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                         done = true;
                     } else {
 #ifdef TL_PROFILE4
+                        if (d == 0 && lane == 0)
+                            printf("sweep %u: dense hit in lead tiles %lu steps %lu cyc, behind %lu steps %lu cyc\n", sweeps, q4l[0], q4l[1], q4l[2], q4l[3]);
+                        for (int q = 0; q < 4; ++q) q4l[q] = 0;
                         if (d == 0 && lane == 0)
                             printf("sweep %u: dense hit %lu steps %lu cyc | dense none %lu steps %lu cyc, tiles %lu of which with valid boxes %lu | pruned hit %lu steps %lu cyc | pruned none %lu steps %lu cyc\n",
                                    sweeps, q4[0], q4[1], q4[2], q4[3], q4[8], q4[9], q4[4], q4[5], q4[6], q4[7]);
@@ -558,6 +562,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             const bool was_pruned4 = c.pruned;
             const uint64_t moves_before4 = acct.moves;
             const uint32_t t0_4 = c.j0 >> 6, dlo4 = c.dirty_lo, dhi4 = c.dirty_hi;
+            const uint32_t key4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->kr[c.slot].x);
 #endif
             float bx_ = 0.f, by_ = 0.f;
             bool reload_ = false;
@@ -574,6 +579,11 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 const int b = (was_pruned4 ? 4 : 0) + (none ? 2 : 0);
                 q4[b] += 1;
                 q4[b + 1] += t2 - t4;
+                if (!was_pruned4 && !none) {
+                    const int l = ((key4 >> 16) >> 6) < t0_4 + kLead ? 0 : 2;
+                    q4l[l] += 1;
+                    q4l[l + 1] += t2 - t4;
+                }
                 t4 = t2;
                 if (!was_pruned4 && none) {
                     uint32_t valid = 0;
@@ -598,6 +608,8 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         rev_lane = acct.rev_lane;
 #ifdef TL_PROFILE4
         if (d == 0 && lane == 0)
+            printf("sweep %u: dense hit in lead tiles %lu steps %lu cyc, behind %lu steps %lu cyc\n", sweeps, q4l[0], q4l[1], q4l[2], q4l[3]);
+        if (d == 0 && lane == 0)
             printf("sweep %u: dense hit %lu steps %lu cyc | dense none %lu steps %lu cyc, tiles %lu of which with valid boxes %lu | pruned hit %lu steps %lu cyc | pruned none %lu steps %lu cyc\n",
                    sweeps, q4[0], q4[1], q4[2], q4[3], q4[8], q4[9], q4[4], q4[5], q4[6], q4[7]);
 #endif
@@ -620,9 +632,13 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         // ------------------------------------------------------------ worker waves
         const int wk = wave - 1;
 #ifdef TL_PROFILE3
-        uint64_t q3[6] = {0, 0, 0, 0, 0, 0};  // dense steps of this wave: boundary, lead tile, B1 wait, round 2, B2 wait, steps
+        // dense steps of this wave by outcome (0: first hit inside the lead tiles, 1: behind them, 2: none): cycles from the previous
+        // step's B2 to the lead round (boundary, flushes, row set-up), lead tile, B1 wait, round 2, B2 wait; [5] steps.  Printed by
+        // wave 1 (a lead wave) and wave 6 of descent 0.
+        uint64_t q3[3][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
+        uint64_t d3[5] = {0, 0, 0, 0, 0};
         uint64_t t3 = __builtin_amdgcn_s_memtime();
-#define TL_STAMP3(k) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); q3[k] += t_ - t3; t3 = t_; } while (0)
+#define TL_STAMP3(k) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); d3[k] = t_ - t3; t3 = t_; } while (0)
 #else
 #define TL_STAMP3(k) do { } while (0)
 #endif
@@ -738,15 +754,24 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             TL_SYNC();  // B2
             TL_STAMP3(4);
 #ifdef TL_PROFILE3
-            q3[5] += c.pruned ? 0 : 1;
+            if (!c.pruned) {
+                const uint32_t key3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->kr[c.slot].x);
+                const int ty = key3 == kNoKey ? 2 : (((key3 >> 16) >> 6) < (c.j0 >> 6) + kLead ? 0 : 1);
+                for (int q = 0; q < 5; ++q) q3[ty][q] += d3[q];
+                q3[ty][5] += 1;
+            } else {
+                t3 = __builtin_amdgcn_s_memtime();  // a pruned step's cycles belong to no dense step
+            }
 #endif
             need_desc = step_boundary<false, NT, kSlots>(c, acct, P, perm, ctl, queues, n, nrows, R, lane, wave, tid, my_hits, bx, by, reload);
         }
 #ifdef TL_PROFILE3
-        if (lane == 0 && (wave == 1 || wave == 6)) {  // a lead wave and a non-lead one
-            uint64_t *st = A.out_stats + (size_t)d * TL_STATS_STRIDE + (wave == 1 ? 5 : 11);
-            for (int q = 0; q < (wave == 1 ? 6 : 5); ++q) st[q] = q3[q];
-        }
+        if (d == 0 && lane == 0 && (wave == 1 || wave == 6))  // a lead wave and a non-lead one
+            for (int ty = 0; ty < 3; ++ty)
+                printf("wave %d, dense steps %s: %lu steps; per step: to the lead round %lu, lead tile %lu, B1 wait %lu, round 2 %lu, B2 wait %lu\n", wave,
+                       ty == 0 ? "with the first hit in the lead tiles" : ty == 1 ? "with the first hit behind them" : "without a hit", q3[ty][5],
+                       q3[ty][0] / (q3[ty][5] ? q3[ty][5] : 1), q3[ty][1] / (q3[ty][5] ? q3[ty][5] : 1), q3[ty][2] / (q3[ty][5] ? q3[ty][5] : 1),
+                       q3[ty][3] / (q3[ty][5] ? q3[ty][5] : 1), q3[ty][4] / (q3[ty][5] ? q3[ty][5] : 1));
 #endif
     }
 
