@@ -492,6 +492,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         // hit (the step that ends a row: the rest of the row + the row's flush) also the tiles they scanned and how many of those
         // lay outside the stale-box range (where an L0 bound would have been valid)
         uint64_t q4[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t q4c[3] = {0, 0, 0}, t4b = __builtin_amdgcn_s_memtime();  // control wave: cycles from B2 to its arrival at B1, its wait at B1, dense steps
         uint64_t q4l[4] = {0, 0, 0, 0};  // dense steps with a hit, split: first hit inside the lead tiles (steps, cycles) / behind them
         uint64_t t4 = __builtin_amdgcn_s_memtime();
 #endif
@@ -551,9 +552,23 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                     TL_SYNC();
                 }
             } else {
+#ifdef TL_PROFILE4
+                const uint64_t tb0 = __builtin_amdgcn_s_memtime();
+#endif
                 TL_SYNC();  // B1: lead round
+#ifdef TL_PROFILE4
+                {   // the control wave's own way to B1 (from the previous step's B2) and its wait there
+                    const uint64_t tb1 = __builtin_amdgcn_s_memtime();
+                    q4c[0] += tb0 - t4b;
+                    q4c[1] += tb1 - tb0;
+                    q4c[2] += 1;
+                }
+#endif
             }
             TL_SYNC();  // B2
+#ifdef TL_PROFILE4
+            t4b = __builtin_amdgcn_s_memtime();
+#endif
 #ifdef TL_PROFILE2
             const bool was_pruned = c.pruned;
             const uint64_t moves_before = acct.moves;
@@ -586,10 +601,11 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 }
                 t4 = t2;
                 if (!was_pruned4 && none) {
-                    uint32_t valid = 0;
-                    for (uint32_t t = t0_4; t <= last_tile; ++t) valid += (dlo4 > dhi4 || t < dlo4 || t > dhi4) ? 1u : 0u;
-                    q4[8] += last_tile - t0_4 + 1u;
-                    q4[9] += valid;
+                    const uint32_t tiles = last_tile - t0_4 + 1u;
+                    const uint32_t lo = dlo4 > t0_4 ? dlo4 : t0_4, hi = dhi4 < last_tile ? dhi4 : last_tile;
+                    const uint32_t stale = (dlo4 <= dhi4 && lo <= hi) ? hi - lo + 1u : 0u;
+                    q4[8] += tiles;
+                    q4[9] += tiles - stale;
                 }
             }
 #endif
@@ -609,6 +625,8 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #ifdef TL_PROFILE4
         if (d == 0 && lane == 0)
             printf("sweep %u: dense hit in lead tiles %lu steps %lu cyc, behind %lu steps %lu cyc\n", sweeps, q4l[0], q4l[1], q4l[2], q4l[3]);
+        if (d == 0 && lane == 0)
+            printf("control wave, dense steps: %lu; per step from B2 to its arrival at B1 %lu cycles, its wait at B1 %lu\n", q4c[2], q4c[0] / (q4c[2] ? q4c[2] : 1), q4c[1] / (q4c[2] ? q4c[2] : 1));
         if (d == 0 && lane == 0)
             printf("sweep %u: dense hit %lu steps %lu cyc | dense none %lu steps %lu cyc, tiles %lu of which with valid boxes %lu | pruned hit %lu steps %lu cyc | pruned none %lu steps %lu cyc\n",
                    sweeps, q4[0], q4[1], q4[2], q4[3], q4[8], q4[9], q4[4], q4[5], q4[6], q4[7]);
