@@ -580,3 +580,30 @@ def test_move_list_and_progress_of_the_matrix_form(ctx, tsplib_dir):
                 assert [np.float32(m[1][1]).tobytes() for m in upd[1:]] == [np.float32(v).tobytes() for v in dist]
                 assert upd[-1][1][0] == [int(ids[v]) for v in route] if len(ij) else True
                 assert sum(1 for m in got if m[0] == "CityChange") == st["sweeps"] * (n - 3)
+
+
+def test_progress_at_tiny_sizes(ctx):
+    # n = 3 ... 6: the move list and the replayed messages where rows are few (n = 3: no row at all, one sweep; n < 4: 3-opt and Or-opt
+    # return before their first message), coordinates and matrix form
+    import teeline_amd as TA
+    for n in (3, 4, 5, 6):
+        for seed in (1, 2, 3):
+            xy = O.synth_xy(n, seed=seed)
+            packed = O.dm_build_packed(xy)
+            init = O.restart_perm(n, seed, 0)
+            for form in ("xy", "dm"):
+                prob = TA.TspProblem(np.arange(n), xy, None if form == "xy" else TA.distance_matrix.DistanceMatrix(n, packed, np.arange(n), "explicit"))
+                got = []
+                sol = TA.two_opt.solve(prob, None, lambda k, p: got.append((k, p)), [int(v) for v in init], ctx=ctx)
+                rc, route, cost, st, ij, dist, sw = O.two_opt_trace(xy, None if form == "xy" else packed, n, init=init)
+                assert list(sol.route()) == route.tolist(), (n, seed, form)
+                pu = [m for m in got if m[0] == "PathUpdate"]
+                assert len(pu) == 1 + len(ij) and got[-1] == ("Done", None)
+                assert sum(1 for m in got if m[0] == "CityChange") == st["sweeps"] * max(n - 3, 0), (n, seed, form, st)
+                assert [np.float32(m[1][1]).tobytes() for m in pu[1:]] == [np.float32(v).tobytes() for v in dist]
+            for solver in (TA.three_opt, TA.or_opt):
+                got = []
+                sol = solver.solve(TA.TspProblem(np.arange(n), xy), None, lambda k, p: got.append((k, p)), [int(v) for v in init], ctx=ctx)
+                assert (got == []) == (n < 4), (solver.__name__, n, got[:2])
+                if n >= 4:
+                    assert got[0][0] == "PathUpdate" and got[-1] == ("Done", None) and got[-2][1][0] == list(sol.route())
