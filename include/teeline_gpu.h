@@ -201,7 +201,7 @@ int tl_or_opt_find_best_move(tl_ctx *ctx, const float *xy, uint32_t n, const flo
 /* The reference's solve() functions take Option<&Sender<ProgressMessage>> (two_opt.rs:10, three_opt.rs:19, lin_kernighan.rs:38;
  * only teeline-qt passes one).  A descent here is one kernel launch (or a device-side state machine), so nothing can be sent
  * while it runs; the *_trace entries return, beside the plain entry's results, the record from which the caller replays the
- * reference's exact message sequence after the fact (teeline_amd/host/*.py, teeline_gpu.hpp, integration/teeline-gpu/gpu.rs do).
+ * reference's exact message sequence after the fact (the Python mirror under teeline_amd/host, teeline_gpu.hpp and integration/teeline-gpu/gpu.rs do).
  * (nearest_neighbor::solve needs no such entry: its messages — the growing path prefix and the current city per step,
  * nearest_neighbor.rs:32-34,40-42,67-69,72-74 — follow from the finished tour.)
  *
