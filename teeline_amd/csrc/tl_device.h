@@ -129,6 +129,16 @@ __device__ __forceinline__ void jitter(uint32_t salt)
 #define TL_SYNC() __syncthreads()
 #endif
 
+// One lane's ds_min_u32 exactly as written.  atomicMin on a wave-uniform LDS address goes through the compiler's atomic optimiser,
+// which wraps it in a scan over the active lanes (~20 scalar instructions and a v_mbcnt pair) even where the caller has already
+// narrowed exec to one lane — on the path every wave of a descent waits for.  (LDS operations of a wave complete in order, so the
+// compiler's own lgkmcnt waits stay sufficient around it.)
+__device__ __forceinline__ void lds_min_u32(uint32_t *p, uint32_t v)
+{
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)p;
+    asm volatile("ds_min_u32 %0, %1" : : "v"(a), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ float readlane_f(float v, int l)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));

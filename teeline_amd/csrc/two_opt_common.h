@@ -143,12 +143,12 @@ struct NoCounts {
 // sqab = sq(a, b) is a row constant the caller already holds.
 // (The logic runs on 64-bit lane masks — every ballot below is taken of a plain comparison, i.e. is the v_cmp itself, and the
 // and / or / not are scalar instructions; a ballot of a boolean expression costs a v_cndmask + v_cmp_ne pair on top.)
+// (tile_mask_terms: the same with the two squares that do not depend on the row's b — s1 = sq(a, c), sqce = sq(c, e) — given: a
+//  wave that chains hits inside a tile decides the tile again and again against a new b and keeps them in registers)
 template <bool PRUNE, typename TC>
-__device__ __forceinline__ uint64_t tile_mask_core(float2 c, float2 e, uint32_t j, uint32_t n, uint32_t jmin,
-                                                   float ax, float ay, float bx, float by, float sqab, TC &tc)
+__device__ __forceinline__ uint64_t tile_mask_terms(float s1, float sqce, float2 e, uint32_t j, uint32_t n, uint32_t jmin,
+                                                    float bx, float by, float sqab, TC &tc)
 {
-    const float sqce = sqdist(c, e);
-    const float s1 = sqdist(make_float2(ax, ay), c);
     const float s2 = sqdist(make_float2(bx, by), e);
     const uint64_t m_rng = __builtin_amdgcn_ballot_w64((j - jmin) <= (n - 2u - jmin));  // jmin <= j <= n-2 in one unsigned compare (callers keep jmin <= n-2)
     if (PRUNE) {
@@ -184,6 +184,13 @@ __device__ __forceinline__ uint64_t tile_mask_core(float2 c, float2 e, uint32_t 
         const float cur = sqrt_rn(sqab) + sqrt_rn(sqce);
         return m_rng & __builtin_amdgcn_ballot_w64(neu < cur);  // two_opt.rs:35-49
     }
+}
+
+template <bool PRUNE, typename TC>
+__device__ __forceinline__ uint64_t tile_mask_core(float2 c, float2 e, uint32_t j, uint32_t n, uint32_t jmin,
+                                                   float ax, float ay, float bx, float by, float sqab, TC &tc)
+{
+    return tile_mask_terms<PRUNE>(sqdist(make_float2(ax, ay), c), sqdist(c, e), e, j, n, jmin, bx, by, sqab, tc);
 }
 
 template <bool PRUNE, typename TC, typename PT>
@@ -240,7 +247,8 @@ __device__ __forceinline__ uint32_t dense_tile(const PT &P, uint32_t n, uint32_t
     if (STOPCHK) {  // an earlier column already improves (kNoKey reads as column 65535)
         if (((uint32_t)__builtin_amdgcn_readfirstlane((int)kbv) >> 16) < tb) return kTileStopped;
     }
-    uint64_t m = tile_mask_core<PRUNE>(c, e, j, n, jmin, ax, ay, bx, by, sqab, tc);
+    float s1 = sqdist(make_float2(ax, ay), c), sqce = sqdist(c, e);  // the tile's terms without b: kept for the chain's re-decisions
+    uint64_t m = tile_mask_terms<PRUNE>(s1, sqce, e, j, n, jmin, bx, by, sqab, tc);
     if (m == 0) return 0;  // the common case: no chain state was ever set up
     uint32_t from = jmin, nh = 0, hitv = 0, mykey = 0;  // lane h of hitv holds the h-th hit column
     bool capped = false;
@@ -250,7 +258,7 @@ __device__ __forceinline__ uint32_t dense_tile(const PT &P, uint32_t n, uint32_t
         hitv = ((uint32_t)lane == nh) ? jh : hitv;
         if (nh == 0) {
             mykey = (jh << 16) | wtag;
-            if (lane == 0) atomicMin(keyslot, mykey);  // post at once: it stops the other waves' scans
+            if (lane == 0) lds_min_u32(keyslot, mykey);  // post at once: it stops the other waves' scans
         }
         ++nh;
         from = jh + 1u;
@@ -261,9 +269,8 @@ __device__ __forceinline__ uint32_t dense_tile(const PT &P, uint32_t n, uint32_t
             break;
         }
         if (from > n - 2u) break;
-        const float dx = ax - bx, dy = ay - by;
-        sqab = dx * dx + dy * dy;
-        m = (l == 63) ? 0ull : tile_mask_core<PRUNE>(c, e, j, n, from, ax, ay, bx, by, sqab, tc);
+        sqab = readlane_f(s1, l);  // the new sq(a, b) is sq(a, c) of the hit lane: the same four roundings
+        m = (l == 63) ? 0ull : tile_mask_terms<PRUNE>(s1, sqce, e, j, n, from, bx, by, sqab, tc);
         uint32_t idle = 0;
         bool stop = false;
         while (m == 0) {  // tile exhausted: the next one, alone
@@ -277,7 +284,9 @@ __device__ __forceinline__ uint32_t dense_tile(const PT &P, uint32_t n, uint32_t
             j += 64u;
             c = pt_get(P, j);
             e = pt_get(P, j + 1u);
-            m = tile_mask_core<PRUNE>(c, e, j, n, from, ax, ay, bx, by, sqab, tc);
+            s1 = sqdist(make_float2(ax, ay), c);
+            sqce = sqdist(c, e);
+            m = tile_mask_terms<PRUNE>(s1, sqce, e, j, n, from, bx, by, sqab, tc);
         }
         if (stop) break;
     }

@@ -765,7 +765,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                     }
                     continue;  // nothing in this row: rows w+NWK, ... next
                 row_hit:
-                    if (lane == 0) atomicMin(keyslot, (i << 16) | ((t << 6) + (uint32_t)(__builtin_ffsll((long long)hm) - 1)));
+                    if (lane == 0) lds_min_u32(keyslot, (i << 16) | ((t << 6) + (uint32_t)(__builtin_ffsll((long long)hm) - 1)));
                     break;  // rows w+NWK, ... are later rows
                 }
             }
