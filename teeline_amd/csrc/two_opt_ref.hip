@@ -493,6 +493,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         // lay outside the stale-box range (where an L0 bound would have been valid)
         uint64_t q4[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         uint64_t q4c[3] = {0, 0, 0}, t4b = __builtin_amdgcn_s_memtime();  // control wave: cycles from B2 to its arrival at B1, its wait at B1, dense steps
+        uint64_t q4m[3] = {0, 0, 0};  // tile-box rebuilds in front of pruned steps: cycles (to the barrier behind them), count, tiles
         uint64_t q4l[4] = {0, 0, 0, 0};  // dense steps with a hit, split: first hit inside the lead tiles (steps, cycles) / behind them
         uint64_t t4 = __builtin_amdgcn_s_memtime();
 #endif
@@ -546,10 +547,18 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             const uint32_t R = c.pruned ? ((uint32_t)kRMax < nrows - c.i0 ? (uint32_t)kRMax : nrows - c.i0) : 1u;
             if (c.pruned) {
                 if (c.dirty_lo <= c.dirty_hi) {  // stale tile boxes: every wave takes its share (this one has nothing else to do here)
+#ifdef TL_PROFILE4
+                    const uint64_t tm0 = __builtin_amdgcn_s_memtime();
+                    q4m[2] += c.dirty_hi - c.dirty_lo + 1u;
+#endif
                     for (uint32_t t = c.dirty_lo; t <= c.dirty_hi; t += (uint32_t)NW) build_tile_meta(P, n, t, lane, tbox, tmsq);
                     c.dirty_lo = 0xFFFFFFFFu;
                     c.dirty_hi = 0;
                     TL_SYNC();
+#ifdef TL_PROFILE4
+                    q4m[0] += __builtin_amdgcn_s_memtime() - tm0;
+                    q4m[1] += 1;
+#endif
                 }
             } else {
 #ifdef TL_PROFILE4
@@ -625,6 +634,8 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #ifdef TL_PROFILE4
         if (d == 0 && lane == 0)
             printf("sweep %u: dense hit in lead tiles %lu steps %lu cyc, behind %lu steps %lu cyc\n", sweeps, q4l[0], q4l[1], q4l[2], q4l[3]);
+        if (d == 0 && lane == 0)
+            printf("tile-box rebuilds: %lu, %lu cycles and %lu tiles apiece\n", q4m[1], q4m[0] / (q4m[1] ? q4m[1] : 1), q4m[2] / (q4m[1] ? q4m[1] : 1));
         if (d == 0 && lane == 0)
             printf("control wave, dense steps: %lu; per step from B2 to its arrival at B1 %lu cycles, its wait at B1 %lu\n", q4c[2], q4c[0] / (q4c[2] ? q4c[2] : 1), q4c[1] / (q4c[2] ? q4c[2] : 1));
         if (d == 0 && lane == 0)
