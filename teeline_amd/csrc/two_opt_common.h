@@ -145,9 +145,11 @@ struct NoCounts {
 // and / or / not are scalar instructions; a ballot of a boolean expression costs a v_cndmask + v_cmp_ne pair on top.)
 // (tile_mask_terms: the same with the two squares that do not depend on the row's b — s1 = sq(a, c), sqce = sq(c, e) — given: a
 //  wave that chains hits inside a tile decides the tile again and again against a new b and keeps them in registers)
-template <bool PRUNE, typename TC>
+// (ROOTS: the chain's copy — the approximate roots of s1, sqce and sqab come with them: r1 and rce were taken once when the chain
+//  began, and the new sqab's root is r1 of the hit lane)
+template <bool PRUNE, bool ROOTS = false, typename TC>
 __device__ __forceinline__ uint64_t tile_mask_terms(float s1, float sqce, float2 e, uint32_t j, uint32_t n, uint32_t jmin,
-                                                    float bx, float by, float sqab, TC &tc)
+                                                    float bx, float by, float sqab, TC &tc, float r1 = 0.0f, float rce = 0.0f, float rab = 0.0f)
 {
     const float s2 = sqdist(make_float2(bx, by), e);
     const uint64_t m_rng = __builtin_amdgcn_ballot_w64((j - jmin) <= (n - 2u - jmin));  // jmin <= j <= n-2 in one unsigned compare (callers keep jmin <= n-2)
@@ -156,8 +158,8 @@ __device__ __forceinline__ uint64_t tile_mask_terms(float s1, float sqce, float2
         const uint64_t m1 = m_rng & (__builtin_amdgcn_ballot_w64(s1 < sqab) | __builtin_amdgcn_ballot_w64(s2 < sqce));  // L1
         if (!m1) return 0;                                               // the common case late in a sweep
         tc.l2 += (uint32_t)__builtin_popcountll(m1);
-        const float neu_a = __builtin_amdgcn_sqrtf(s1) + __builtin_amdgcn_sqrtf(s2);  // L2
-        const float cur_a = __builtin_amdgcn_sqrtf(sqab) + __builtin_amdgcn_sqrtf(sqce);
+        const float neu_a = (ROOTS ? r1 : __builtin_amdgcn_sqrtf(s1)) + __builtin_amdgcn_sqrtf(s2);  // L2
+        const float cur_a = (ROOTS ? rab : __builtin_amdgcn_sqrtf(sqab)) + (ROOTS ? rce : __builtin_amdgcn_sqrtf(sqce));
         const float margin = cur_a * 1.9073486e-6f;                      // 2^-19
         uint64_t m_imp = m1 & __builtin_amdgcn_ballot_w64(neu_a < cur_a - margin);
         // near-ties, tiny squares (v_sqrt_f32 loses accuracy on denormals) and non-finite sums go to L3.  Squares are
@@ -252,6 +254,11 @@ __device__ __forceinline__ uint32_t dense_tile(const PT &P, uint32_t n, uint32_t
     if (m == 0) return 0;  // the common case: no chain state was ever set up
     uint32_t from = jmin, nh = 0, hitv = 0, mykey = 0;  // lane h of hitv holds the h-th hit column
     bool capped = false;
+    float r1 = 0.0f, rce = 0.0f;  // the chain's roots of s1 and sqce (PRUNE: L2 works on approximate roots)
+    if (PRUNE) {
+        r1 = __builtin_amdgcn_sqrtf(s1);
+        rce = __builtin_amdgcn_sqrtf(sqce);
+    }
     for (;;) {
         const int l = __builtin_ffsll((long long)m) - 1;
         const uint32_t jh = tb + (uint32_t)l;
@@ -270,7 +277,8 @@ __device__ __forceinline__ uint32_t dense_tile(const PT &P, uint32_t n, uint32_t
         }
         if (from > n - 2u) break;
         sqab = readlane_f(s1, l);  // the new sq(a, b) is sq(a, c) of the hit lane: the same four roundings
-        m = (l == 63) ? 0ull : tile_mask_terms<PRUNE>(s1, sqce, e, j, n, from, bx, by, sqab, tc);
+        const float rab = PRUNE ? readlane_f(r1, l) : 0.0f;
+        m = (l == 63) ? 0ull : tile_mask_terms<PRUNE, PRUNE>(s1, sqce, e, j, n, from, bx, by, sqab, tc, r1, rce, rab);
         uint32_t idle = 0;
         bool stop = false;
         while (m == 0) {  // tile exhausted: the next one, alone
@@ -286,7 +294,11 @@ __device__ __forceinline__ uint32_t dense_tile(const PT &P, uint32_t n, uint32_t
             e = pt_get(P, j + 1u);
             s1 = sqdist(make_float2(ax, ay), c);
             sqce = sqdist(c, e);
-            m = tile_mask_terms<PRUNE>(s1, sqce, e, j, n, from, bx, by, sqab, tc);
+            if (PRUNE) {
+                r1 = __builtin_amdgcn_sqrtf(s1);
+                rce = __builtin_amdgcn_sqrtf(sqce);
+            }
+            m = tile_mask_terms<PRUNE, PRUNE>(s1, sqce, e, j, n, from, bx, by, sqab, tc, r1, rce, rab);
         }
         if (stop) break;
     }
