@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
                         if (m && !done) {
                             const uint32_t l = (uint32_t)(__builtin_ffsll((long long)m) - 1);
                             if (lane == l) {
-                                atomicMin(&keys[slot], (i << 16) | j);
+                                lds_min_u32(&keys[slot], (i << 16) | j);  // (one lane; not through the atomic optimiser's lane scan, tl_device.h)
                                 hl_j[wave * kDmChain] = j;
                                 hl_a[wave * kDmChain] = dac[u];
                                 hl_b[wave * kDmChain] = dbe[u];
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
                         const uint32_t l = (uint32_t)(__builtin_ffsll((long long)m) - 1);
                         jh = jb + l;
                         if (lane == l) {
-                            if (nh == 0) atomicMin(&keys[slot], (i << 16) | jh);
+                            if (nh == 0) lds_min_u32(&keys[slot], (i << 16) | jh);
                             hl_j[wave * kDmChain + nh] = jh;
                             hl_a[wave * kDmChain + nh] = dac;
                             hl_b[wave * kDmChain + nh] = dbe;
