@@ -162,24 +162,27 @@ def latest_profile(pattern):
     return f[-1] if f else None
 
 
-def scan_valu_roofline(kernel, n, ms, info, clock_hz):
-    """VALU-issue roofline of a whole-chip scan kernel (3-opt / Or-opt find_best_move): wave64 VALU instructions of ONE launch from
-    the committed rocprofv3 PMC pass (profiles/rNN_scans_pmc.json, scripts/pmc_scans.sh: same instance, same tour, so the count is a
-    property of the launch) over the kernel time measured live here; peak = SIMDs x live clock / 2.  None if no profile matches."""
+def scan_valu_roofline(kernel, n, ms, info, clock_hz, also=()):
+    """VALU-issue roofline of a whole-chip scan kernel (3-opt / Or-opt find_best_move; a BEST_SWEEP sweep; an LK round): wave64 VALU
+    instructions of ONE launch from the committed rocprofv3 PMC pass (profiles/rNN_scans_pmc.json, scripts/pmc_scans.sh: same instance,
+    same tour, so the count is a property of the launch) over the time measured live here; peak = SIMDs x live clock / 2.
+    `also`: further kernels of the same unit of work (the step kernel of a round), their instructions added.  None if no profile matches."""
     prof = latest_profile("r*_scans_pmc.json")
     if not prof or clock_hz <= 0:
         return None
     try:
-        pj = json.load(open(prof)).get(kernel)
+        allp = json.load(open(prof))
+        pj = allp.get(kernel)
         if not pj or pj.get("n") != n:
             return None
         simds = info["cus"] * SIMDS_PER_CU
         peak = simds * clock_hz / VALU_CYCLES_PER_WAVE_INST / 1e9
-        ach = float(pj["SQ_INSTS_VALU"]) / (ms * 1e-3) / 1e9
+        insts = float(pj["SQ_INSTS_VALU"]) + sum(float(allp[k]["SQ_INSTS_VALU"]) for k in also if k in allp)
+        ach = insts / (ms * 1e-3) / 1e9
         r = {"bound": "valu_issue", "achieved": ach, "peak": peak, "unit": "G wave64-VALU-instructions/s", "frac": ach / peak, "traffic": None,
-             "kernel": kernel, "kernel_ms": ms, "valu_insts_per_launch": pj["SQ_INSTS_VALU"], "source": os.path.relpath(prof, ROOT),
+             "kernel": " + ".join((kernel,) + tuple(also)), "kernel_ms": ms, "valu_insts_per_launch": insts, "source": os.path.relpath(prof, ROOT),
              "formula": "frac = SQ_INSTS_VALU / (simds * kernel_s * clock_hz / 2); clock = the headline kernel's live in-kernel clock of this run"}
-        for k in ("SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CU_CYCLES", "kernel_ms_profiled"):
+        for k in ("SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CU_CYCLES", "kernel_ms_profiled", "kernel_ms_profiled_mean", "launches"):
             if k in pj:
                 r.setdefault("pmc", {})[k] = pj[k]
         return r
@@ -242,7 +245,93 @@ def valu_roofline(n, R, seed, first, info, k_ms, clock_hz, work, cand_per_launch
     return r
 
 
+def write_tsplib(path, name, xy):
+    """EUC_2D TSPLIB file whose coordinates read back (strtof, tsplib.rs:356-377) as exactly these f32 values."""
+    with open(path, "w") as fh:
+        fh.write(f"NAME : {name}\nTYPE : TSP\nDIMENSION : {len(xy)}\nEDGE_WEIGHT_TYPE : EUC_2D\nNODE_COORD_SECTION\n")
+        for k, (x, y) in enumerate(np.asarray(xy, dtype=np.float32), 1):
+            fh.write(f"{k} {float(x):.9g} {float(y):.9g}\n")
+        fh.write("EOF\n")
+
+
+def drop_in_end_to_end(TA, with_cpu):
+    """What a user of the drop-in sees (BASELINE configs[0] is "berlin52 via teeline-cli", which the reference does
+    in 0.01 s, docs/benchmarks.md:28): `teeline-gpu pipeline --steps=nn,2opt -i FILE` as a FRESH process, its wall split into process
+    start + exit, reading the file, tl_create, the first (cold) run of the stage list, a steady run and the kernels' own time
+    (teeline_gpu_cli.cpp --timing --repeat 3) — beside the oracle doing the same nn -> 2opt on one host core.  Same tour cost asserted."""
+    import subprocess
+    import tempfile
+    from teeline_amd import build as B
+    cli = B.CLI if os.path.exists(B.CLI) else B.build_cli()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    O = None
+    if with_cpu:
+        import _oracle as O
+    rows = {}
+    sizes = [("berlin52", None), ("synthetic_n200", 200), ("synthetic_n500", 500), ("synthetic_n1002", 1002), ("synthetic_n2000", 2000),
+             ("synthetic_n5000", 5000), ("synthetic_n10000", 10000)]
+    with tempfile.TemporaryDirectory(prefix="teeline_e2e_") as tmp:
+        for name, n in sizes:
+            if n is None:
+                f = os.path.join(ROOT, "tests", "golden", "tsplib", "berlin52.tsp")
+                xy = np.ascontiguousarray(TA.tsplib.read_from_file(f).xy, dtype=np.float32)
+            else:
+                xy = TA.synth.synth_xy(n)
+                f = os.path.join(tmp, name + ".tsp")
+                write_tsplib(f, name, xy)
+            cmd = [cli, "pipeline", "--steps=nn,2opt", "-i", f, "--timing", "--repeat", "3"]
+            best = None
+            for _ in range(2):  # the second process start finds the library and the file in the page cache
+                t0 = time.perf_counter()
+                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+                wall = (time.perf_counter() - t0) * 1e3
+                if pr.returncode != 0:
+                    raise RuntimeError(f"{' '.join(cmd)}: rc {pr.returncode}: {pr.stderr[-300:]}")
+                tj = json.loads([ln for ln in pr.stderr.splitlines() if ln.startswith('{"timing_ms"')][-1])["timing_ms"]
+                if best is None or wall < best[0]:
+                    best = (wall, tj, pr.stdout)
+            wall, tj, stdout = best
+            runs = tj["runs"]
+            steady = min(runs[1:], key=lambda r: r["wall_ms"])
+            extra = sum(r["wall_ms"] for r in runs[1:])
+            row = {"n": int(len(xy)), "fresh_process_wall_ms": wall - extra,
+                   "process_start_and_exit_ms": wall - tj["main_total"], "read_input_ms": tj["read_input"], "tl_create_ms": tj["tl_create"],
+                   "first_call_ms": runs[0]["wall_ms"], "steady_call_ms": steady["wall_ms"],
+                   "steady_kernel_ms": sum(st["kernel_ms"] for st in steady["stages"]), "output_ms": tj["output"],
+                   "first_call_stages_ms": {st["solver"]: st["wall_ms"] for st in runs[0]["stages"]},
+                   "steady_call_stages_ms": {st["solver"]: st["wall_ms"] for st in steady["stages"]},
+                   "cost": stdout.split()[0]}
+            if O is not None:
+                t0 = time.perf_counter()
+                _rc, nn_route, _c = O.nearest_neighbor(xy, None, len(xy), 3)
+                _rc, _route, cost, _st = O.two_opt(xy, None, len(xy), init=nn_route)
+                row["oracle_one_core_ms"] = (time.perf_counter() - t0) * 1e3
+                assert f"{float(cost):.5f}" == row["cost"], f"{name}: CLI cost {row['cost']} != oracle {float(cost):.5f}"
+                row["fresh_process_vs_one_core"] = row["oracle_one_core_ms"] / row["fresh_process_wall_ms"]
+                row["steady_call_vs_one_core"] = row["oracle_one_core_ms"] / row["steady_call_ms"]
+            rows[name] = row
+    out = {"command": "teeline_amd/teeline-gpu pipeline --steps=nn,2opt -i FILE --timing --repeat 3 (fresh process; best of two starts)", "instances": rows,
+           "note": "fresh_process_wall_ms = the process's wall with ONE run of the stage list (the two extra --repeat runs subtracted); "
+                   "first_call = cold run (code-object load of the kernels used, workspace allocation, LDS attribute), steady_call = a later run "
+                   "in the same process (what a long-lived caller such as teeline-api pays per request)"}
+    if O is not None:
+        order = sorted(rows.values(), key=lambda r: r["n"])
+        cf = [r["n"] for r in order if r["fresh_process_vs_one_core"] > 1.0]
+        cs = [r["n"] for r in order if r["steady_call_vs_one_core"] > 1.0]
+        out["crossover_n_fresh_process"] = cf[0] if cf else None
+        out["crossover_n_steady_call"] = cs[0] if cs else None
+        out["cpu_baseline"] = {"kind": "port", "cores": 1, "unit": "ms per nn -> 2opt pipeline", "sample": "the oracle's nearest_neighbor + two_opt on the same "
+                               "instance, one core, in-process (no process start, no file parse): oracle_one_core_ms per instance; same final cost asserted"}
+    return out
+
+
 METRIC = "2-opt candidate swaps evaluated/sec + final tour cost, TSPLIB EUC_2D n=10000"
+STRONG_TOTAL = 256  # BASELINE.json configs[3]: "256 random restarts sharded 1/2/4/8 GPUs"
+SCALING_NOTE = ("two readings of configs[3] in one line: `value` / weak_per_gpu = R restarts PER GPU (one descent per CU on every GPU; work grows "
+                "with N: weak scaling, the headline) and strong_256_total = 256 restarts IN ALL dealt over the ranks as configs[3] words it.  "
+                "The strong reading is flat by design: a descent is sequential and occupies one CU, a batch takes as long as its slowest "
+                "descent (~107 ms at n = 10^4) whether a GPU runs 256 of them or 32, so N GPUs finish 256 restarts in the time of one — "
+                "strong-scaling efficiency ~1/N; more GPUs buy more restarts per unit time (weak), not a shorter batch (DESIGN.md §6)")
 
 
 def gather_rank_ms(ms_local, device, dist):
@@ -269,21 +358,31 @@ def dry_launch(a, rank, world):
     seen = dist.get_world_size() if world > 1 else 1
     if seen != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but the process group has {seen} ranks")
-    n, R = 64, 4
-    first, R = ms.shard_total(rank, world, a.restarts_total) if a.restarts_total > 0 else ms.shard(rank, R)
-    ids = torch.arange(first, first + R, dtype=torch.int64)
-    costs = (((ids * 3 + 1) % 8) + ids // 8).to(torch.float32) + 1.0       # stub: a fixed cost per restart id (restart 5 wins)
-    tours = torch.stack([torch.roll(torch.arange(n, dtype=torch.int32), int(r)) for r in ids.tolist()])
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        keys = ms.pack_keys(costs, first)
-        best = ms.allreduce_best(keys, dist if world > 1 else None)
-        tour = ms.share_best_tour(keys, tours, best, dist if world > 1 else None)
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    total, dt_max = ms.aggregate_throughput(R * a.steps, dt, dev, dist if world > 1 else None)
+    n = 64
+
+    def stub_loop(first, R):
+        """the collectives of a..steps steps around the stub costs of restarts [first, first + R)"""
+        ids = torch.arange(first, first + R, dtype=torch.int64)
+        costs = (((ids * 3 + 1) % 8) + ids // 8).to(torch.float32) + 1.0       # stub: a fixed cost per restart id (restart 5 wins)
+        tours = torch.stack([torch.roll(torch.arange(n, dtype=torch.int32), int(r)) for r in ids.tolist()]) if R else torch.zeros((0, n), dtype=torch.int32)
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            keys = ms.pack_keys(costs, first)
+            best = ms.allreduce_best(keys, dist if world > 1 else None)
+            tour = ms.share_best_tour(keys, tours, best, dist if world > 1 else None)
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        total, dt_max = ms.aggregate_throughput(R * a.steps, dt, dev, dist if world > 1 else None)
+        return best, tour, dt, total, dt_max, R
+
+    strong_total = a.restarts_total if a.restarts_total > 0 else STRONG_TOTAL
+    first, R = ms.shard_total(rank, world, a.restarts_total) if a.restarts_total > 0 else ms.shard(rank, 4)
+    best, tour, dt, total, dt_max, R = stub_loop(first, R)
     per_rank = gather_rank_ms(dt / max(a.steps, 1) * 1e3, dev, dist if world > 1 else None)
+    # the second reading of the same line (VERDICT r03 item 6): configs[3] as worded — a fixed total dealt over the ranks
+    sf, sR = ms.shard_total(rank, world, strong_total)
+    _b2, _t2, _dt2, s_total, s_dt_max, _ = stub_loop(sf, sR)
     cost, restart = ms.unpack_key(best.item())
     ok = tour.tolist() == torch.roll(torch.arange(n, dtype=torch.int32), int(restart)).tolist()
     if world > 1:
@@ -296,7 +395,11 @@ def dry_launch(a, rank, world):
                           "ms_per_step_per_rank": per_rank, "higher_is_better": True, "dry_launch": True,
                           "scaling": "strong" if a.restarts_total > 0 else "weak", "vs_baseline": None, "dtype": "f32",
                           "data": "stub", "config": {"workload": "dry launch: gloo ranks, stub step (no GPU, no kernel, no oracle) — not a measurement"},
-                          "stub_units_all_ranks": total, "best_restart": restart, "launcher": "torch.distributed.run" if world > 1 else "none"}))
+                          "stub_units_all_ranks": total, "best_restart": restart, "launcher": "torch.distributed.run" if world > 1 else "none",
+                          "weak_per_gpu": {"ms_per_step": dt_max / max(a.steps, 1) * 1e3, "value": None, "restarts_per_rank": R},
+                          f"strong_{strong_total}_total": {"ms_per_step": s_dt_max / max(a.steps, 1) * 1e3, "value": None, "restarts_per_rank": sR,
+                                                           "stub_units_all_ranks": s_total},
+                          "scaling_note": SCALING_NOTE}))
 
 
 def single_process(a):
@@ -385,34 +488,11 @@ def main():
     lib, h = ctx.lib, ctx.handle
 
     d_xy = torch.from_numpy(xy).to(dev)
-    d_pos = torch.empty((R, n), dtype=torch.int32, device=dev)
-    d_cost = torch.empty(R, dtype=torch.float32, device=dev)
-    d_stats = torch.zeros((R, _capi.TL_DEV_STATS_STRIDE), dtype=torch.int64, device=dev)
     per_sweep = (n - 3) * (n - 2) // 2
     # Everything of a step is enqueued on ONE explicit stream: the descent kernel (through the C ABI), the key packing
     # and the collective.  (A NULL stream would mean the context's own non-blocking stream, unordered with torch's.)
     stream = torch.cuda.Stream(device=dev)
-    sweeps_dev = torch.zeros((), dtype=torch.int64, device=dev)
     stream.wait_stream(torch.cuda.current_stream())
-
-    best_tour = [None]
-
-    def step(count_it=False, events=None):
-        with torch.cuda.stream(stream):
-            if events is not None:
-                events[0].record(stream)
-            ctx.check(lib.tl_two_opt_batch_dev(h, d_xy.data_ptr(), n, None, a.seed, first, R, _capi.TL_MODE_REF_ORDER,
-                                               d_pos.data_ptr(), d_cost.data_ptr(), d_stats.data_ptr(),
-                                               C.c_void_p(stream.cuda_stream)))
-            if events is not None:
-                events[1].record(stream)
-            if count_it:
-                sweeps_dev.add_(d_stats[:, 0].sum())
-            # RCCL over xGMI: one 8-byte min-all-reduce per round, then the winner's tour (n x 4 B) to every rank
-            keys = TA.multistart.pack_keys(d_cost, first)
-            best = TA.multistart.allreduce_best(keys, dist)
-            best_tour[0] = TA.multistart.share_best_tour(keys, d_pos, best, dist)
-            return best
 
     def sync():
         torch.cuda.synchronize()
@@ -423,20 +503,52 @@ def main():
     if dist is not None:  # RCCL communicator set-up (lazy on the first collective) is not part of any timed step
         with torch.cuda.stream(stream):
             dist.all_reduce(torch.zeros(1, dtype=torch.int64, device=dev), op=dist.ReduceOp.MIN)
-    for _ in range(max(a.warmup, 0)):
-        step(count_it=True)
-    sync()
-    sweeps_dev.zero_()
-    sync()
-    # HIP events around every launch, on the stream the kernel is launched on
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-    t0 = time.perf_counter()
-    for k in range(a.steps):
-        key = step(count_it=True, events=evs[k])
-    sync()
-    dt = time.perf_counter() - t0
-    kernel_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
-    cands = int(sweeps_dev.item()) * per_sweep
+
+    def timed_loop(first, R, steps, warmup):
+        """warmup untimed + exactly `steps` timed steps of restarts [first, first + R) on this rank, bracketed by barrier +
+        synchronize on both sides.  A rank without restarts (strong reading, more ranks than restarts) still takes part in
+        every collective."""
+        d_pos = torch.empty((max(R, 1), n), dtype=torch.int32, device=dev)
+        d_cost = torch.full((max(R, 1),), float("inf"), dtype=torch.float32, device=dev)
+        d_stats = torch.zeros((max(R, 1), _capi.TL_DEV_STATS_STRIDE), dtype=torch.int64, device=dev)
+        sweeps_dev = torch.zeros((), dtype=torch.int64, device=dev)
+        best_tour = [None]
+
+        def step(events=None):
+            with torch.cuda.stream(stream):
+                if events is not None:
+                    events[0].record(stream)
+                if R:
+                    ctx.check(lib.tl_two_opt_batch_dev(h, d_xy.data_ptr(), n, None, a.seed, first, R, _capi.TL_MODE_REF_ORDER,
+                                                       d_pos.data_ptr(), d_cost.data_ptr(), d_stats.data_ptr(),
+                                                       C.c_void_p(stream.cuda_stream)))
+                if events is not None:
+                    events[1].record(stream)
+                sweeps_dev.add_(d_stats[:, 0].sum())
+                # RCCL over xGMI: one 8-byte min-all-reduce per round, then the winner's tour (n x 4 B) to every rank
+                keys = TA.multistart.pack_keys(d_cost, first)
+                best = TA.multistart.allreduce_best(keys, dist)
+                best_tour[0] = TA.multistart.share_best_tour(keys, d_pos, best, dist)
+                return best
+
+        for _ in range(max(warmup, 0)):
+            step()
+        sync()
+        sweeps_dev.zero_()
+        sync()
+        # HIP events around every launch, on the stream the kernel is launched on
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for k in range(steps):
+            key = step(events=evs[k])
+        sync()
+        dt = time.perf_counter() - t0
+        return {"dt": dt, "kernel_ms": [e0.elapsed_time(e1) for e0, e1 in evs], "cands": int(sweeps_dev.item()) * per_sweep, "key": key,
+                "d_pos": d_pos, "d_cost": d_cost, "d_stats": d_stats, "best_tour": best_tour[0], "R": R, "first": first}
+
+    L = timed_loop(first, R, a.steps, a.warmup)
+    dt, kernel_ms, cands, key = L["dt"], L["kernel_ms"], L["cands"], L["key"]
+    d_pos, d_cost, d_stats, best_tour = L["d_pos"], L["d_cost"], L["d_stats"], [L["best_tour"]]
     st_host = d_stats.cpu().numpy().astype(np.uint64)       # the last launch (every launch does the same work)
     cost_host = d_cost.cpu().numpy()
     # The clock the CUs held: st[9] shader clocks over st[10] ticks of the constant 100 MHz reference, per descent.
@@ -465,6 +577,22 @@ def main():
         raise SystemExit(f"bench.py: --gpus {a.gpus} but the process group has {ranks_seen} ranks")
     per_rank_ms = gather_rank_ms(dt / a.steps * 1e3, dev, dist)
     best_cost, best_restart = TA.multistart.unpack_key(key.item())
+    # The other reading of configs[3], in the same line: a FIXED total of restarts dealt over the ranks (strong scaling).  At one
+    # GPU with the default 256 per GPU it is the timed loop above, word for word; otherwise a second timed loop of the same K steps.
+    weak_obj = strong_obj = None
+    if not strong:
+        weak_obj = {"ms_per_step": dt_max / a.steps * 1e3, "value": total / dt_max, "restarts_per_rank": R}
+        if world == 1 and R == STRONG_TOTAL:
+            strong_obj = dict(weak_obj, note="one GPU: the same batch as the headline loop (not run twice)")
+        else:
+            sf, sR = TA.multistart.shard_total(rank, world, STRONG_TOTAL)
+            S = timed_loop(sf, sR, a.steps, min(a.warmup, 1))
+            s_total, s_dt_max = TA.multistart.aggregate_throughput(S["cands"], S["dt"], dev, dist)
+            skey_cost, skey_restart = TA.multistart.unpack_key(S["key"].item())
+            strong_obj = {"ms_per_step": s_dt_max / a.steps * 1e3, "value": s_total / s_dt_max, "restarts_per_rank": sR,
+                          "final_tour_cost": skey_cost, "best_restart": skey_restart}
+    else:
+        strong_obj = {"ms_per_step": dt_max / a.steps * 1e3, "value": total / dt_max, "restarts_per_rank": R}
 
     if rank != 0:
         if dist is not None:
@@ -494,6 +622,9 @@ def main():
                    "n": n, "restarts_per_gpu": R, "restarts_total": a.restarts_total if strong else R * world, "mode": "REF_ORDER",
                    "restart_seed": a.seed, "collective": "RCCL min-all-reduce of (cost_bits<<32|restart) per step + SUM-all-reduce of the winner's tour (n x 4 B)" if world > 1 else "none (1 GPU)"},
         "final_tour_cost": best_cost, "best_restart": best_restart,
+        "weak_per_gpu": weak_obj,
+        f"strong_{a.restarts_total if strong else STRONG_TOTAL}_total": strong_obj,
+        "scaling_note": SCALING_NOTE,
         "candidates_per_step_per_gpu": cand_per_launch,
         "descents_not_converged": status_bad,
         "device": info,
@@ -509,6 +640,8 @@ def main():
                 "`value` counts candidates as the reference's loop visits them (SURVEY.md §8(d)), L0 decides most of "
                 "them a tile at a time",
     }
+    out["value_l1_evaluated"] = {"value": out["candidates_touched"]["l1_candidates_per_s"], "unit": "candidates/s",
+                                 "note": "candidates whose own squared-distance test (L1) ran, per second of kernel time — what is left after the tile bound L0"}
     out["roofline"] = valu_roofline(n, R, a.seed, first, info, k_ms, clock_hz, work, cand_per_launch, a.steps)
     if world == 1 and not a.no_extras:
         extras = {}
@@ -545,14 +678,38 @@ def main():
                                                  "moves": sol_g.stats["moves"], "sweeps": sol_g.stats["sweeps"],
                                                  "note": "BASELINE configs[2]: one REF_ORDER descent from the NN seed on ONE CU; expected cost 77647.55469"}
             sol_b = TA.two_opt.solve(prob, None, None, rc_nn.route(), ctx=ctx, mode=TA.TL_MODE_BEST_SWEEP)
+            bs_us = sol_b.stats["kernel_ms"] * 1e3 / max(sol_b.stats["sweeps"], 1)
             extras["best_sweep_nn_start"] = {"candidates_per_s": sol_b.stats["candidates"] / (sol_b.stats["kernel_ms"] * 1e-3),
                                              "kernel_ms": sol_b.stats["kernel_ms"], "cost": float(sol_b.total), "sweeps": sol_b.stats["sweeps"],
-                                             "note": "TL_MODE_BEST_SWEEP (own mode, whole chip per sweep), single descent"}
+                                             "us_per_sweep": bs_us,
+                                             "note": "TL_MODE_BEST_SWEEP (own mode, whole chip per sweep), single descent; a sweep = k_bs_scan + k_bs_apply",
+                                             # measured: the VALU instructions of one sweep's two kernels (PMC pass, per-launch means) over the live time per sweep
+                                             "roofline": scan_valu_roofline("k_bs_scan", n, bs_us * 1e-3, info, clock_hz, also=("k_bs_apply",)),
+                                             # modelled, NOT a counter: what a sweep cannot go below as two dependent launches
+                                             "latency_model": {"floor_us_per_sweep": 2 * 1.45, "frac": 2 * 1.45 / bs_us,
+                                                               "source": "MI355X_MICROARCH.md price list, row `boundary`: 1.45 us between two dependent trivial kernels; "
+                                                                         "a sweep is k_bs_scan -> k_bs_apply -> next k_bs_scan"}}
+            if not a.no_cpu_baseline:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import _oracle as O
+                nn_pos = np.asarray([int(v) for v in rc_nn.route()], dtype=np.uint32)
+                cap_moves = 40  # bounded sample: ~50 M candidates per sweep on one core
+                t0c = time.perf_counter()
+                _rc, _p, _c, st_b = O.two_opt(xy, None, n, init=nn_pos, best=True, max_moves=cap_moves)
+                wc = time.perf_counter() - t0c
+                extras["best_sweep_nn_start"]["cpu_baseline"] = {
+                    "value": st_b["candidates"] / wc, "unit": "candidates/s", "cores": 1, "kind": "port",
+                    "sample": f"the first {st_b['sweeps']} sweeps ({st_b['moves']} moves) of the same BEST_SWEEP descent (NN start, n = {n}) by the "
+                              f"oracle's tlo_two_opt_best on one core; wall {wc:.1f} s"}
             with TA.Context(local, TA.TL_FLAG_NO_PRUNE) as c2:
+                s2 = TA.two_opt.multistart(prob, R, seed=a.seed, first=0, ctx=c2)
                 s2 = TA.two_opt.multistart(prob, R, seed=a.seed, first=0, ctx=c2)
                 extras["no_prune_multistart"] = {"candidates_per_s": s2.stats["candidates"] / (s2.stats["kernel_ms"] * 1e-3),
                                                  "kernel_ms": s2.stats["kernel_ms"], "best_cost": float(s2.total),
-                                                 "note": "TL_FLAG_NO_PRUNE: every candidate decided with two fresh correctly rounded sqrt"}
+                                                 "note": "TL_FLAG_NO_PRUNE: every candidate decided with two fresh correctly rounded sqrt — the like-for-like "
+                                                         "rate against a CPU loop that evaluates every candidate (the top-level cpu_baseline does)",
+                                                 "roofline": scan_valu_roofline("k_two_opt_ref_lds_no_prune", n, s2.stats["kernel_ms"], info, clock_hz)}
+                assert np.float32(s2.total).tobytes() == np.float32(best_cost).tobytes() or first != 0, "NO_PRUNE gave another best tour"
             for _ in range(3):  # warm-up: workspace allocation and first touch of its 200 MB, and the clock after the batches above
                 dm, ms = TA.distance_matrix.build(np.arange(n), xy, ctx=ctx, return_ms=True)
             dm_ms = []
@@ -675,11 +832,12 @@ def main():
             extras["lin_kernighan_n13509_20_epochs"] = {"kernel_ms": lk_ms, "total_ms": slk.stats["total_ms"], "cost": float(slk.total),
                                                         "instance": label13, "scans": lk_rounds, "moves": lk_moves, "moves_per_s": lk_moves / (lk_ms * 1e-3),
                                                         "us_per_round": lk_ms * 1e3 / max(lk_rounds, 1),
-                                                        "roofline": {"bound": "dependent_latency", "achieved": lk_rounds / (lk_ms * 1e-3), "peak": 1e6 / lk_floor_us,
-                                                                     "unit": "rounds/s", "frac": lk_floor_us / (lk_ms * 1e3 / max(lk_rounds, 1)), "traffic": None,
-                                                                     "kernel": "k_lk_scan_sub + k_lk_control per round",
-                                                                     "formula": "peak = 1 / (2 x 1.45 us kernel boundary + 15 dependent L2 look-ups x 200 cycles / clock)",
-                                                                     "pmc": (json.load(open(latest_profile("r*_scans_pmc.json"))).get("k_lk_scan_sub") if latest_profile("r*_scans_pmc.json") else None)},
+                                                        # measured: VALU instructions of a round's kernels (PMC pass, per-launch means over the same run) over the live time per round
+                                                        "roofline": scan_valu_roofline("k_lk_scan_sub", n13, lk_ms / max(lk_rounds, 1), info, clock_hz, also=("k_lk_control",)),
+                                                        # modelled, NOT a counter: the chain of dependent latencies a round cannot go below
+                                                        "latency_model": {"bound": "dependent_latency", "floor_us_per_round": lk_floor_us, "frac": lk_floor_us / (lk_ms * 1e3 / max(lk_rounds, 1)),
+                                                                          "formula": "floor = 2 x 1.45 us kernel boundary + 15 dependent L2 look-ups x 200 cycles / live clock",
+                                                                          "source": "constants from MI355X_MICROARCH.md (price list row `boundary`; L2 hit latency), not from a counter of this run"},
                                                         "note": "tl_lk incl. NN seed and k-NN lists; the same run is a golden-checked -m gpu test (tests/test_gpu_full_size.py)"}
             if not a.no_cpu_baseline:
                 # CPU side of the same workload, bounded: ONE ILS epoch — a double-bridge kick of the GPU run's final tour, then the
@@ -695,7 +853,15 @@ def main():
                     "sample": f"one ILS epoch at n = {n13}: double-bridge kick of the GPU run's final tour, then the oracle's lk_pass to the next local optimum ({st_lk['moves']} moves, {st_lk['sweeps']} find_lk_move scans) on one core; wall {wc:.1f} s"}
         except Exception as exc:
             extras["error"] = repr(exc)
+        try:
+            extras["drop_in_end_to_end"] = drop_in_end_to_end(TA, not a.no_cpu_baseline)
+        except Exception as exc:
+            extras["drop_in_end_to_end"] = {"error": repr(exc)}
         out["extras"] = extras
+        if "no_prune_multistart" in extras and "candidates_per_s" in extras["no_prune_multistart"]:
+            # `value` counts candidates DECIDED (82 % of them a tile at a time by the exact L0 bound); the two like-for-like rates beside it:
+            out["value_every_candidate_exact"] = {"value": extras["no_prune_multistart"]["candidates_per_s"], "unit": "candidates/s",
+                                                  "note": "TL_FLAG_NO_PRUNE: every candidate evaluated with the reference's own arithmetic (4 correctly rounded sqrt), same tours"}
         if "multistart_two_descents_per_cu" in extras:  # the same kernel with a batch of 2 x CUs restarts (two descents per CU), for the record
             out["value_with_two_descents_per_cu"] = {"value": extras["multistart_two_descents_per_cu"]["candidates_per_s"], "unit": "candidates/s",
                                                      "restarts_per_gpu": extras["multistart_two_descents_per_cu"]["restarts"]}
@@ -709,6 +875,8 @@ def main():
                 j = k - first
                 if np.float32(cost_host[j]).tobytes() != np.float32(c).tobytes() or int(st_host[j, 0]) != sw or int(st_host[j, 1]) != mv:
                     bad.append((k, float(cost_host[j]), float(c), int(st_host[j, 0]), sw, int(st_host[j, 1]), mv))
+        if "extras" in out and isinstance(out["extras"].get("no_prune_multistart"), dict):
+            out["extras"]["no_prune_multistart"]["cpu_baseline"] = dict(out["cpu_baseline"], note="the top-level cpu_baseline: the oracle evaluates every candidate exactly, like this kernel form")
         out["parity_checked_restarts"] = sum(1 for k in range(len(res)) if first <= k < first + R)
         out["parity_mismatches"] = bad
         if bad:

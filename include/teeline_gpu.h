@@ -21,8 +21,13 @@
  *    NULL means EUC_2D computed on the fly from xy with the reference's exact f32 arithmetic
  *    (sqrtf(dx*dx+dy*dy), no FMA; kdtree.rs:291-295).
  *  - All host pointers are borrowed for the duration of the call only.  A tl_ctx is single-threaded;
- *    distinct contexts are independent (own HIP stream and workspace) — the reference calls solvers
- *    from arbitrary threads (teeline-api tsp_service.rs:295,328), so create one context per thread.
+ *    distinct contexts are independent (own HIP stream, event pair and workspace; the library's only
+ *    shared mutable state is a mutex-guarded set) — the reference calls solvers from arbitrary threads
+ *    (teeline-api tsp_service.rs:295,328, teeline-qt solver_engine.rs:412-432), so create one context per
+ *    thread; any number of threads may be inside the library at once, each with its own context
+ *    (tests/test_gpu_threads.py).  Two threads on ONE context do not race: the second to arrive gets
+ *    TL_ERR_BUSY back at once from every entry point that takes the context.  (tl_destroy on a context
+ *    another thread is using is undefined, as free() of a buffer in use is.)
  *  - Return value: TL_OK (0) or a negative tl_status; tl_last_error(ctx) has the message.
  *  - There is NO CPU fallback: every compute entry point fails with TL_ERR_NO_DEVICE / TL_ERR_HIP when
  *    no gfx950 device is usable.
@@ -37,7 +42,7 @@
 extern "C" {
 #endif
 
-#define TL_ABI_VERSION 4
+#define TL_ABI_VERSION 5
 
 typedef struct tl_ctx tl_ctx;
 
@@ -50,7 +55,9 @@ typedef enum tl_status {
     TL_ERR_HIP = -4,         /* a HIP runtime call failed                                              */
     TL_ERR_NOMEM = -5,       /* device or host allocation failed                                       */
     TL_ERR_UNSUPPORTED = -6, /* size/mode combination this build cannot run                            */
-    TL_ERR_NO_CONVERGE = -7  /* safety cap on sweeps hit (the reference would still be looping)        */
+    TL_ERR_NO_CONVERGE = -7, /* safety cap on sweeps hit (the reference would still be looping)        */
+    TL_ERR_BUSY = -8         /* another host thread is inside an entry point with this context (ABI v5);  */
+                             /* nothing was touched, tl_last_error(ctx) is NOT updated (it is that thread's) */
 } tl_status;
 
 /* 2-opt evaluation order */
@@ -231,7 +238,8 @@ int tl_or_opt_trace(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_pa
 /* tl_lk_trace — lin_kernighan.rs:71,90 sends PathUpdate(best_tour, best_dist) after the first lk_pass and after every epoch that
  * improves on it (no Done).  snap_pos holds those tours (snap_cap x n positions, in order), snap_dist their best_dist (the
  * Euclidean tour_distance of :118-122, whatever problem.distances holds); *snap_len counts them all, the buffers hold the first
- * snap_cap.  n < 4: none (:57-59).  Not with TL_FLAG_LK_ONE_WORKGROUP (TL_ERR_UNSUPPORTED). */
+ * snap_cap.  n < 4: none (:57-59).  With TL_FLAG_LK_ONE_WORKGROUP (a cross-check form that keeps no snapshots on the device) the
+ * list is the reference's LAST message alone: the final best tour and its best_dist (*snap_len = 1). */
 int tl_lk_trace(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
                 const tl_lk_opts *opts, uint64_t seed, uint32_t *out_pos, float *out_cost, tl_stats *stats,
                 uint32_t *snap_pos, float *snap_dist, uint32_t snap_cap, uint32_t *snap_len);

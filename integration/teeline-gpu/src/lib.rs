@@ -1,4 +1,4 @@
-//! teeline-gpu — safe Rust binding of `libteeline_gpu.so` (C ABI declared in `include/teeline_gpu.h`, ABI version 2).
+//! teeline-gpu — safe Rust binding of `libteeline_gpu.so` (C ABI declared in `include/teeline_gpu.h`, ABI version 5).
 //!
 //! The library is the MI355X (gfx950) engine that replaces the bodies of
 //!   `two_opt::solve`        (src/tsp/two_opt.rs:7-67)
@@ -20,7 +20,7 @@ use std::ffi::{c_char, c_int, CStr};
 use std::fmt;
 use std::ptr;
 
-pub const TL_ABI_VERSION: c_int = 4;
+pub const TL_ABI_VERSION: c_int = 5;
 
 #[repr(C)]
 pub struct TlCtx {
@@ -99,6 +99,8 @@ pub enum Code {
     NoMem,
     Unsupported,
     NoConverge,
+    /// Another thread is inside a call with the same context (`with_context` keeps one per thread, so this crate never sees it).
+    Busy,
     Other(i32),
 }
 
@@ -112,6 +114,7 @@ impl Code {
             -5 => Code::NoMem,
             -6 => Code::Unsupported,
             -7 => Code::NoConverge,
+            -8 => Code::Busy,
             x => Code::Other(x),
         }
     }
@@ -169,6 +172,10 @@ impl Context {
     fn check(&self, rc: c_int) -> Result<(), Error> {
         if rc == 0 {
             return Ok(());
+        }
+        if rc == -8 {
+            // TL_ERR_BUSY: the context's error string belongs to the thread that is inside the library; it is not read
+            return Err(Error { code: Code::Busy, message: "the context is in use by another thread".to_string() });
         }
         // SAFETY: tl_last_error returns a NUL-terminated string owned by the context.
         let msg = unsafe { CStr::from_ptr(tl_last_error(self.raw)).to_string_lossy().into_owned() };

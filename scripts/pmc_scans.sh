@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of the scan kernels bench.py's extras report (3-opt scan n = 1002, Or-opt scan n = 5000, LK n = 13 509): one rocprofv3
+# SQ counters of the scan kernels bench.py's extras report (3-opt scan n = 1002, Or-opt scan n = 5000, LK n = 13 509, a BEST_SWEEP descent and the NO_PRUNE batch at n = 10^4): one rocprofv3
 # --pmc pass each (+ --kernel-trace only), summarised into gpurun_out/<round>/scans_pmc.json (copy it to profiles/<round>_scans_pmc.json).
 #   bash scripts/pmc_scans.sh r03
 R=${1:-r03}
@@ -9,7 +9,9 @@ REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
 CNT="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CU_CYCLES SQ_WAVES"
 timeout -k 10 200 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $OUT/scans -- python3 $REPO/scripts/scan_once.py scans > $OUT/scans.log 2>&1 \
-&& timeout -k 10 300 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $OUT/lk -- python3 $REPO/scripts/scan_once.py lk > $OUT/lk.log 2>&1
+&& timeout -k 10 300 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $OUT/lk -- python3 $REPO/scripts/scan_once.py lk > $OUT/lk.log 2>&1 \
+&& timeout -k 10 200 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $OUT/best -- python3 $REPO/scripts/scan_once.py best > $OUT/best.log 2>&1 \
+&& timeout -k 10 200 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $OUT/noprune -- python3 $REPO/scripts/scan_once.py noprune > $OUT/noprune.log 2>&1
 python3 - $OUT $OUT/../scans_pmc.json <<'PY'
 import csv, glob, json, sys, collections
 out = {}
@@ -43,8 +45,26 @@ for key in ("k_lk_scan_sub", "k_lk_control"):
     for r in sel: tot[r["Counter_Name"]] += float(r["Counter_Value"])
     for k, v in tot.items(): e[k] = v / len(ids)
     out[key] = e
+rows, tr = load("best"), trace("best")
+for key in ("k_bs_scan", "k_bs_apply"):
+    sel = [r for r in rows if key in r["Kernel_Name"]]
+    if not sel: continue
+    ids = sorted({int(r["Dispatch_Id"]) for r in sel})
+    e = {"n": 10000, "launches": len(ids), "kernel_ms_profiled_mean": sum(tr.get(str(i), 0.0) for i in ids) / len(ids), "note": "per-launch means over the descent (one launch per sweep)"}
+    tot = collections.Counter()
+    for r in sel: tot[r["Counter_Name"]] += float(r["Counter_Value"])
+    for k, v in tot.items(): e[k] = v / len(ids)
+    out[key] = e
+rows, tr = load("noprune"), trace("noprune")
+sel = [r for r in rows if "k_two_opt_ref_lds" in r["Kernel_Name"]]
+if sel:
+    last = max(int(r["Dispatch_Id"]) for r in sel)
+    e = {"n": 10000, "restarts": 256, "seed": 12345, "dispatch": last, "kernel_ms_profiled": tr.get(str(last)), "kernel_name": [r["Kernel_Name"] for r in sel if int(r["Dispatch_Id"]) == last][0]}
+    for r in sel:
+        if int(r["Dispatch_Id"]) == last: e[r["Counter_Name"]] = e.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    out["k_two_opt_ref_lds_no_prune"] = e
 out["source"] = "rocprofv3 --pmc SQ_* --kernel-trace on scripts/scan_once.py (scripts/pmc_scans.sh); summed over the dispatch; the scan kernels: second launch"
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])
 PY
-tail -n 3 $OUT/scans.log; tail -n 3 $OUT/lk.log
+tail -n 3 $OUT/scans.log; tail -n 3 $OUT/lk.log; tail -n 2 $OUT/best.log; tail -n 2 $OUT/noprune.log

@@ -13,7 +13,7 @@ TL_DEV_STATS_STRIDE = 16
 
 TL_OK = 0
 TL_ERR_BADARG, TL_ERR_REF_PANICS, TL_ERR_NO_DEVICE, TL_ERR_HIP = -1, -2, -3, -4
-TL_ERR_NOMEM, TL_ERR_UNSUPPORTED, TL_ERR_NO_CONVERGE = -5, -6, -7
+TL_ERR_NOMEM, TL_ERR_UNSUPPORTED, TL_ERR_NO_CONVERGE, TL_ERR_BUSY = -5, -6, -7, -8
 TL_MODE_REF_ORDER, TL_MODE_BEST_SWEEP = 0, 1
 TL_FLAG_NONE, TL_FLAG_NO_PRUNE = 0, 1
 # alternative kernel forms (identical results; cross-checks of each other)

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libteeline_gpu.so")
 
-SOURCES = ["tl_api.hip", "two_opt_ref.hip", "two_opt_dm.hip", "dm_build.hip", "three_opt.hip", "lk.hip", "two_opt_best.hip", "or_opt.hip", "two_opt_large.hip", "kdtree.hip"]
+SOURCES = ["tl_api.hip", "two_opt_ref.hip", "two_opt_dm.hip", "dm_build.hip", "three_opt.hip", "lk.hip", "lk_deep.hip", "nn_knn.hip", "two_opt_best.hip", "or_opt.hip", "two_opt_large.hip", "kdtree.hip"]
 HEADERS = ["tl_device.h", "tl_kernels.h", "two_opt_common.h", os.path.join(ROOT, "include", "teeline_gpu.h")]
 
 # -ffp-contract=off: the reference never fuses mul+add (src/tsp/kdtree.rs:291-295); bit-exact parity
@@ -66,8 +66,99 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
         if verbose:
             print(" ".join(link), file=sys.stderr)
         subprocess.check_call(link)
+    bad = verify_ds_min_waits(LIB_OUT + ".tmp")
+    if bad:
+        raise RuntimeError("ds_min_u32 reaches an s_barrier without `s_waitcnt lgkmcnt(0)` in: " + ", ".join(f"{k} @ {a}" for k, a in bad[:8]))
     os.replace(LIB_OUT + ".tmp", LIB_OUT)
     return LIB_OUT
+
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def verify_ds_min_waits(lib=None):
+    """Build-time check of the linked library's gfx950 code: on every control-flow path from a `ds_min_u32` to the next
+    `s_barrier` there is an `s_waitcnt` that drains lgkmcnt to 0.  The hit keys of the 2-opt kernels are posted with an inline-asm
+    ds_min_u32 (csrc/tl_device.h lds_min_u32), which the compiler's wait insertion does not count; the barrier behind the post is
+    only safe if a tracked LDS operation (or the explicit wait of lds_min_u32_fenced) sits in between.  Returns the list of
+    offending (kernel, address) pairs — empty = good; raises if the disassembler is missing."""
+    import re
+    import tempfile
+    lib = lib or LIB
+    if not os.path.exists(OBJDUMP):
+        raise RuntimeError(f"{OBJDUMP} not found: cannot check the ds_min_u32 -> s_barrier waits")
+    bad = []
+    with tempfile.TemporaryDirectory(prefix="teeline_gpu_asm_") as tmp:
+        local = os.path.join(tmp, os.path.basename(lib))
+        shutil.copy(lib, local)
+        subprocess.check_call([OBJDUMP, "--offloading", local], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=tmp)
+        for name in sorted(os.listdir(tmp)):
+            if "gfx950" not in name:
+                continue
+            text = subprocess.check_output([OBJDUMP, "-d", os.path.join(tmp, name)], text=True)
+            if "ds_min_u32" not in text:
+                continue
+            bad += _check_ds_min_paths(text, re)
+    return bad
+
+
+def _check_ds_min_paths(text, re):
+    sym_re = re.compile(r"^([0-9a-f]+) <([^>]+)>:")
+    ins_re = re.compile(r"^\s+(\S+)(.*?)//\s*([0-9A-Fa-f]+):")
+    tgt_re = re.compile(r"<([^>+]+)\+0x([0-9a-f]+)>\s*$")
+    syms, ins = {}, []  # symbol -> start address; (addr, mnemonic, operands, target address or None, kernel)
+    cur = None
+    for line in text.splitlines():
+        m = sym_re.match(line)
+        if m:
+            cur = m.group(2)
+            syms[cur] = int(m.group(1), 16)
+            continue
+        m = ins_re.match(line)
+        if not m:
+            continue
+        tgt = None
+        t = tgt_re.search(line)
+        if t and m.group(1).startswith(("s_branch", "s_cbranch")):
+            tgt = syms.get(t.group(1), None)
+            tgt = None if tgt is None else tgt + int(t.group(2), 16)
+        ins.append((int(m.group(3), 16), m.group(1), m.group(2), tgt, cur))
+    at = {a: k for k, (a, *_rest) in enumerate(ins)}
+    bad = []
+    for k0, (a0, mn0, _o, _t, kern) in enumerate(ins):
+        if mn0 != "ds_min_u32":
+            continue
+        seen, stack, ok = set(), [k0 + 1], True
+        while stack and ok:
+            k = stack.pop()
+            while k < len(ins) and k not in seen:
+                seen.add(k)
+                _a, mn, ops, tgt, _k = ins[k]
+                if mn == "s_waitcnt" and ("lgkmcnt(0)" in ops or ops.strip().startswith("0")):
+                    break  # drained on this path
+                if mn == "s_barrier":
+                    ok = False
+                    break
+                if mn in ("s_endpgm",):
+                    break
+                if mn in ("s_setpc_b64", "s_swappc_b64"):
+                    ok = False  # an indirect jump: not followed, so not proven
+                    break
+                if mn.startswith("s_cbranch"):
+                    if tgt not in at:
+                        ok = False  # a target this parser could not resolve: not proven
+                        break
+                    stack.append(at[tgt])
+                elif mn == "s_branch":
+                    if tgt in at:
+                        stack.append(at[tgt])
+                    else:
+                        ok = False
+                    break
+                k += 1
+        if not ok:
+            bad.append((kern, hex(a0)))
+    return bad
 
 
 JITTER_LIB = os.path.join(HERE, "libteeline_gpu_jitter.so")

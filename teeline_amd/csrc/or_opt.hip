@@ -8,9 +8,9 @@
 //
 // Best-improvement, so one pass is a whole-chip scan: a wave takes 8 consecutive segment starts x a slab of insertion
 // points (lanes along j) and shares the distances between the five placement kinds and the 8 starts (k_or_scan), every
-// f32 expression associated exactly as the reference writes it; argmin by a packed 64-bit key
-// (~delta_bits << 32 | loop-order index) reduced per wave, per workgroup, then by k_or_pick, which also applies the
-// relocation in place.  Exact distances (correctly rounded sqrt); roofline: VALU.
+// f32 expression associated exactly as the reference writes it; argmin by a packed 96-bit key
+// (~delta_bits << 64 | loop-order index; the index 6 n^2 needs more than 32 bits from n = 26 755 on — round 4) reduced per wave,
+// per workgroup, then by k_or_pick, which also applies the relocation in place.  Exact distances (correctly rounded sqrt); roofline: VALU.
 #include "tl_kernels.h"
 
 #pragma clang fp contract(off)
@@ -23,15 +23,19 @@ constexpr int kOrWaves = 4;
 constexpr int kOrIR = 8;          // consecutive segment starts served from one set of distance registers
 constexpr uint32_t kOrTargetWaves = 4096;  // waves a scan should at least consist of: small tours take fewer 63-wide chunks of
                                            // insertion points per wave (or_opt_chunks)
+typedef unsigned __int128 key_t;  // (~delta bits) << 64 | loop-order index
 constexpr unsigned long long kNoKey64 = ~0ULL;
+__device__ __forceinline__ key_t make_key(unsigned long long hi, unsigned long long lo) { return ((key_t)hi << 64) | (key_t)lo; }
+__device__ __forceinline__ key_t no_key() { return make_key(kNoKey64, kNoKey64); }
 
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+__device__ __forceinline__ key_t wave_min_key(key_t v)
 {
     for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_down(v, off);
+        const unsigned long long oh = __shfl_down((unsigned long long)(v >> 64), off), ol = __shfl_down((unsigned long long)v, off);
+        const key_t o = make_key(oh, ol);
         v = o < v ? o : v;
     }
-    return __shfl(v, 0);
+    return make_key(__shfl((unsigned long long)(v >> 64), 0), __shfl((unsigned long long)v, 0));
 }
 
 static uint32_t or_opt_grid_x(uint32_t n) { return ((n + kOrIR - 1) / kOrIR + kOrWaves - 1) / kOrWaves; }
@@ -69,13 +73,13 @@ struct Dist {
 template <bool DM>
 __global__ __launch_bounds__(kOrWaves * 64) void k_or_scan(OrOptArgs A, uint32_t chunks)
 {
-    __shared__ unsigned long long s_key[kOrWaves];
+    __shared__ unsigned long long s_key[kOrWaves][2];
     const uint32_t n = A.n;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t i0 = (blockIdx.x * kOrWaves + (uint32_t)wave) * kOrIR;
     const uint32_t jlo = blockIdx.y * (chunks * 63u);
-    unsigned long long best = kNoKey64;
+    key_t best = no_key();
     float bestd = __builtin_inff();
     if (i0 < n) {
         const Dist<DM> D{A.Pt, A.dm, A.perm};
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(kOrWaves * 64) void k_or_scan(OrOptArgs A, uint32_t
                         const unsigned long long order = ((unsigned long long)((uint32_t)(len - 1) * n + i) * n + j) * 2ull + (unsigned long long)(q != 0 && (q & 1) == 0);
                         const float v = val[q];
                         if ((v < -1e-3f) & (v <= bestd)) {
-                            const unsigned long long key = ((unsigned long long)(~__builtin_bit_cast(uint32_t, v)) << 32) | order;
+                            const key_t key = make_key((unsigned long long)(~__builtin_bit_cast(uint32_t, v)), order);
                             if (key < best) {
                                 best = key;
                                 bestd = v;
@@ -148,13 +152,21 @@ __global__ __launch_bounds__(kOrWaves * 64) void k_or_scan(OrOptArgs A, uint32_t
             }
         }
     }
-    best = wave_min_u64(best);
-    if (lane == 0) s_key[wave] = best;
+    best = wave_min_key(best);
+    if (lane == 0) {
+        s_key[wave][0] = (unsigned long long)(best >> 64);
+        s_key[wave][1] = (unsigned long long)best;
+    }
     TL_SYNC();
     if (threadIdx.x == 0) {
-        unsigned long long k = s_key[0];
-        for (int w = 1; w < kOrWaves; ++w) k = s_key[w] < k ? s_key[w] : k;
-        A.partials[blockIdx.y * gridDim.x + blockIdx.x] = k;
+        key_t k = make_key(s_key[0][0], s_key[0][1]);
+        for (int w = 1; w < kOrWaves; ++w) {
+            const key_t o = make_key(s_key[w][0], s_key[w][1]);
+            k = o < k ? o : k;
+        }
+        unsigned long long *out = A.partials + 2u * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
+        out[0] = (unsigned long long)(k >> 64);
+        out[1] = (unsigned long long)k;
     }
 }
 
@@ -170,30 +182,38 @@ __global__ __launch_bounds__(256) void k_or_prepare(OrOptArgs A)
 }
 
 // reduce, publish the move and (optionally) apply_relocation (or_opt.rs:170-184)
-__global__ __launch_bounds__(1024) void k_or_pick(OrOptArgs A, uint32_t nblocks, int apply)
+__global__ __launch_bounds__(1024) void k_or_pick(OrOptArgs A, uint32_t nblocks, int apply, int stage_lds)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *old = reinterpret_cast<uint32_t *>(smem);  // n entries
-    __shared__ unsigned long long s_key[16];
+    // the pre-move tour: in LDS where n entries fit, else in the workspace (one workgroup: its own barrier orders the copy)
+    uint32_t *old = stage_lds ? reinterpret_cast<uint32_t *>(smem) : A.scratch;
+    __shared__ unsigned long long s_key[16][2];
     const uint32_t tid = threadIdx.x, n = A.n;
     const int lane = tid & 63, wave = tid >> 6;
-    unsigned long long best = kNoKey64;
+    key_t best = no_key();
     for (uint32_t b = tid; b < nblocks; b += 1024u) {
-        const unsigned long long k = A.partials[b];
+        const key_t k = make_key(A.partials[2u * (size_t)b], A.partials[2u * (size_t)b + 1u]);
         best = k < best ? k : best;
     }
-    best = wave_min_u64(best);
-    if (lane == 0) s_key[wave] = best;
+    best = wave_min_key(best);
+    if (lane == 0) {
+        s_key[wave][0] = (unsigned long long)(best >> 64);
+        s_key[wave][1] = (unsigned long long)best;
+    }
     TL_SYNC();
-    best = s_key[0];
-    for (int w = 1; w < 16; ++w) best = s_key[w] < best ? s_key[w] : best;
-    const bool found = best != kNoKey64;
-    const uint32_t order = (uint32_t)(best & 0xFFFFFFFFu);
-    const uint32_t reversed = order & 1u, j = (order >> 1) % n, row = (order >> 1) / n;
-    const uint32_t seg_len = row / n + 1u, i = row % n;
+    best = make_key(s_key[0][0], s_key[0][1]);
+    for (int w = 1; w < 16; ++w) {
+        const key_t o = make_key(s_key[w][0], s_key[w][1]);
+        best = o < best ? o : best;
+    }
+    const bool found = best != no_key();
+    const unsigned long long order = (unsigned long long)best;
+    const uint32_t reversed = (uint32_t)(order & 1ull), j = (uint32_t)((order >> 1) % n);
+    const unsigned long long row = (order >> 1) / n;
+    const uint32_t seg_len = (uint32_t)(row / n) + 1u, i = (uint32_t)(row % n);
     if (tid == 0) {
         A.best->found = found ? 1u : 0u;
-        A.best->delta_bits = ~(uint32_t)(best >> 32);
+        A.best->delta_bits = ~(uint32_t)(unsigned long long)(best >> 64);
         A.best->i = i;
         A.best->j = j;
         A.best->seg_len = seg_len;
@@ -217,7 +237,7 @@ __global__ __launch_bounds__(1024) void k_or_pick(OrOptArgs A, uint32_t nblocks,
     }
 }
 
-hipError_t launch_or_opt_pass(const OrOptArgs &A, bool dm, int apply, hipStream_t s)
+hipError_t launch_or_opt_pass(const OrOptArgs &A, bool dm, int apply, hipStream_t s, int lds_budget)
 {
     const uint32_t gx = or_opt_grid_x(A.n), gy = or_opt_grid_y(A.n), nblocks = gx * gy;
     const uint32_t pg = (A.n + 255u) / 256u;
@@ -230,7 +250,8 @@ hipError_t launch_or_opt_pass(const OrOptArgs &A, bool dm, int apply, hipStream_
     }
     hipError_t e = allow_max_lds(reinterpret_cast<const void *>(k_or_pick));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_or_pick, dim3(1), dim3(1024), (size_t)A.n * 4, s, A, nblocks, apply);
+    const bool stage_lds = (size_t)A.n * 4 + 1024 <= (size_t)lds_budget;
+    hipLaunchKernelGGL(k_or_pick, dim3(1), dim3(1024), stage_lds ? (size_t)A.n * 4 : 0, s, A, nblocks, apply, stage_lds ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -7,11 +7,15 @@
 #include "tl_kernels.h"
 
 #include <chrono>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace tl;
@@ -38,7 +42,43 @@ struct tl_ctx {
     DevBuf xy, dm, init, out_pos, out_cost, out_stats, misc, work, dmfull, kd, fx;
     uint32_t dm_n = 0;
     int dm_layout = -1;
+    // which host thread is inside an entry point with this context (default id: none) and how deep (entries call entries)
+    std::atomic<std::thread::id> owner{};
+    int depth = 0;
 };
+
+// A tl_ctx is single-threaded (include/teeline_gpu.h): its stream, event pair, workspace and error string belong to the call in
+// progress.  Every entry point that takes a context enters through this guard; a second host thread that arrives while another is
+// inside gets TL_ERR_BUSY back at once — nothing of the context is touched, not even its error string — instead of racing on
+// the workspace.  Re-entry by the owning thread (tl_lk -> tl_nearest_neighbor -> tl_tour_length ...) is counted.
+struct CtxUse {
+    tl_ctx *c;
+    bool ok = true;
+    explicit CtxUse(tl_ctx *c_) : c(c_)
+    {
+        if (!c) return;
+        const std::thread::id me = std::this_thread::get_id();
+        if (c->owner.load(std::memory_order_acquire) == me) {
+            ++c->depth;
+            return;
+        }
+        std::thread::id none{};
+        if (c->owner.compare_exchange_strong(none, me, std::memory_order_acq_rel)) {
+            c->depth = 1;
+            return;
+        }
+        ok = false;
+    }
+    ~CtxUse()
+    {
+        if (c && ok && --c->depth == 0) c->owner.store(std::thread::id(), std::memory_order_release);
+    }
+    CtxUse(const CtxUse &) = delete;
+    CtxUse &operator=(const CtxUse &) = delete;
+};
+#define TL_ENTER(c)      \
+    CtxUse tl_use_((c)); \
+    if (!tl_use_.ok) return TL_ERR_BUSY
 
 static thread_local std::string g_create_err;  // tl_last_error(NULL): the calling thread's last tl_create failure
 
@@ -61,9 +101,11 @@ static int fail(tl_ctx *c, int code, const char *fmt, ...)
 #define HIPCHK(c, expr)                                                                           \
     do {                                                                                          \
         hipError_t _e = (expr);                                                                   \
-        if (_e != hipSuccess)                                                                     \
+        if (_e != hipSuccess) {                                                                   \
+            (void)hipGetLastError(); /* the thread's sticky error: a later launch check must not report this one again */ \
             return fail((c), _e == hipErrorOutOfMemory ? TL_ERR_NOMEM : TL_ERR_HIP, "%s: %s", #expr, \
                         hipGetErrorString(_e));                                                   \
+        }                                                                                         \
     } while (0)
 
 static int ensure(tl_ctx *c, DevBuf &b, size_t bytes)
@@ -185,6 +227,7 @@ extern "C" uint32_t tl_two_opt_lds_max_n(const tl_ctx *c) { return c ? lds_max_n
 // ------------------------------------------------------------------------------------------------
 extern "C" int tl_last_kernel_ms(tl_ctx *c, double *ms)
 {
+    TL_ENTER(c);
     if (!c || !ms) return TL_ERR_BADARG;
     if (!c->ev_valid) return fail(c, TL_ERR_BADARG, "tl_last_kernel_ms: no kernel sequence recorded yet");
     HIPCHK(c, hipSetDevice(c->device));
@@ -197,6 +240,7 @@ extern "C" int tl_last_kernel_ms(tl_ctx *c, double *ms)
 
 extern "C" int tl_dm_build_dev(tl_ctx *c, const float *d_xy, uint32_t n, int dist, int layout, float *d_out, void *stream)
 {
+    TL_ENTER(c);
     if (!c || !d_xy || !d_out) return fail(c, TL_ERR_BADARG, "tl_dm_build_dev: NULL argument");
     if (n < 2) return fail(c, TL_ERR_BADARG, "distance matrix requires at least 2 points");  // distance_matrix.rs:124-126
     if ((dist != TL_DIST_EUC2D && dist != TL_DIST_GEO) || (layout != TL_DM_PACKED_LOWER && layout != TL_DM_FULL))
@@ -212,6 +256,7 @@ extern "C" int tl_dm_build_dev(tl_ctx *c, const float *d_xy, uint32_t n, int dis
 
 extern "C" int tl_selftest_sqrt(tl_ctx *c, uint32_t first_bits, uint64_t count, uint64_t *mismatches, uint32_t *first_bad_bits)
 {
+    TL_ENTER(c);
     if (!c || !mismatches) return fail(c, TL_ERR_BADARG, "tl_selftest_sqrt: NULL argument");
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
@@ -228,6 +273,7 @@ extern "C" int tl_selftest_sqrt(tl_ctx *c, uint32_t first_bits, uint64_t count, 
 
 extern "C" int tl_dm_build(tl_ctx *c, const float *xy, uint32_t n, int dist, int layout, float *out_host, double *kernel_ms)
 {
+    TL_ENTER(c);
     if (!c || !xy) return fail(c, TL_ERR_BADARG, "tl_dm_build: NULL argument");
     if (n < 2) return fail(c, TL_ERR_BADARG, "distance matrix requires at least 2 points");
     HIPCHK(c, hipSetDevice(c->device));
@@ -246,6 +292,7 @@ extern "C" int tl_dm_build(tl_ctx *c, const float *xy, uint32_t n, int dist, int
 
 extern "C" int tl_dm_is_euc2d(tl_ctx *c, const float *xy, const float *dm_packed, uint32_t n, int *is_euc2d)
 {
+    TL_ENTER(c);
     if (!c || !xy || !dm_packed || !is_euc2d) return fail(c, TL_ERR_BADARG, "tl_dm_is_euc2d: NULL argument");
     *is_euc2d = 1;
     if (n < 2) return TL_OK;
@@ -266,6 +313,7 @@ extern "C" int tl_dm_is_euc2d(tl_ctx *c, const float *xy, const float *dm_packed
 
 extern "C" int tl_tour_length(tl_ctx *c, const float *xy, const float *dm_packed, uint32_t n, const uint32_t *perm, float *out_cost)
 {
+    TL_ENTER(c);
     if (!c || (!xy && !dm_packed) || !perm || !out_cost) return fail(c, TL_ERR_BADARG, "tl_tour_length: NULL argument");
     if (n < 2) {  // distance_matrix.rs:236-238
         *out_cost = 0.0f;
@@ -375,6 +423,7 @@ extern "C" int tl_two_opt_batch_dev(tl_ctx *c, const float *d_xy, uint32_t n, co
                                     uint32_t first, uint32_t count, int mode, uint32_t *d_out_pos, float *d_out_cost,
                                     uint64_t *d_out_stats, void *stream)
 {
+    TL_ENTER(c);
     if (!c || !d_xy || !d_out_pos || !d_out_cost || !d_out_stats) return fail(c, TL_ERR_BADARG, "tl_two_opt_batch_dev: NULL argument");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
@@ -404,7 +453,6 @@ static int two_opt_best_sweep(tl_ctx *c, const float *xy, uint32_t n, const floa
 static int two_opt_ref_large(tl_ctx *c, const float *xy, uint32_t n, const uint32_t *init_pos, uint32_t *out_pos, float *out_cost,
                              tl_stats *stats)
 {
-    if (n > 65535) return fail(c, TL_ERR_UNSUPPORTED, "two_opt: n=%u > 65535 (packed (i,j) key)", n);
     const auto t0 = std::chrono::steady_clock::now();
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
@@ -469,6 +517,7 @@ static int two_opt_ref_large(tl_ctx *c, const float *xy, uint32_t n, const uint3
 extern "C" int tl_two_opt(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos, int mode,
                           uint32_t *out_pos, float *out_cost, tl_stats *stats)
 {
+    TL_ENTER(c);
     if (!c || (!xy && !dm_packed) || !out_pos) return fail(c, TL_ERR_BADARG, "tl_two_opt: NULL argument");
     if (mode != TL_MODE_REF_ORDER && mode != TL_MODE_BEST_SWEEP) return fail(c, TL_ERR_BADARG, "tl_two_opt: bad mode %d", mode);
     if (n < 3) return fail(c, TL_ERR_REF_PANICS, "two_opt: n=%u < 3 — the reference underflows `n_indices - 2` (two_opt.rs:17,29)", n);
@@ -530,6 +579,8 @@ extern "C" int tl_two_opt(tl_ctx *c, const float *xy, uint32_t n, const float *d
 extern "C" int tl_two_opt_trace(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos, uint32_t *out_pos,
                                 float *out_cost, tl_stats *stats, uint32_t *move_log, uint32_t log_cap, uint32_t *log_len)
 {
+    TL_ENTER(c);
+    if (log_len) *log_len = 0;  // every error return leaves an empty log, like the 3-opt / Or-opt / LK variants
     if (!c || (!xy && !dm_packed) || !out_pos || !move_log || !log_len) return fail(c, TL_ERR_BADARG, "tl_two_opt_trace: NULL argument");
     if (n < 3) return fail(c, TL_ERR_REF_PANICS, "two_opt: n=%u < 3 — the reference underflows `n_indices - 2` (two_opt.rs:17,29)", n);
     if (init_pos && !is_permutation(init_pos, n)) return fail(c, TL_ERR_BADARG, "tl_two_opt_trace: init tour is not a permutation of 0..n-1");
@@ -574,7 +625,12 @@ extern "C" int tl_two_opt_trace(tl_ctx *c, const float *xy, uint32_t n, const fl
     if (raw[3] != 0) return fail(c, TL_ERR_NO_CONVERGE, "two_opt: sweep cap reached");
     *log_len = (uint32_t)raw[15];  // words: moves applied + one mark per sweep after the first; more than log_cap: the log holds the first log_cap
     const uint32_t have = *log_len < log_cap ? *log_len : log_cap;
-    if (have) HIPCHK(c, hipMemcpy(move_log, c->work.p, (size_t)have * 4, hipMemcpyDeviceToHost));
+    // (on the context's own stream: a synchronous hipMemcpy goes through the legacy default stream, which may not meet another
+    //  thread's capturing stream — tl_lk records its round loop as a hipGraph; found by tests/test_gpu_threads.py)
+    if (have) {
+        HIPCHK(c, hipMemcpyAsync(move_log, c->work.p, (size_t)have * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     if (out_cost) *out_cost = cost;
     double kms = 0;
     tl_last_kernel_ms(c, &kms);
@@ -630,6 +686,7 @@ extern "C" int tl_two_opt_multistart(tl_ctx *c, const float *xy, uint32_t n, uin
                                      int mode, uint32_t *out_best_pos, float *out_best_cost, uint32_t *out_best_restart,
                                      float *out_costs, tl_stats *stats)
 {
+    TL_ENTER(c);
     tl_ctx *one[1] = {c};
     return tl_two_opt_multistart_devices(one, 1, xy, n, seed, first, count, mode, out_best_pos, out_best_cost, out_best_restart,
                                          out_costs, stats);
@@ -648,6 +705,11 @@ extern "C" int tl_two_opt_multistart_devices(tl_ctx *const *ctxs, int n_ctxs, co
     if (!c0 || !xy || !out_best_pos) return fail(c0, TL_ERR_BADARG, "tl_two_opt_multistart: NULL argument");
     for (int d = 0; d < n_ctxs; ++d)
         if (!ctxs[d]) return fail(c0, TL_ERR_BADARG, "tl_two_opt_multistart_devices: context %d is NULL", d);
+    std::vector<std::unique_ptr<CtxUse>> uses;
+    for (int d = 0; d < n_ctxs; ++d) {
+        uses.emplace_back(new CtxUse(ctxs[d]));
+        if (!uses.back()->ok) return TL_ERR_BUSY;
+    }
     if (count == 0) return fail(c0, TL_ERR_BADARG, "tl_two_opt_multistart: count == 0");
     if (n < 3) return fail(c0, TL_ERR_REF_PANICS, "two_opt: n=%u < 3", n);
     const auto t0 = std::chrono::steady_clock::now();
@@ -690,7 +752,8 @@ extern "C" int tl_two_opt_multistart_devices(tl_ctx *const *ctxs, int n_ctxs, co
     }
     tl_ctx *cb = ctxs[best_dev];
     HIPCHK(cb, hipSetDevice(cb->device));
-    HIPCHK(cb, hipMemcpy(out_best_pos, (const uint32_t *)cb->out_pos.p + (size_t)best.local * n, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(cb, hipMemcpyAsync(out_best_pos, (const uint32_t *)cb->out_pos.p + (size_t)best.local * n, (size_t)n * 4, hipMemcpyDeviceToHost, cb->stream));
+    HIPCHK(cb, hipStreamSynchronize(cb->stream));  // never the legacy stream: see tl_two_opt_trace
     const uint32_t best_restart = (uint32_t)(best.key & 0xFFFFFFFFull);
     if (out_best_cost) *out_best_cost = costs[best_restart - first];
     if (out_best_restart) *out_best_restart = best_restart;
@@ -704,6 +767,7 @@ extern "C" int tl_two_opt_multistart_devices(tl_ctx *const *ctxs, int n_ctxs, co
 extern "C" int tl_two_opt_population(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
                                      uint32_t count, uint32_t *out_pos, float *out_costs, tl_stats *stats)
 {
+    TL_ENTER(c);
     if (!c || (!xy && !dm_packed) || !init_pos || !out_pos) return fail(c, TL_ERR_BADARG, "tl_two_opt_population: NULL argument");
     if (count == 0) return fail(c, TL_ERR_BADARG, "tl_two_opt_population: count == 0");
     if (n < 3) return fail(c, TL_ERR_REF_PANICS, "two_opt: n=%u < 3", n);
@@ -894,6 +958,7 @@ static int three_opt_setup(tl_ctx *c, const float *xy, uint32_t n, const float *
 extern "C" int tl_three_opt_find_best_move(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *path,
                                            int *found, uint32_t *oi, uint32_t *oj, uint32_t *ok, int *kase, float *savings)
 {
+    TL_ENTER(c);
     if (!c || (!xy && !dm_packed) || !path || !found) return fail(c, TL_ERR_BADARG, "tl_three_opt_find_best_move: NULL argument");
     *found = 0;
     if (n < 4) return TL_OK;
@@ -992,6 +1057,7 @@ static int three_opt_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm
 extern "C" int tl_three_opt(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
                             uint32_t *out_pos, float *out_cost, tl_stats *stats)
 {
+    TL_ENTER(c);
     return three_opt_run(c, xy, n, dm_packed, init_pos, out_pos, out_cost, stats, nullptr, 0, nullptr);
 }
 
@@ -1000,6 +1066,7 @@ extern "C" int tl_three_opt(tl_ctx *c, const float *xy, uint32_t n, const float 
 extern "C" int tl_three_opt_trace(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
                                   uint32_t *out_pos, float *out_cost, tl_stats *stats, uint32_t *move_log, uint32_t log_cap, uint32_t *log_len)
 {
+    TL_ENTER(c);
     if (!move_log || !log_len) return fail(c, TL_ERR_BADARG, "tl_three_opt_trace: NULL argument");
     return three_opt_run(c, xy, n, dm_packed, init_pos, out_pos, out_cost, stats, move_log, log_cap, log_len);
 }
@@ -1009,10 +1076,7 @@ extern "C" int tl_three_opt_trace(tl_ctx *c, const float *xy, uint32_t n, const 
 // ------------------------------------------------------------------------------------------------
 static int or_opt_setup(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *path, OrOptArgs &A, bool &dm)
 {
-    if ((uint64_t)3 * n * n * 2 > 0xFFFFFFFFull)
-        return fail(c, TL_ERR_UNSUPPORTED, "or_opt: n=%u too large for the packed loop-order key (n <= 26754)", n);
-    if ((size_t)n * 4 > (size_t)c->lds_bytes - 1024) return fail(c, TL_ERR_UNSUPPORTED, "or_opt: n=%u exceeds the LDS staging limit", n);
-    int rc;
+    int rc;  // (round 4: a 96-bit argmin key and a workspace copy of the tour beyond the LDS — no size limit of its own any more)
     dm = dm_packed != nullptr;
     if (dm) {
         const size_t b = (size_t)n * (n - 1) / 2 * 4;
@@ -1025,7 +1089,7 @@ static int or_opt_setup(tl_ctx *c, const float *xy, uint32_t n, const float *dm_
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const uint32_t nblocks = or_opt_scan_blocks(n);
     const size_t o_perm = 0, o_pt = up((size_t)n * 4), o_e = up(o_pt + (size_t)n * 8), o_par = up(o_e + (size_t)n * 4),
-                 o_best = up(o_par + (size_t)nblocks * 8), total = o_best + 256;
+                 o_best = up(o_par + (size_t)nblocks * 16), o_old = up(o_best + 256), total = o_old + (size_t)n * 4 + 256;
     if ((rc = ensure(c, c->work, total))) return rc;
     unsigned char *w = (unsigned char *)c->work.p;
     std::vector<uint32_t> ident;
@@ -1043,6 +1107,7 @@ static int or_opt_setup(tl_ctx *c, const float *xy, uint32_t n, const float *dm_
     A.E = (float *)(w + o_e);
     A.partials = (unsigned long long *)(w + o_par);
     A.best = (OrOptBest *)(w + o_best);
+    A.scratch = (uint32_t *)(w + o_old);
     A.n = n;
     return TL_OK;
 }
@@ -1050,6 +1115,7 @@ static int or_opt_setup(tl_ctx *c, const float *xy, uint32_t n, const float *dm_
 extern "C" int tl_or_opt_find_best_move(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *path,
                                         int *found, float *delta, uint32_t *oi, uint32_t *oj, uint32_t *seg_len, int *reversed)
 {
+    TL_ENTER(c);
     if (!c || (!xy && !dm_packed) || !path || !found) return fail(c, TL_ERR_BADARG, "tl_or_opt_find_best_move: NULL argument");
     *found = 0;
     if (n < 4) return TL_OK;
@@ -1060,7 +1126,7 @@ extern "C" int tl_or_opt_find_best_move(tl_ctx *c, const float *xy, uint32_t n, 
     int rc;
     if ((rc = or_opt_setup(c, xy, n, dm_packed, path, A, dm))) return rc;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    HIPCHK(c, launch_or_opt_pass(A, dm, 0, c->stream));
+    HIPCHK(c, launch_or_opt_pass(A, dm, 0, c->stream, c->lds_bytes));
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->ev_valid = true;
     OrOptBest b{};
@@ -1106,7 +1172,7 @@ static int or_opt_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_pa
     uint64_t passes = 0, moves = 0;
     const uint64_t cap = 64ull * n + 1024;
     for (;;) {  // or_opt.rs:45 while let Some(best) = find_best_move(..)
-        HIPCHK(c, launch_or_opt_pass(A, dm, 1, c->stream));
+        HIPCHK(c, launch_or_opt_pass(A, dm, 1, c->stream, c->lds_bytes));
         OrOptBest b{};
         HIPCHK(c, hipMemcpyAsync(&b, A.best, sizeof(b), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1154,6 +1220,7 @@ static int or_opt_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_pa
 extern "C" int tl_or_opt(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
                          uint32_t *out_pos, float *out_cost, tl_stats *stats)
 {
+    TL_ENTER(c);
     return or_opt_run(c, xy, n, dm_packed, init_pos, out_pos, out_cost, stats, nullptr, 0, nullptr);
 }
 
@@ -1162,6 +1229,7 @@ extern "C" int tl_or_opt(tl_ctx *c, const float *xy, uint32_t n, const float *dm
 extern "C" int tl_or_opt_trace(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
                                uint32_t *out_pos, float *out_cost, tl_stats *stats, uint32_t *move_log, uint32_t log_cap, uint32_t *log_len)
 {
+    TL_ENTER(c);
     if (!move_log || !log_len) return fail(c, TL_ERR_BADARG, "tl_or_opt_trace: NULL argument");
     return or_opt_run(c, xy, n, dm_packed, init_pos, out_pos, out_cost, stats, move_log, log_cap, log_len);
 }
@@ -1201,6 +1269,7 @@ static int build_candidates_dev(tl_ctx *c, const float *xy_host, const float2 *d
 // ------------------------------------------------------------------------------------------------
 extern "C" int tl_build_candidates(tl_ctx *c, const float *xy, uint32_t n, uint32_t k, uint32_t *out)
 {
+    TL_ENTER(c);
     if (!c || !xy || !out) return fail(c, TL_ERR_BADARG, "tl_build_candidates: NULL argument");
     if (n == 0) return fail(c, TL_ERR_BADARG, "tl_build_candidates: n == 0");
     if (k > n - 1) k = n - 1;  // lin_kernighan.rs:14
@@ -1249,6 +1318,7 @@ static int nn_seed_dev(tl_ctx *c, const float2 *d_xy, uint32_t n, uint32_t n_nea
 extern "C" int tl_nearest_neighbor(tl_ctx *c, const float *xy, const float *dm_packed, uint32_t n, uint32_t n_nearest,
                                    uint32_t *out_pos, float *out_cost)
 {
+    TL_ENTER(c);
     if (!c || (!xy && !dm_packed) || !out_pos) return fail(c, TL_ERR_BADARG, "tl_nearest_neighbor: NULL argument");
     if (n == 0) return fail(c, TL_ERR_REF_PANICS, "nearest_neighbor: cities[0] on an empty problem (nearest_neighbor.rs:28)");
     if (n == 1) {  // the walk is [cities[0]]; tour_length of fewer than two cities is 0 (distance_matrix.rs:236-238)
@@ -1305,7 +1375,11 @@ static int lk_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed
     if (opts) o = *opts;
     if (o.n_nearest == 0) return fail(c, TL_ERR_BADARG, "n_nearest must be >= 1");   // mod.rs:677-682
     if (o.max_depth == 0) return fail(c, TL_ERR_BADARG, "max_depth must be >= 1");   // mod.rs:1270-1276
-    if (o.max_depth > 6) return fail(c, TL_ERR_UNSUPPORTED, "tl_lk: max_depth=%u > 6 (compile-time recursion bound)", o.max_depth);
+    // chains of up to 6 exchanges live in registers (lk.hip); 7..16 run the same kernels built with larger chain arrays (lk_deep.hip)
+    const bool deep = o.max_depth > lk_max_depth();
+    if (o.max_depth > tl_lk_deep::lk_max_depth())
+        return fail(c, TL_ERR_UNSUPPORTED, "tl_lk: max_depth=%u > %u (the largest chain this build holds; the reference's max_depth is unbounded, mod.rs:1252)",
+                    o.max_depth, tl_lk_deep::lk_max_depth());
     if (o.n_nearest > 16) return fail(c, TL_ERR_UNSUPPORTED, "tl_lk: n_nearest=%u > 16", o.n_nearest);
     if (init_pos && !is_permutation(init_pos, n)) return fail(c, TL_ERR_BADARG, "tl_lk: init tour is not a permutation of 0..n-1");
     const auto t0 = std::chrono::steady_clock::now();
@@ -1344,21 +1418,32 @@ static int lk_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed
     const bool lk_small = ((tf & TL_FLAG_LK_SMALL) || (!((c->flags | tf) & variant_flags) && n <= small_max_n)) &&
                           lk_small_lds_bytes(n, k_small) + 4096 <= (size_t)c->lds_bytes;
     const bool multi_cu = !(c->flags & TL_FLAG_LK_ONE_WORKGROUP) && !lk_small;
-    const size_t o_pairmin = o_chains + (multi_cu ? up((size_t)2 * n * lk_chain_slot_words() * 4) : 0);
+    const size_t slot_words = deep ? tl_lk_deep::lk_chain_slot_words() : lk_chain_slot_words();
+    const size_t sub_bytes = (deep ? tl_lk_deep::lk_sub_slot_words() : lk_sub_slot_words()) * 4;  // 64 at depth <= 6
+    const size_t o_pairmin = o_chains + (multi_cu ? up((size_t)2 * n * slot_words * 4) : 0);
     const bool split_scan = multi_cu && max_depth_ge2_split(o.max_depth) && !(tf & TL_FLAG_LK_NO_SPLIT);
     // every successful sub-search keeps its chain (64 B) so that the pick step does not walk the winner again; sized for
     // 288 GB of HBM (45 MB at n = 13 509, k = 5), skipped beyond 4 GB
     // three split levels (k(k+1)^2 sub-searches per pair: the sequential part of a walk shrinks to k^2 nodes) while their
     // kept chains fit 4 GB, else two
-    const uint32_t levels = (split_scan && !(tf & TL_FLAG_LK_SPLIT2) && (size_t)2 * n * k * (k + 1) * (k + 1) * 64 <= ((size_t)4 << 30)) ? 3u : 2u;
-    const size_t sub_b = split_scan ? (size_t)2 * n * k * (k + 1) * (levels == 3u ? k + 1 : 1) * 64 : 0;
+    const uint32_t levels = (split_scan && !(tf & TL_FLAG_LK_SPLIT2) && (size_t)2 * n * k * (k + 1) * (k + 1) * sub_bytes <= ((size_t)4 << 30)) ? 3u : 2u;
+    const size_t sub_b = split_scan ? (size_t)2 * n * k * (k + 1) * (levels == 3u ? k + 1 : 1) * sub_bytes : 0;
     // one workgroup per pair (k(k+1)^2 or k(k+1) <= 1024 threads): the scan picks and validates the pair's first chain itself
     const bool fused_pick = split_scan && (size_t)k * (k + 1) * (levels == 3u ? k + 1 : 1) <= 1024 &&
                             !(tf & (TL_FLAG_LK_SEPARATE_PICK | TL_FLAG_LK_NO_SUBCHAINS));
     const bool keep_sub = split_scan && !fused_pick && sub_b <= ((size_t)4 << 30) && !(tf & TL_FLAG_LK_NO_SUBCHAINS);
     const size_t o_sub = o_pairmin + (split_scan ? up((size_t)2 * n * 4) : 0);
     const size_t total = o_sub + (keep_sub ? up(sub_b) : 0);
+    // every mode / size check and every allocation comes before the first event record and the first enqueue: a rejected call
+    // leaves the previous kernel sequence's event pair intact and nothing in flight
+    // (the single-workgroup forms keep no snapshots on the device: a trace of theirs is the final best tour alone, below)
+    const bool snap_dev = snap_pos && multi_cu;
+    if (!init_pos && dm_packed && (size_t)n + 1024 > (size_t)c->lds_bytes)
+        return fail(c, TL_ERR_UNSUPPORTED, "nearest_neighbor: n=%u exceeds the LDS-resident visited flags", n);
     if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->work, total)) || (rc = ensure(c, c->out_cost, 4))) return rc;
+    if (snap_dev && ((rc = ensure(c, c->out_pos, (size_t)(snap_cap ? snap_cap : 1) * n * 4)) ||
+                     (rc = ensure(c, c->out_stats, (size_t)(snap_cap ? snap_cap : 1) * 4))))
+        return rc;
     unsigned char *w = (unsigned char *)c->work.p;
     HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     const float *ddm = nullptr;
@@ -1373,8 +1458,6 @@ static int lk_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed
     if (init_pos) {
         HIPCHK(c, hipMemcpyAsync(w + o_tour, init_pos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     } else if (ddm) {
-        if ((size_t)n + 1024 > (size_t)c->lds_bytes)
-            return fail(c, TL_ERR_UNSUPPORTED, "nearest_neighbor: n=%u exceeds the LDS-resident visited flags", n);
         HIPCHK(c, launch_nn_seed_dm(ddm, n, (uint32_t *)(w + o_tour), c->lds_bytes, c->stream));
     } else {
         // lin_kernighan.rs:47-55: nearest_neighbor::solve with HeuristicOptions::default() (n_nearest = 3)
@@ -1407,9 +1490,7 @@ static int lk_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed
     G.split_levels = levels;
     G.fused_pick = fused_pick ? 1u : 0u;
     G.chip_step = (fused_pick && levels == 3u && n >= 1500u && !(tf & TL_FLAG_LK_SEPARATE_STEP)) ? 1u : 0u;
-    if (snap_pos) {
-        if (!multi_cu) return fail(c, TL_ERR_UNSUPPORTED, "tl_lk_trace: the single-workgroup forms record no snapshots");
-        if ((rc = ensure(c, c->out_pos, (size_t)(snap_cap ? snap_cap : 1) * n * 4)) || (rc = ensure(c, c->out_stats, (size_t)(snap_cap ? snap_cap : 1) * 4))) return rc;
+    if (snap_dev) {
         G.snap = (uint32_t *)c->out_pos.p;
         G.snap_dist = (float *)c->out_stats.p;
         G.snap_cap = snap_cap;
@@ -1417,9 +1498,10 @@ static int lk_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed
     if (split_scan) HIPCHK(c, hipMemsetAsync(G.pairmin, 0xFF, (size_t)2 * n * 4, c->stream));
     uint64_t cnt[4] = {0, 0, 0, 0};
     if (!multi_cu) {
-        HIPCHK(c, launch_lk_solve(G, c->stream, lk_small, small_nt));
+        HIPCHK(c, deep ? tl_lk_deep::launch_lk_solve(G, c->stream, lk_small, small_nt) : launch_lk_solve(G, c->stream, lk_small, small_nt));
     } else {
-        HIPCHK(c, launch_lk_begin(G, c->stream));
+        HIPCHK(c, deep ? tl_lk_deep::launch_lk_begin(G, c->stream) : launch_lk_begin(G, c->stream));
+        auto lk_round = [&](uint32_t r) { return deep ? tl_lk_deep::launch_lk_round(G, c->stream, r) : launch_lk_round(G, c->stream, r); };
         LkState hs{};
         // 64 rounds per poll of `finished` (the kernels are no-ops once it is set).  The first batch is enqueued launch by
         // launch; a search that is still running after it replays the same 64 rounds as ONE hipGraph launch per poll — a round
@@ -1434,16 +1516,31 @@ static int lk_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed
                 graph_ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
                 if (graph_ok) {
                     hipError_t le = hipSuccess;
-                    for (int r = 0; r < 64 && le == hipSuccess; ++r) le = launch_lk_round(G, c->stream, (uint32_t)r);
+                    for (int r = 0; r < 64 && le == hipSuccess; ++r) le = lk_round((uint32_t)r);
                     const hipError_t ce = hipStreamEndCapture(c->stream, &graph);
                     graph_ok = le == hipSuccess && ce == hipSuccess && graph &&
                                hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) == hipSuccess;
-                    if (!graph_ok) (void)hipGetLastError();  // separately enqueued launches from here on
+                }
+                if (!graph_ok) {
+                    // separately enqueued launches from here on — after making sure the stream has left capture mode (a capture
+                    // that another thread's legacy-stream operation invalidated stays "active, invalidated" until it is ended)
+                    (void)hipGetLastError();
+                    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                    if (hipStreamIsCapturing(c->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+                        hipGraph_t g2 = nullptr;
+                        (void)hipStreamEndCapture(c->stream, &g2);
+                        if (g2) (void)hipGraphDestroy(g2);
+                    }
+                    (void)hipGetLastError();
+                    if (graph) {
+                        (void)hipGraphDestroy(graph);
+                        graph = nullptr;
+                    }
                 }
             }
             hipError_t e = hipSuccess;
             if (gexec) e = hipGraphLaunch(gexec, c->stream);
-            else for (int r = 0; r < 64 && e == hipSuccess; ++r) e = launch_lk_round(G, c->stream, (uint32_t)r);
+            else for (int r = 0; r < 64 && e == hipSuccess; ++r) e = lk_round((uint32_t)r);
             if (e == hipSuccess) e = hipMemcpyAsync(&hs, G.state, sizeof(hs), hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) {
@@ -1479,6 +1576,22 @@ static int lk_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed
     HIPCHK(c, hipMemcpyAsync(&cost, c->out_cost.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (out_cost) *out_cost = cost;
+    if (snap_pos && !multi_cu) {
+        // TL_FLAG_LK_ONE_WORKGROUP: the reference's last PathUpdate only — the final best tour with its best_dist, the Euclidean
+        // tour_distance of lin_kernighan.rs:118-122 (edges in tour order, the closing edge last; f32, as KDPoint::distance)
+        float bd = 0.0f;
+        for (uint32_t q = 0; q < n; ++q) {
+            const float *p0 = xy + 2 * (size_t)out_pos[q], *p1 = xy + 2 * (size_t)out_pos[(q + 1u) % n];
+            const float dx = p0[0] - p1[0], dy = p0[1] - p1[1];
+            const float sq = dx * dx + dy * dy;  // -ffp-contract=off: three roundings
+            bd += sqrtf(sq);
+        }
+        if (snap_len) *snap_len = 1;
+        if (snap_cap) {
+            memcpy(snap_pos, out_pos, (size_t)n * 4);
+            if (snap_dist) snap_dist[0] = bd;
+        }
+    }
     if (stats) {
         stats->sweeps = cnt[0];
         stats->candidates = cnt[1];
@@ -1495,6 +1608,7 @@ static int lk_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed
 extern "C" int tl_lk(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos, const tl_lk_opts *opts,
                      uint64_t seed, uint32_t *out_pos, float *out_cost, tl_stats *stats)
 {
+    TL_ENTER(c);
     return lk_run(c, xy, n, dm_packed, init_pos, opts, seed, out_pos, out_cost, stats, nullptr, nullptr, 0, nullptr);
 }
 
@@ -1505,6 +1619,7 @@ extern "C" int tl_lk_trace(tl_ctx *c, const float *xy, uint32_t n, const float *
                            uint64_t seed, uint32_t *out_pos, float *out_cost, tl_stats *stats, uint32_t *snap_pos, float *snap_dist,
                            uint32_t snap_cap, uint32_t *snap_len)
 {
+    TL_ENTER(c);
     if (!snap_pos || !snap_dist || !snap_len) return fail(c, TL_ERR_BADARG, "tl_lk_trace: NULL argument");
     return lk_run(c, xy, n, dm_packed, init_pos, opts, seed, out_pos, out_cost, stats, snap_pos, snap_dist, snap_cap, snap_len);
 }

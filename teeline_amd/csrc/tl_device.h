@@ -131,12 +131,24 @@ __device__ __forceinline__ void jitter(uint32_t salt)
 
 // One lane's ds_min_u32 exactly as written.  atomicMin on a wave-uniform LDS address goes through the compiler's atomic optimiser,
 // which wraps it in a scan over the active lanes (~20 scalar instructions and a v_mbcnt pair) even where the caller has already
-// narrowed exec to one lane — on the path every wave of a descent waits for.  (LDS operations of a wave complete in order, so the
-// compiler's own lgkmcnt waits stay sufficient around it.)
+// narrowed exec to one lane — on the path every wave of a descent waits for.
+// An LDS operation issued through inline asm is NOT counted by the compiler's s_waitcnt insertion: a barrier that follows it
+// gets its `s_waitcnt lgkmcnt(0)` only if some tracked LDS operation of the wave sits in between (LDS operations of a wave
+// complete in order, so waiting for a later one covers this one).  Callers therefore either follow the post with a tracked LDS
+// write before the step's barrier (the hit list of a dense step, two_opt_common.h / two_opt_dm.hip) or use lds_min_u32_fenced.
+// teeline_amd/build.py disassembles the linked library and refuses it unless every path from a ds_min_u32 to the next
+// s_barrier passes an `s_waitcnt lgkmcnt(0)` (verify_ds_min_waits; tests/test_build_asm.py).
 __device__ __forceinline__ void lds_min_u32(uint32_t *p, uint32_t v)
 {
     const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)p;
     asm volatile("ds_min_u32 %0, %1" : : "v"(a), "v"(v) : "memory");
+}
+// ... with its own wait: for a post that is followed by a barrier with no tracked LDS operation of this wave in between (the
+// pruned step's hit, two_opt_ref.hip — rare there, so the ~100 cycles of the wait are not on a hot path).
+__device__ __forceinline__ void lds_min_u32_fenced(uint32_t *p, uint32_t v)
+{
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)p;
+    asm volatile("ds_min_u32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : : "v"(a), "v"(v) : "memory");
 }
 
 __device__ __forceinline__ float readlane_f(float v, int l)

@@ -94,7 +94,8 @@ uint32_t best_sweep_scan_blocks(uint32_t n);
 
 // two_opt_large.hip — REF_ORDER for tours beyond one CU's LDS
 struct LargeTwoOptState {
-    uint32_t key, i0, j0, rows, improved, sweeps, done, status;
+    unsigned long long key;  // (row << 32) | column of the lexicographically first improving candidate of the round; ~0 = none
+    uint32_t i0, j0, rows, improved, sweeps, done, status, pad_;
     uint64_t moves, reversed;
 };
 struct LargeTwoOptArgs {
@@ -143,11 +144,12 @@ struct OrOptArgs {
     uint32_t *perm;                // [n] tour positions, updated in place by k_or_pick
     float2 *Pt;                    // [n] tour-ordered coordinates
     float *E;                      // [n] tour-edge lengths, E[n-1] = closing edge
-    unsigned long long *partials;  // one packed key per scan workgroup
+    unsigned long long *partials;  // one packed key (two words: ~delta bits, loop-order index) per scan workgroup
     OrOptBest *best;
+    uint32_t *scratch;             // [n] the pre-move tour of k_or_pick where it does not fit the LDS
     uint32_t n;
 };
-hipError_t launch_or_opt_pass(const OrOptArgs &A, bool dm, int apply, hipStream_t s);
+hipError_t launch_or_opt_pass(const OrOptArgs &A, bool dm, int apply, hipStream_t s, int lds_budget);
 uint32_t or_opt_scan_blocks(uint32_t n);
 
 // lk.hip
@@ -204,6 +206,21 @@ size_t lk_small_lds_bytes(uint32_t n, uint32_t k);
 hipError_t launch_lk_begin(const LkArgs &G, hipStream_t s);
 hipError_t launch_lk_round(const LkArgs &G, hipStream_t s, uint32_t round);
 size_t lk_chain_slot_words();
+size_t lk_sub_slot_words();
+uint32_t lk_max_depth();  // the build's compile-time recursion bound (6)
+
+}  // namespace tl
+// lk_deep.hip — lk.hip compiled with chains of up to 16 exchanges (max_depth 7..16)
+namespace tl_lk_deep {
+hipError_t launch_lk_solve(const tl::LkArgs &G, hipStream_t s, bool small = false, int threads = 1024);
+size_t lk_small_lds_bytes(uint32_t n, uint32_t k);
+hipError_t launch_lk_begin(const tl::LkArgs &G, hipStream_t s);
+hipError_t launch_lk_round(const tl::LkArgs &G, hipStream_t s, uint32_t round);
+size_t lk_chain_slot_words();
+size_t lk_sub_slot_words();
+uint32_t lk_max_depth();
+}  // namespace tl_lk_deep
+namespace tl {
 
 // kdtree.hip — build_candidates through the reference's kd-tree (kdtree.rs)
 struct KdNode {

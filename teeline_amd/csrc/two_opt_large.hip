@@ -1,10 +1,10 @@
 // two_opt_large.hip — REF_ORDER 2-opt (src/tsp/two_opt.rs:26-61) for tours that do not fit one CU's LDS
-// (n > ~14.7 K, up to 65 535): the same first-improvement order and the same exact decision cascade as
+// (n > ~14.7 K; no upper limit but the u32 positions of the C ABI): the same first-improvement order and the same exact decision cascade as
 // two_opt_ref.hip, with the tour-ordered coordinates, the tour and the L0 tile boxes in HBM (L2-resident) and the
 // speculative block of rows spread over the whole chip.
 //   k_rl_scan    rows [i0, i0+R) of the current cursor, one wave per row: L0 (lanes = tiles) -> live tiles ->
 //                L1/L2/L3 inline (dense_tile, shared with the LDS kernel); the lexicographically first improving
-//                (i, j) is reduced with a global atomicMin on (i << 16 | j).
+//                (i, j) is reduced with a global 64-bit atomicMin on (i << 32 | j) (round 4: was i << 16 | j, n <= 65 535).
 //   k_rl_apply   one workgroup, device-side cursor state machine: no hit -> advance R rows (R doubles up to 1024
 //                while nothing is found, restarts at 16 after a move); hit -> swap_2opt(path, i+1, j) on P and perm,
 //                rebuild the touched tile boxes, resume at (i, j+1); end of sweep -> next sweep or done.
@@ -18,7 +18,7 @@
 namespace tl {
 
 namespace {
-constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+constexpr unsigned long long kNoKey = ~0ull;
 constexpr int kRlWaves = 4;
 constexpr uint32_t kRlMinRows = 16, kRlMaxRows = 1024;
 }  // namespace
@@ -39,8 +39,9 @@ __global__ __launch_bounds__(kRlWaves * 64) void k_rl_scan(LargeTwoOptArgs A)
     const uint32_t jmin = (r == 0u) ? j0 : (i + 2u), tmin = jmin >> 6;
     const uint32_t ngroups = ((A.n_pad >> 6) + 63u) >> 6;
     for (uint32_t g = tmin >> 6; g < ngroups; ++g) {
-        const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)S->key);
-        if (kb != kNoKey && (kb >> 16) < i) return;  // an earlier row already improves
+        // an earlier row already improves (the high word alone decides; kNoKey reads as row 0xFFFFFFFF)
+        const unsigned long long kb = __hip_atomic_load(&S->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // a fresh read per tile group
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(kb >> 32)) < i) return;
         const uint32_t tl = (g << 6) + (uint32_t)lane;
         const float4 box = A.tbox[tl];
         const float msq = A.tmsq[tl];
@@ -49,7 +50,12 @@ __global__ __launch_bounds__(kRlWaves * 64) void k_rl_scan(LargeTwoOptArgs A)
         while (m) {
             const uint32_t t = (g << 6) + (uint32_t)(__builtin_ffsll((long long)m) - 1);
             m &= m - 1;
-            if (tile_first_hit<true>(P, n, i, t << 6, jmin, a.x, a.y, b.x, b.y, sqab, &S->key, lane)) return;
+            NoCounts tc;
+            const uint64_t hm = tile_improving_mask<true>(P, n, t << 6, jmin, a.x, a.y, b.x, b.y, sqab, lane, tc);
+            if (hm) {
+                if (lane == 0) atomicMin(&S->key, ((unsigned long long)i << 32) | ((t << 6) + (uint32_t)(__builtin_ffsll((long long)hm) - 1)));
+                return;
+            }
         }
     }
 }
@@ -60,7 +66,8 @@ __global__ __launch_bounds__(1024) void k_rl_apply(LargeTwoOptArgs A)
     if (S->done) return;
     const uint32_t tid = threadIdx.x, n = A.n, nrows = n - 3u;
     const int lane = tid & 63, wave = tid >> 6;
-    const uint32_t key = S->key, i0 = S->i0, R = S->rows;
+    const unsigned long long key = S->key;
+    const uint32_t i0 = S->i0, R = S->rows;
     TL_SYNC();
     uint32_t ni0, nj0, nrowsstep = R;
     bool improved = S->improved != 0u;
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(1024) void k_rl_apply(LargeTwoOptArgs A)
         nj0 = ni0 + 2u;
         nrowsstep = R * 2u > kRlMaxRows ? kRlMaxRows : R * 2u;
     } else {
-        const uint32_t is = key >> 16, js = key & 0xFFFFu;
+        const uint32_t is = (uint32_t)(key >> 32), js = (uint32_t)key;
         const uint32_t lo = is + 1u, hi = js, half = (hi - lo + 1u) >> 1;
         float2 *P = A.P;
         uint32_t *perm = A.perm;

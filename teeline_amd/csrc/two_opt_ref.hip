@@ -776,7 +776,8 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                     }
                     continue;  // nothing in this row: rows w+NWK, ... next
                 row_hit:
-                    if (lane == 0) lds_min_u32(keyslot, (i << 16) | ((t << 6) + (uint32_t)(__builtin_ffsll((long long)hm) - 1)));
+                    // (fenced: the break below runs straight into B2 with no tracked LDS operation of this wave in between, tl_device.h)
+                    if (lane == 0) lds_min_u32_fenced(keyslot, (i << 16) | ((t << 6) + (uint32_t)(__builtin_ffsll((long long)hm) - 1)));
                     break;  // rows w+NWK, ... are later rows
                 }
             }

@@ -54,6 +54,8 @@ class Context:
     def check(self, rc):
         if rc == _capi.TL_OK:
             return
+        if rc == _capi.TL_ERR_BUSY:  # the context's error string belongs to the thread that is inside: do not read it
+            raise TeelineGpuError(rc, "the context is in use by another thread (one tl_ctx per thread)")
         msg = self._lib.tl_last_error(self._h).decode()
         if rc == _capi.TL_ERR_REF_PANICS:
             raise ReferencePanics(rc, msg)

@@ -50,6 +50,7 @@ class Context {  // one tl_ctx per thread (teeline-api calls solvers from spawn_
     void check(int rc) const
     {
         if (rc == TL_OK) return;
+        if (rc == TL_ERR_BUSY) throw std::runtime_error("teeline-gpu: the context is in use by another thread (one Context per thread)");
         if (rc == TL_ERR_REF_PANICS) throw ReferencePanic(tl_last_error(h_));
         throw std::runtime_error(std::string("teeline-gpu: ") + tl_last_error(h_));
     }
@@ -772,6 +773,7 @@ struct StageOutcome {  // :11-14
     Solvers solver;
     Solution solution;
     uint64_t duration_ms = 0;
+    double duration_us = 0.0;  // the same interval, finer (the CLI's --timing)
 };
 
 // stage_warnings (:92-132), for the solvers this build knows
@@ -809,12 +811,13 @@ inline std::vector<StageOutcome> run_pipeline_stages(Context &ctx, const TspProb
             case Solvers::LinKernighan: sol = lin_kernighan::solve(ctx, problem, o.lk, o.progress, init, o.seed); break;
             case Solvers::RandomShuffle: sol = random_shuffle::solve(ctx, problem, o.seed); break;
         }
-        const uint64_t ms = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        const auto t1 = std::chrono::steady_clock::now();
+        const uint64_t ms = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count();
         if (!validate_tour(sol.route(), problem.cities))
             throw std::runtime_error(std::string("stage ") + solver_name(s) + " invalid tour");  // :70-71
         seed = sol.route();
         have_seed = true;
-        out.push_back(StageOutcome{s, std::move(sol), ms});
+        out.push_back(StageOutcome{s, std::move(sol), ms, std::chrono::duration<double, std::micro>(t1 - t0).count()});
     }
     return out;
 }

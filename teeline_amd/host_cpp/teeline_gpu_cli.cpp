@@ -10,9 +10,13 @@
 //     stdout  : print_solution "{:.5} {0|1}\n<id id ... >\n" (main.rs:645-652) or the JSON object of main.rs:700-712;
 //               with --optimal-tour the comparison goes to stderr in text mode and into the JSON object in JSON mode
 //   own flags (no counterpart in the reference): --seed S (LK kicks and the shuffle stage; the reference draws both from an
-//   unseeded thread RNG), --best-sweep (TL_MODE_BEST_SWEEP), --device N, --stats
+//   unseeded thread RNG), --best-sweep (TL_MODE_BEST_SWEEP), --device N, --stats,
+//   --timing (one JSON line on stderr: milliseconds of main() by phase — read input, create context, every stage's wall and kernel
+//   time, output — what bench.py's drop_in_end_to_end reads), --repeat K (run the stage list K times in this process, the last
+//   run is printed: with --timing the first run is the cold one — code-object load, workspace allocation — the others steady)
 #include "teeline_gpu.hpp"
 
+#include <chrono>
 #include <cstring>
 #include <iostream>
 
@@ -23,8 +27,8 @@ namespace {
 
 struct Args {
     std::string cmd, solver, file, steps, optimal_tour, distance_type, output_format = "text";
-    bool no_seed = false, best = false, stats = false, short_list = false, progress_digest = false;
-    int device = 0;
+    bool no_seed = false, best = false, stats = false, short_list = false, progress_digest = false, timing = false;
+    int device = 0, repeat = 1;
     pipeline::StageOptions opt;
 };
 
@@ -99,6 +103,8 @@ Args parse(int argc, char **argv)
         else if (s == "--stats") a.stats = true;
         else if (s == "--short") a.short_list = true;
         else if (s == "--progress-digest") a.progress_digest = true;
+        else if (s == "--timing") a.timing = true;
+        else if (s == "--repeat") a.repeat = std::max(1, std::stoi(val()));
         else usage_exit(("unexpected argument " + s).c_str());
     }
     if (a.output_format != "text" && a.output_format != "json") usage_exit("--output-format: text or json");
@@ -134,6 +140,9 @@ std::vector<Solvers> parse_steps(const std::string &csv)
 
 int main(int argc, char **argv)
 {
+    using clk = std::chrono::steady_clock;
+    const auto t_main = clk::now();
+    auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
     try {
         Args a = parse(argc, argv);
         if (a.cmd == "solvers") {  // `teeline solvers [--short]`, restricted to what this build runs
@@ -206,8 +215,13 @@ int main(int argc, char **argv)
                 return 1;
             }
         }
+        const double ms_read = ms_since(t_main);
+        const auto t_ctx = clk::now();
         Context ctx(a.device);
+        const double ms_create = ms_since(t_ctx);
+        const auto t_prob = clk::now();
         TspProblem problem = data.problem(ctx);
+        const double ms_problem = ms_since(t_prob);
         bool have_opt = false;
         opt_tour::OptTour ot;
         if (!a.optimal_tour.empty()) {
@@ -238,7 +252,22 @@ int main(int argc, char **argv)
             dg.word(k == 0 ? bits : 0u, 4);
         };
         if (a.progress_digest) a.opt.progress = &on_progress;
-        auto outcomes = pipeline::run_pipeline_stages(ctx, problem, stages, a.opt);
+        std::string runs_json;
+        std::vector<pipeline::StageOutcome> outcomes;
+        for (int rep = 0; rep < a.repeat; ++rep) {
+            const auto t_run = clk::now();
+            outcomes = pipeline::run_pipeline_stages(ctx, problem, stages, a.opt);
+            char buf[160];
+            std::snprintf(buf, sizeof(buf), "%s{\"wall_ms\": %.4f, \"stages\": [", rep ? ", " : "", ms_since(t_run));
+            runs_json += buf;
+            for (size_t k = 0; k < outcomes.size(); ++k) {
+                std::snprintf(buf, sizeof(buf), "%s{\"solver\": \"%s\", \"wall_ms\": %.4f, \"kernel_ms\": %.4f}", k ? ", " : "", solver_name(outcomes[k].solver),
+                              outcomes[k].duration_us * 1e-3, outcomes[k].solution.stats.kernel_ms);
+                runs_json += buf;
+            }
+            runs_json += "]}";
+        }
+        const auto t_out = clk::now();
         if (a.progress_digest)
             std::fprintf(stderr, "progress: path_updates=%llu city_changes=%llu done=%llu digest=%016llx\n", (unsigned long long)dg.n[0],
                          (unsigned long long)dg.n[1], (unsigned long long)dg.n[2], (unsigned long long)dg.h);
@@ -248,6 +277,11 @@ int main(int argc, char **argv)
         const bool have_cmp = have_opt && cli::compute_optimal_comparison(ctx, tour.total, problem, ot, cmp);
         if (json_mode) std::fputs(cli::format_solution_json(tour, false, have_cmp ? &cmp : nullptr).c_str(), stdout);
         else if (have_cmp) std::fputs(cli::format_optimal_comparison(tour.total, cmp).c_str(), stderr);
+        if (a.timing) {
+            std::fflush(stdout);
+            std::fprintf(stderr, "{\"timing_ms\": {\"read_input\": %.4f, \"tl_create\": %.4f, \"problem\": %.4f, \"runs\": [%s], \"output\": %.4f, \"main_total\": %.4f}, \"n\": %zu}\n",
+                         ms_read, ms_create, ms_problem, runs_json.c_str(), ms_since(t_out), ms_since(t_main), problem.cities.size());
+        }
         if (a.stats)
             for (const auto &o : outcomes)
                 std::fprintf(stderr, "stage %s: cost=%.5f sweeps=%llu candidates=%llu moves=%llu kernel_ms=%.3f wall_ms=%llu\n", solver_name(o.solver),

@@ -77,6 +77,14 @@ def test_bare_gpus_2_starts_two_ranks_itself():
     assert line["dry_launch"] is True and line["value"] is None          # a rehearsal never carries a number
     assert line["best_restart"] == 5                                      # the stub's winner lives on rank 1: its tour crossed ranks
     assert line["launcher"] == "torch.distributed.run"
+    # both readings of configs[3] in ONE line — R per GPU (weak, the headline) and 256 in all (strong) — and
+    # the note that says the strong one is flat by design
+    assert line["scaling"] == "weak"
+    assert line["weak_per_gpu"]["restarts_per_rank"] == 4 and line["weak_per_gpu"]["ms_per_step"] > 0
+    st = line["strong_256_total"]
+    assert st["restarts_per_rank"] == 128 and st["ms_per_step"] > 0 and st["stub_units_all_ranks"] == 256 * 2  # 2 steps
+    assert st["value"] is None and line["weak_per_gpu"]["value"] is None
+    assert "flat by design" in line["scaling_note"]
 
 
 def test_rank_count_mismatch_is_an_error_not_a_one_gpu_run():

@@ -37,10 +37,7 @@ def test_two_opt_size_limits(ctx):
         rc, again, c2, st2 = O.two_opt(xy, None, n, init=route, max_candidates=1)   # one reference sweep: nothing left to improve
         assert st2["moves"] == 0 and np.float32(c2).tobytes() == np.float32(sol.total).tobytes()
         assert sol.stats["candidates"] == sol.stats["sweeps"] * ((n - 3) * (n - 2) // 2)
-    # packed (i, j) keys: 65 535 cities is the last size (next test), 65 536 is refused before anything is launched
-    with pytest.raises(TA.TeelineGpuError) as e:
-        TA.two_opt.solve(prob(O.synth_xy(65536, seed=13)), None, None, None, ctx=ctx)
-    assert e.value.code == TA._capi.TL_ERR_UNSUPPORTED
+    # (the HBM-resident form has had 64-bit (i, j) keys since round 4: no 65 535 limit any more — test_two_opt_beyond_65535_cities)
     # multi-start / population are LDS-only
     with pytest.raises(TA.TeelineGpuError) as e:
         TA.two_opt.multistart(prob(O.synth_xy(nmax + 1, seed=11)), 2, seed=1, ctx=ctx)
@@ -61,6 +58,28 @@ def test_two_opt_largest_instance_from_a_good_tour(ctx):
     assert np.float32(sol.total).tobytes() == O.tour_length(xy, None, route).tobytes()
     rc, again, c2, st2 = O.two_opt(xy, None, n, init=route, max_candidates=1)
     assert st2["moves"] == 0
+
+
+def test_two_opt_beyond_65535_cities(ctx):
+    """the reference takes any n (`usize` indices, two_opt.rs:26-61); the HBM-resident form packed (i, j) into 32 bits
+    and stopped at 65 535.  With the 64-bit key: a 257 x 257 lattice (n = 66 049, every distance exact in f32) walked as a snake — an
+    optimal open path — with segments reversed near both ends of the tour, so that improving candidates sit at rows beyond 65 535 as
+    well as below; tour, cost bits, sweeps, moves and reversal count against the oracle (~25 s of one host core)."""
+    import teeline_amd as TA
+    m = 257
+    n = m * m
+    gx, gy = np.meshgrid(np.arange(m, dtype=np.float32), np.arange(m, dtype=np.float32))
+    xy = np.ascontiguousarray(np.stack([gx.ravel() * 3.0, gy.ravel() * 3.0], 1), dtype=np.float32)
+    snake = np.concatenate([(r * m + (np.arange(m) if r % 2 == 0 else np.arange(m)[::-1])) for r in range(m)]).astype(np.uint32)
+    init = snake.copy()
+    for a, b in ((40, 90), (300, 1500), (65540, 65600), (65700, 65990), (66000, 66040)):
+        init[a:b + 1] = init[a:b + 1][::-1].copy()
+    sol = TA.two_opt.solve(prob(xy), None, None, [int(v) for v in init], ctx=ctx)
+    rc, route, cost, st = O.two_opt(xy, None, n, init=init)
+    assert rc == 0 and st["moves"] >= 5
+    assert list(sol.route()) == route.tolist()
+    assert np.float32(sol.total).tobytes() == np.float32(cost).tobytes()
+    assert (sol.stats["sweeps"], sol.stats["moves"], sol.stats["reversed"], sol.stats["candidates"]) == (st["sweeps"], st["moves"], st["reversed"], st["candidates"])
 
 
 def test_matrix_form_size_limit(ctx):
@@ -96,18 +115,33 @@ def test_three_opt_and_or_opt_limits(ctx):
     rc, after = O.apply_3opt(nn, *mv[:4])
     assert rc == 0 and O.validate_tour(after)
     assert abs(len64(xy, nn) - len64(xy, after) - float(mv[4])) < 0.01 and mv[4] > 0
-    # Or-opt: the packed loop-order key 6 n^2 < 2^32 -> n <= 26 754
-    with pytest.raises(TA.TeelineGpuError) as e:
-        TA.or_opt.find_best_move(prob(O.synth_xy(26755, seed=7)), np.arange(26755), ctx=ctx)
-    assert e.value.code == TA._capi.TL_ERR_UNSUPPORTED
-    n = 26754
+    # Or-opt (round 4): the loop-order key 6 n^2 no longer has to fit 32 bits (n <= 26 754 before) and the pick kernel stages the tour
+    # in the workspace where it does not fit the LDS (n > ~40 700).  Limit + 1 against the oracle: an instance whose best move has a
+    # loop-order index beyond 2^32 — the NN tour of a random instance with a displaced PAIR of cities near the tour's end (seg_len 2
+    # rows start at index 2 n^2 > 2^32) — then a size beyond the LDS staging with an apply, checked through what the move must do.
+    n = 26800
     xy = O.synth_xy(n, seed=8)
-    rc, nn, cnn = O.nearest_neighbor(xy, None, n, 3)
-    mv = TA.or_opt.find_best_move(prob(xy), nn, ctx=ctx)
-    assert mv is not None and mv[0] < -1e-3
-    rc, after = O.apply_relocation(nn, mv[1], mv[3], mv[2], mv[4])
-    assert rc == 0 and O.validate_tour(after)
-    assert abs(len64(xy, after) - len64(xy, nn) - float(mv[0])) < 0.01
+    sol_nn = TA.nearest_neighbor.solve(prob(xy), ctx=ctx)
+    nn = np.asarray(sol_nn.route(), dtype=np.uint32)
+    path = np.concatenate([nn[:n - 300], nn[100:102], nn[n - 300:]])
+    path = np.concatenate([path[:100], path[102:]]).astype(np.uint32)  # cities nn[100], nn[101] now sit 300 from the end
+    assert O.validate_tour(path)
+    mv = TA.or_opt.find_best_move(prob(xy), path, ctx=ctx)
+    omv = O.or_opt_find_best_move(xy, None, path)
+    assert mv is not None and omv is not None
+    assert np.float32(mv[0]).tobytes() == np.float32(omv[0]).tobytes() and tuple(mv[1:]) == tuple(omv[1:])
+    order = (((mv[3] - 1) * n + mv[1]) * n + mv[2]) * 2 + int(mv[4])
+    assert order >= 2 ** 32, "the winning move's loop-order index needs the wide key"
+    # beyond the LDS staging of k_or_pick (4 n bytes): a convex instance (cities on a circle, in order) with one displaced pair —
+    # the best relocation puts it back, after which nothing improves: one move, two passes, the tour is the circle again
+    n = 41000
+    ang = (np.arange(n, dtype=np.float64) * (2.0 * np.pi / n))
+    cxy = np.ascontiguousarray(np.stack([1e5 * np.cos(ang), 1e5 * np.sin(ang)], 1), dtype=np.float32)
+    ident = np.arange(n, dtype=np.uint32)
+    moved = np.concatenate([ident[:100], ident[102:40000], ident[100:102], ident[40000:]]).astype(np.uint32)
+    sol = TA.or_opt.solve(prob(cxy), None, None, [int(v) for v in moved], ctx=ctx)
+    assert list(sol.route()) == ident.tolist() and sol.stats["moves"] == 1 and sol.stats["sweeps"] == 2
+    assert np.float32(sol.total).tobytes() == O.tour_length(cxy, None, ident).tobytes()
 
 
 def test_candidate_lists_and_nn_seed_at_large_n(ctx):
@@ -144,8 +178,33 @@ def test_lk_at_a_size_beyond_the_oracle(ctx):
     assert np.float32(sol.total).tobytes() == O.tour_length(xy, None, route).tobytes()
     # the result of an lk_pass is LK-optimal for its own candidate lists: one more pass of the oracle finds nothing ... from
     # the tour the LAST pass ended in, which is `route` only if the kick was rejected; so only when no kick improved
-    with pytest.raises(TA.TeelineGpuError):
-        TA.lin_kernighan.solve(prob(xy[:100]), TA.LKOptions(h, 7), None, None, ctx=ctx)   # max_depth > 6
+    with pytest.raises(TA.TeelineGpuError) as e:
+        TA.lin_kernighan.solve(prob(xy[:100]), TA.LKOptions(h, 17), None, None, ctx=ctx)   # max_depth > 16 (the deep build's chain capacity)
+    assert e.value.code == TA._capi.TL_ERR_UNSUPPORTED and "unbounded" in str(e.value)
+
+
+def test_lk_max_depth_beyond_the_register_build(ctx):
+    """the reference's max_depth is an unbounded usize (mod.rs:1252, recursion lin_kernighan.rs:265-340); up to 6
+    the chain lives in registers (lk.hip), 7..16 run the same kernels built with larger chain arrays (lk_deep.hip).  Limit + 1 and
+    beyond against the oracle on small instances with large options: every form of the scan (fused pick with parked walks at
+    k (k+1)^2 <= 1024, the flat form beyond, the chip-wide step from n = 1500, the single-workgroup cross-check)."""
+    import teeline_amd as TA
+    from test_gpu_lk import assert_same, gpu_lk, lattice
+    xy = O.synth_xy(300, seed=21)
+    for depth, k, epochs in ((7, 5, 6), (8, 3, 6), (10, 4, 4), (16, 2, 6), (12, 10, 2)):
+        assert_same(gpu_lk(ctx, xy, seed=2, epochs=epochs, max_depth=depth, n_nearest=k),
+                    O.lin_kernighan(xy, seed=2, epochs=epochs, max_depth=depth, n_nearest=k))
+    lat = lattice(9, 3)  # ties everywhere: long chains of equal-gain exchanges
+    assert_same(gpu_lk(ctx, lat, seed=5, epochs=10, max_depth=9, n_nearest=6), O.lin_kernighan(lat, seed=5, epochs=10, max_depth=9, n_nearest=6))
+    big = O.synth_xy(1600, seed=22)  # chip-wide step (n >= 1500)
+    assert_same(gpu_lk(ctx, big, seed=3, epochs=2, max_depth=7), O.lin_kernighan(big, seed=3, epochs=2, max_depth=7))
+    rnd = O.restart_perm(300, 5, 0)  # a random start: thousands of moves, many of them deep
+    assert_same(gpu_lk(ctx, xy, init=rnd, seed=4, epochs=2, max_depth=8), O.lin_kernighan(xy, init=rnd, seed=4, epochs=2, max_depth=8))
+    with TA.Context(0, TA.TL_FLAG_LK_ONE_WORKGROUP) as c1:
+        assert_same(gpu_lk(c1, xy, seed=2, epochs=3, max_depth=7), O.lin_kernighan(xy, seed=2, epochs=3, max_depth=7))
+    # a depth both builds take gives the same result in either (the deep build is the same source)
+    d6 = gpu_lk(ctx, xy, seed=9, epochs=5, max_depth=6)
+    assert_same(d6, O.lin_kernighan(xy, seed=9, epochs=5, max_depth=6))
 
 
 def test_empty_and_tiny_inputs_of_every_entry_point(ctx):
