@@ -295,7 +295,8 @@ def drop_in_end_to_end(TA, with_cpu):
             steady = min(runs[1:], key=lambda r: r["wall_ms"])
             extra = sum(r["wall_ms"] for r in runs[1:])
             row = {"n": int(len(xy)), "fresh_process_wall_ms": wall - extra,
-                   "process_start_and_exit_ms": wall - tj["main_total"], "read_input_ms": tj["read_input"], "tl_create_ms": tj["tl_create"],
+                   "process_start_ms": tj.get("before_main"), "process_exit_ms": wall - tj["main_total"] - max(tj.get("before_main", 0.0), 0.0),
+                   "read_input_ms": tj["read_input"], "tl_create_ms": tj["tl_create"],
                    "first_call_ms": runs[0]["wall_ms"], "steady_call_ms": steady["wall_ms"],
                    "steady_kernel_ms": sum(st["kernel_ms"] for st in steady["stages"]), "output_ms": tj["output"],
                    "first_call_stages_ms": {st["solver"]: st["wall_ms"] for st in runs[0]["stages"]},
@@ -309,9 +310,14 @@ def drop_in_end_to_end(TA, with_cpu):
                 assert f"{float(cost):.5f}" == row["cost"], f"{name}: CLI cost {row['cost']} != oracle {float(cost):.5f}"
                 row["fresh_process_vs_one_core"] = row["oracle_one_core_ms"] / row["fresh_process_wall_ms"]
                 row["steady_call_vs_one_core"] = row["oracle_one_core_ms"] / row["steady_call_ms"]
+            if n == 1002:  # what leaving through exit() (the HIP runtime's static teardown) would add: the CLI leaves through _exit
+                t0 = time.perf_counter()
+                subprocess.run(cmd + ["--full-exit"], capture_output=True, text=True, timeout=300)
+                row["wall_ms_with_full_exit"] = (time.perf_counter() - t0) * 1e3 - extra
             rows[name] = row
     out = {"command": "teeline_amd/teeline-gpu pipeline --steps=nn,2opt -i FILE --timing --repeat 3 (fresh process; best of two starts)", "instances": rows,
-           "note": "fresh_process_wall_ms = the process's wall with ONE run of the stage list (the two extra --repeat runs subtracted); "
+           "note": "fresh_process_wall_ms = the process's wall with ONE run of the stage list (the two extra --repeat runs subtracted); process_start_ms = "
+                   "exec to main() (dynamic loading of libamdhip64 and libteeline_gpu, 10 ms resolution), process_exit_ms = the rest outside main(); "
                    "first_call = cold run (code-object load of the kernels used, workspace allocation, LDS attribute), steady_call = a later run "
                    "in the same process (what a long-lived caller such as teeline-api pays per request)"}
     if O is not None:

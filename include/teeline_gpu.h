@@ -99,9 +99,11 @@ typedef enum tl_mode {
 #define TL_FLAG_LK_SEPARATE_PICK (1u << 11) /* tl_lk: pick and validate the pairs' first chains in a kernel of their own (k_lk_scan_pick) */
 #define TL_FLAG_LK_NO_GRAPH (1u << 12)      /* tl_lk: enqueue every round's kernels separately instead of replaying 64 rounds as one hipGraph */
 #define TL_FLAG_LK_SEPARATE_STEP (1u << 13) /* tl_lk: state machine (one workgroup) and tour rebuild as two kernels at every n */
+#define TL_FLAG_LK_SCAN_PERSIST (1u << 17)  /* tl_lk: the fused scan as a persistent grid striding over the window's pairs (round 4, VERDICT r03
+                                               item 3: measured 60.6 us per round against 47.0 for one workgroup per pair at n = 13 509) */
 #define TL_TUNE_ONLY_FLAGS                                                                                                        \
     (TL_FLAG_LK_NO_SPLIT | TL_FLAG_LK_SPLIT2 | TL_FLAG_LK_NO_SUBCHAINS | TL_FLAG_KNN_4LANES | TL_FLAG_KNN_1LANE | TL_FLAG_LK_SMALL | \
-     TL_FLAG_LK_SEPARATE_PICK | TL_FLAG_LK_NO_GRAPH | TL_FLAG_LK_SEPARATE_STEP)
+     TL_FLAG_LK_SEPARATE_PICK | TL_FLAG_LK_NO_GRAPH | TL_FLAG_LK_SEPARATE_STEP | TL_FLAG_LK_SCAN_PERSIST)
 /* The LDS-resident 2-opt kernel also counts the work its exact decision cascade really does (d_out_stats words 5..8: tile
  * bounds, candidates into L1 / L2 / L3).  Same results; slower (the counters are live scalar registers), so bench.py uses it for one
  * untimed launch only.  Counted: the form of one descent per CU (16 waves, float2 points); the narrower and the

@@ -25,6 +25,7 @@ TL_FLAG_LK_NO_GRAPH = 1 << 12  # tl_lk: no hipGraph replay of the round loop
 TL_FLAG_LK_SEPARATE_STEP = 1 << 13  # tl_lk: k_lk_control + k_lk_rebuild instead of the chip-wide step kernel
 TL_FLAG_2OPT_NT512, TL_FLAG_2OPT_NT256 = 1 << 14, 1 << 15  # LDS 2-opt: force the 8- / 4-wave form of a descent
 TL_FLAG_2OPT_FX = 1 << 16  # LDS 2-opt: grid-coordinate form of the tour (two tours of n = 10^4 per CU) wherever it is exact
+TL_FLAG_LK_SCAN_PERSIST = 1 << 17  # tl_lk (tuning build): the fused scan as a persistent grid striding over the window's pairs
 TL_FLAG_LK_SMALL = 1 << 9  # tl_lk: the LDS-resident single-workgroup form wherever it fits
 TL_FLAG_COUNT_WORK = 1 << 8  # the LDS 2-opt kernel also counts the work of its cascade (stats words 5..8); ~8 % slower
 TL_DM_PACKED_LOWER, TL_DM_FULL = 0, 1

@@ -854,6 +854,106 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     }
 }
 
+#ifdef TL_TUNE
+// MEASURED AND REJECTED (tuning build only): the fused three-level scan as a PERSISTENT grid (round 4): a fixed number of workgroups — what the chip
+// holds at 8 waves per SIMD — stride over the window's pairs instead of one workgroup per pair of the whole tour, of which all
+// beyond the window exited after one load (dispatching those 2n workgroups was 8-9 us of a 34.5 us scan at n = 13 509).  Same
+// per-pair code as k_lk_scan_sub<true>'s fused branch; the per-pair LDS words are double-buffered by the iteration's parity (a
+// workgroup's barriers keep its waves within one iteration of each other), and a pair whose index lies above an already posted
+// one does nothing (it cannot be the lowest valid pair: lin_kernighan.rs:345-389 takes the first in t1 order).
+#ifndef TL_LK_PERSIST_ASCENDING
+#define TL_LK_PERSIST_ASCENDING 0
+#endif
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lk_scan_persist(LkArgs G)
+{
+    if (G.state->finished) return;
+    const uint32_t n = G.n;
+    const uint32_t win = G.state->window;
+    __shared__ uint32_t s_minkey[2], s_qn[2];
+    __shared__ uint32_t s_q[2][kLkTailCap][kLkTailWords];
+    const uint32_t k1 = G.k + 1u, per = G.k * k1;
+    const uint32_t q1 = threadIdx.z, s1 = threadIdx.y, s2 = threadIdx.x;
+    const uint32_t sub = (q1 * k1 + s1) * k1 + s2;
+    const uint32_t nthr = blockDim.x * blockDim.y * blockDim.z;
+    // chip-wide step: which of the two tour buffers is current changes hands here — no kernel reads it during a scan
+    if (G.chip_step && blockIdx.x == 0u && sub == 0u) G.state->flip = G.state->flip_next;
+    LkView V{G.xy, G.cand, G.next, G.k, G.max_depth};
+    uint32_t par = 0u;
+    for (uint32_t blk = blockIdx.x; blk < win; blk += gridDim.x, par ^= 1u) {
+        const uint32_t idx = TL_LK_PERSIST_ASCENDING ? blk : win - 1u - blk;
+        if (sub == 0u) {
+            s_minkey[par] = 0xFFFFFFFFu;
+            s_qn[par] = 0u;
+        }
+        // (An early-out for pairs above an already posted one was measured and dropped: an agent-scope read of the key word by
+        //  every workgroup — one address for the whole chip — cost more than the skipped walks saved: +10 us per round with one lane
+        //  reading in front of the barrier, +27 us with every lane reading beside its own loads.)
+        const bool dead = false;
+        const uint32_t t1 = G.city_ids[idx >> 1];
+        const uint32_t t2 = (idx & 1u) ? G.prev[t1] : G.next[t1];
+        const float2 p1 = G.xy[t1], p2 = G.xy[t2];
+        TL_SYNC();
+        uint32_t chain[kLkMaxChain];
+        uint32_t clen = 0;
+        chain[0] = t1;
+        chain[1] = t2;
+        const float g0 = t1 == t2 ? 0.0f : dist(p1, p2);
+        uint32_t mykey = 0xFFFFFFFFu;
+        float2 p_open;
+        float gain;
+        const int st = dead ? 0 : lk_subsearch3_front<uint32_t>(V, chain, clen, p1, t2, p2, g0, q1, s1, s2, p_open, gain);
+        if (st == 1) mykey = sub * (per + 1u);
+        if (st == 2) {
+            const uint32_t slot = atomicAdd(&s_qn[par], 1u);
+            if (slot < kLkTailCap) {
+#pragma unroll
+                for (int t = 0; t < 6; ++t) s_q[par][slot][t] = chain[2 + t];
+                s_q[par][slot][6] = __float_as_uint(gain);
+                s_q[par][slot][7] = sub;
+                s_q[par][slot][8] = __float_as_uint(p_open.x);
+                s_q[par][slot][9] = __float_as_uint(p_open.y);
+            } else if (lk_chain_from3<uint32_t>(V, chain, clen, p1, p_open, gain)) {  // queue full: walk on alone
+                mykey = sub * (per + 1u);
+            }
+        }
+        TL_SYNC();
+        const uint32_t nq = s_qn[par] < kLkTailCap ? s_qn[par] : kLkTailCap;
+        for (uint32_t w = sub; w < nq * per; w += nthr) {
+            const uint32_t e = w / per, r = w - e * per, q3 = r / k1, s4 = r - q3 * k1;
+            const uint32_t key = s_q[par][e][7] * (per + 1u) + 1u + r;
+            if (key >= mykey) continue;  // this lane already holds an earlier chain
+            uint32_t c2[kLkMaxChain];
+            uint32_t l2 = 0;
+            c2[0] = t1;
+            c2[1] = t2;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) c2[2 + t] = s_q[par][e][t];
+            const float2 po = make_float2(__uint_as_float(s_q[par][e][8]), __uint_as_float(s_q[par][e][9]));
+            if (lk_tail_branch<uint32_t>(V, c2, l2, p1, po, __uint_as_float(s_q[par][e][6]), q3, s4)) {
+                mykey = key;
+                clen = l2;
+#pragma unroll
+                for (int t = 0; t < kLkMaxChain; ++t) chain[t] = c2[t];
+            }
+        }
+        if (mykey != 0xFFFFFFFFu) atomicMin(&s_minkey[par], mykey);
+        TL_SYNC();
+        if (mykey != 0xFFFFFFFFu && s_minkey[par] == mykey && chain_valid(chain, clen, G.tour, G.pos, n)) {
+            uint32_t *slot = G.chains + (size_t)idx * kLkSlot;
+            slot[0] = clen;
+            for (uint32_t t = 0; t < clen; ++t) slot[1 + t] = chain[t];
+            if (G.chip_step) {
+#pragma unroll 1
+                for (uint32_t t = 0; t < kLkMaxChain; ++t) slot[1 + kLkMaxChain + t] = t < clen ? G.pos[slot[1 + t]] : 0xFFFFFFFFu;
+                atomicMin(&G.state->key2[G.parity], idx);
+            } else {
+                atomicMin(&G.state->key, idx);
+            }
+        }
+    }
+}
+#endif  // TL_TUNE
+
 __global__ __launch_bounds__(256) void k_lk_scan_pick(LkArgs G)
 {
     LkState *S = G.state;
@@ -1202,6 +1302,13 @@ hipError_t launch_lk_round(const LkArgs &G0, hipStream_t s, uint32_t round)
     if (G.pairmin) {  // split scan
         const uint64_t lanes = (uint64_t)2u * G.n * G.k * (G.k + 1u) * (G.split_levels == 3u ? G.k + 1u : 1u);
         const uint32_t k1 = G.k + 1u, per_pair = lk_subs(G);
+#ifdef TL_TUNE
+        if (per_pair <= 1024u && G.persist_blocks && G.fused_pick && G.split_levels == 3u) {
+            // persistent form: a fixed grid strides over the window's pairs (k_lk_scan_persist)
+            const uint32_t grid = G.persist_blocks < 2u * G.n ? G.persist_blocks : 2u * G.n;
+            hipLaunchKernelGGL(k_lk_scan_persist, dim3(grid), dim3(k1, k1, G.k), 0, s, G);
+        } else
+#endif
         if (per_pair <= 1024u) {  // one workgroup per pair, thread coordinates = sub-search digits
             const dim3 blk = G.split_levels == 3u ? dim3(k1, k1, G.k) : dim3(k1, G.k, 1);
             hipLaunchKernelGGL(k_lk_scan_sub<true>, dim3(2u * G.n), blk, 0, s, G);

@@ -1414,7 +1414,7 @@ static int lk_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed
     if (const char *e = getenv("TL_LK_SMALL_NT")) small_nt = atoi(e);
 #endif
     const uint32_t tf = tune_flags(c);  // rejected forms: tuning build only
-    const uint32_t variant_flags = TL_FLAG_LK_ONE_WORKGROUP | TL_FLAG_LK_NO_SPLIT | TL_FLAG_LK_SPLIT2 | TL_FLAG_LK_NO_SUBCHAINS | TL_FLAG_LK_SEPARATE_PICK | TL_FLAG_LK_NO_GRAPH | TL_FLAG_LK_SEPARATE_STEP;
+    const uint32_t variant_flags = TL_FLAG_LK_ONE_WORKGROUP | TL_FLAG_LK_NO_SPLIT | TL_FLAG_LK_SPLIT2 | TL_FLAG_LK_NO_SUBCHAINS | TL_FLAG_LK_SEPARATE_PICK | TL_FLAG_LK_NO_GRAPH | TL_FLAG_LK_SEPARATE_STEP | TL_FLAG_LK_SCAN_PERSIST;
     const bool lk_small = ((tf & TL_FLAG_LK_SMALL) || (!((c->flags | tf) & variant_flags) && n <= small_max_n)) &&
                           lk_small_lds_bytes(n, k_small) + 4096 <= (size_t)c->lds_bytes;
     const bool multi_cu = !(c->flags & TL_FLAG_LK_ONE_WORKGROUP) && !lk_small;
@@ -1489,6 +1489,16 @@ static int lk_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed
     G.subchains = keep_sub ? (uint32_t *)(w + o_sub) : nullptr;
     G.split_levels = levels;
     G.fused_pick = fused_pick ? 1u : 0u;
+    // tuning build: the persistent scan grid (measured and rejected, DESIGN.md / NOTEBOOK.md): what the chip holds of these
+    // workgroups at 8 waves per SIMD (32 wave slots per CU), or TL_LK_PERSIST_BLOCKS from the environment
+    if (tf & TL_FLAG_LK_SCAN_PERSIST) {
+        const uint32_t wg_waves = (uint32_t)((k * (k + 1) * (k + 1) + 63) / 64);
+        const uint32_t per_cu = wg_waves ? 32u / wg_waves : 0u;
+        G.persist_blocks = (fused_pick && levels == 3u && per_cu) ? (uint32_t)c->cus * per_cu : 0u;
+#ifdef TL_TUNE
+        if (const char *e = getenv("TL_LK_PERSIST_BLOCKS")) G.persist_blocks = G.persist_blocks ? (uint32_t)atoi(e) : 0u;
+#endif
+    }
     G.chip_step = (fused_pick && levels == 3u && n >= 1500u && !(tf & TL_FLAG_LK_SEPARATE_STEP)) ? 1u : 0u;
     if (snap_dev) {
         G.snap = (uint32_t *)c->out_pos.p;

@@ -195,6 +195,7 @@ struct LkArgs {
     uint32_t *snap;         // optional [snap_cap][n]: every best tour the search settles on, in order — what the reference sends as
     float *snap_dist;       // PathUpdate(best_tour, best_dist) (lin_kernighan.rs:71,90) — and its best_dist; nullptr = not recorded
     uint32_t snap_cap;
+    uint32_t persist_blocks; // fused three-level scan: workgroups of the persistent grid (k_lk_scan_persist); 0 = one workgroup per pair
 };
 // form: 0 = default (16 lanes per city up to n = 32 K, 4 beyond), 4 = four lanes per city, 1 = one lane per city
 hipError_t launch_knn(const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, hipStream_t s, int form = 0);

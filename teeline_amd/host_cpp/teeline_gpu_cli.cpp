@@ -13,12 +13,15 @@
 //   unseeded thread RNG), --best-sweep (TL_MODE_BEST_SWEEP), --device N, --stats,
 //   --timing (one JSON line on stderr: milliseconds of main() by phase — read input, create context, every stage's wall and kernel
 //   time, output — what bench.py's drop_in_end_to_end reads), --repeat K (run the stage list K times in this process, the last
-//   run is printed: with --timing the first run is the cold one — code-object load, workspace allocation — the others steady)
+//   run is printed: with --timing the first run is the cold one — code-object load, workspace allocation — the others steady),
+//   --full-exit (leave through exit() with every static destructor — the HIP runtime's teardown, tens of milliseconds — instead of
+//   flushing and _exit(); the default leaves quickly: the process holds nothing but GPU memory, which the driver reclaims)
 #include "teeline_gpu.hpp"
 
 #include <chrono>
 #include <cstring>
 #include <iostream>
+#include <unistd.h>
 
 using namespace teeline;
 using namespace teeline::tsp;
@@ -27,7 +30,7 @@ namespace {
 
 struct Args {
     std::string cmd, solver, file, steps, optimal_tour, distance_type, output_format = "text";
-    bool no_seed = false, best = false, stats = false, short_list = false, progress_digest = false, timing = false;
+    bool no_seed = false, best = false, stats = false, short_list = false, progress_digest = false, timing = false, full_exit = false;
     int device = 0, repeat = 1;
     pipeline::StageOptions opt;
 };
@@ -104,6 +107,7 @@ Args parse(int argc, char **argv)
         else if (s == "--short") a.short_list = true;
         else if (s == "--progress-digest") a.progress_digest = true;
         else if (s == "--timing") a.timing = true;
+        else if (s == "--full-exit") a.full_exit = true;
         else if (s == "--repeat") a.repeat = std::max(1, std::stoi(val()));
         else usage_exit(("unexpected argument " + s).c_str());
     }
@@ -136,15 +140,53 @@ std::vector<Solvers> parse_steps(const std::string &csv)
     return v;
 }
 
+// milliseconds between the start of this process (field 22 of /proc/self/stat, clock ticks since boot) and now: what the dynamic
+// loader and the static initialisers of libamdhip64 / libteeline_gpu took before main() (10 ms resolution); -1 if unreadable
+double ms_since_process_start()
+{
+    std::ifstream st("/proc/self/stat");
+    std::string line;
+    if (!st || !std::getline(st, line)) return -1.0;
+    const size_t rp = line.rfind(')');
+    if (rp == std::string::npos) return -1.0;
+    std::istringstream rest(line.substr(rp + 2));
+    std::string tok;
+    for (int f = 3; f <= 22 && (rest >> tok); ++f)
+        if (f == 22) {
+            const double start_s = std::strtod(tok.c_str(), nullptr) / (double)sysconf(_SC_CLK_TCK);
+            std::ifstream up("/proc/uptime");
+            double now_s = 0.0;
+            if (!(up >> now_s)) return -1.0;
+            return (now_s - start_s) * 1e3;
+        }
+    return -1.0;
+}
+
+bool g_full_exit = false;
+
+int run(int argc, char **argv);
+
 }  // namespace
 
 int main(int argc, char **argv)
 {
+    const int rc = run(argc, argv);
+    std::fflush(stdout);
+    std::fflush(stderr);
+    if (!g_full_exit) _exit(rc);  // skip the HIP runtime's static teardown (measured: tests/probes/create_cost_probe.cpp)
+    return rc;
+}
+
+namespace {
+int run(int argc, char **argv)
+{
     using clk = std::chrono::steady_clock;
+    const double ms_before_main = ms_since_process_start();
     const auto t_main = clk::now();
     auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
     try {
         Args a = parse(argc, argv);
+        g_full_exit = a.full_exit;
         if (a.cmd == "solvers") {  // `teeline solvers [--short]`, restricted to what this build runs
             static const char *rows[][3] = {{"nearest_neighbor", "nn", "heuristic"}, {"two_opt", "2opt", "heuristic"}, {"three_opt", "3opt", "heuristic"},
                                             {"or_opt", "or-opt", "heuristic"}, {"lin_kernighan", "lk", "heuristic"}, {"random_shuffle", "shuffle", "heuristic"}};
@@ -279,8 +321,8 @@ int main(int argc, char **argv)
         else if (have_cmp) std::fputs(cli::format_optimal_comparison(tour.total, cmp).c_str(), stderr);
         if (a.timing) {
             std::fflush(stdout);
-            std::fprintf(stderr, "{\"timing_ms\": {\"read_input\": %.4f, \"tl_create\": %.4f, \"problem\": %.4f, \"runs\": [%s], \"output\": %.4f, \"main_total\": %.4f}, \"n\": %zu}\n",
-                         ms_read, ms_create, ms_problem, runs_json.c_str(), ms_since(t_out), ms_since(t_main), problem.cities.size());
+            std::fprintf(stderr, "{\"timing_ms\": {\"before_main\": %.1f, \"read_input\": %.4f, \"tl_create\": %.4f, \"problem\": %.4f, \"runs\": [%s], \"output\": %.4f, \"main_total\": %.4f}, \"n\": %zu}\n",
+                         ms_before_main, ms_read, ms_create, ms_problem, runs_json.c_str(), ms_since(t_out), ms_since(t_main), problem.cities.size());
         }
         if (a.stats)
             for (const auto &o : outcomes)
@@ -296,3 +338,4 @@ int main(int argc, char **argv)
         return 1;
     }
 }
+}  // namespace

@@ -117,14 +117,15 @@ def test_three_opt_and_or_opt_limits(ctx):
     assert abs(len64(xy, nn) - len64(xy, after) - float(mv[4])) < 0.01 and mv[4] > 0
     # Or-opt (round 4): the loop-order key 6 n^2 no longer has to fit 32 bits (n <= 26 754 before) and the pick kernel stages the tour
     # in the workspace where it does not fit the LDS (n > ~40 700).  Limit + 1 against the oracle: an instance whose best move has a
-    # loop-order index beyond 2^32 — the NN tour of a random instance with a displaced PAIR of cities near the tour's end (seg_len 2
-    # rows start at index 2 n^2 > 2^32) — then a size beyond the LDS staging with an apply, checked through what the move must do.
+    # loop-order index beyond 2^32 — the NN tour of a random instance with a displaced TRIPLE of cities near the tour's end (the
+    # index is ((seg_len - 1) n + i) n + j) * 2: only seg_len 3 rows with i near n pass 2^32 at this size) — then a size beyond
+    # the LDS staging with an apply, checked through what the move must do.
     n = 26800
     xy = O.synth_xy(n, seed=8)
     sol_nn = TA.nearest_neighbor.solve(prob(xy), ctx=ctx)
     nn = np.asarray(sol_nn.route(), dtype=np.uint32)
-    path = np.concatenate([nn[:n - 300], nn[100:102], nn[n - 300:]])
-    path = np.concatenate([path[:100], path[102:]]).astype(np.uint32)  # cities nn[100], nn[101] now sit 300 from the end
+    path = np.concatenate([nn[:n - 40], nn[100:103], nn[n - 40:]])
+    path = np.concatenate([path[:100], path[103:]]).astype(np.uint32)  # cities nn[100..102] now sit 40 from the end
     assert O.validate_tour(path)
     mv = TA.or_opt.find_best_move(prob(xy), path, ctx=ctx)
     omv = O.or_opt_find_best_move(xy, None, path)

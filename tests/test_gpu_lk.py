@@ -198,7 +198,7 @@ def test_lk_variants_are_identical(tsplib_dir):
     tri = np.array([[0, 0], [1, 0], [0.5, 1]], np.float32)
     import teeline_amd as TA
     for flag in (TA.TL_FLAG_LK_NO_SPLIT, TA.TL_FLAG_LK_ONE_WORKGROUP, TA.TL_FLAG_LK_NO_SUBCHAINS, TA.TL_FLAG_LK_SPLIT2, TA.TL_FLAG_LK_SMALL,
-                 TA.TL_FLAG_LK_SEPARATE_PICK, TA.TL_FLAG_LK_SEPARATE_PICK | TA.TL_FLAG_LK_SPLIT2, TA.TL_FLAG_LK_NO_GRAPH, TA.TL_FLAG_LK_SEPARATE_STEP):
+                 TA.TL_FLAG_LK_SEPARATE_PICK, TA.TL_FLAG_LK_SEPARATE_PICK | TA.TL_FLAG_LK_SPLIT2, TA.TL_FLAG_LK_NO_GRAPH, TA.TL_FLAG_LK_SEPARATE_STEP, TA.TL_FLAG_LK_SCAN_PERSIST):
         with TA.Context(0, flag) as ctx:
             for seed in (1, 2):
                 assert_same(gpu_lk(ctx, xy, seed=seed), O.lin_kernighan(xy, seed=seed))
@@ -212,7 +212,7 @@ def test_lk_variants_are_identical(tsplib_dir):
     want = O.lin_kernighan(big, seed=5, epochs=8)
     # n >= 1500: the chip-wide step kernel (state machine + move application in one launch) is the default;
     # TL_FLAG_LK_SEPARATE_STEP / _SEPARATE_PICK / _SPLIT2 run the two-kernel forms
-    for flag in (0, TA.TL_FLAG_LK_SEPARATE_STEP, TA.TL_FLAG_LK_SEPARATE_PICK, TA.TL_FLAG_LK_SPLIT2, TA.TL_FLAG_LK_NO_GRAPH):
+    for flag in (0, TA.TL_FLAG_LK_SEPARATE_STEP, TA.TL_FLAG_LK_SEPARATE_PICK, TA.TL_FLAG_LK_SPLIT2, TA.TL_FLAG_LK_NO_GRAPH, TA.TL_FLAG_LK_SCAN_PERSIST):
         with TA.Context(0, flag) as ctx:
             assert_same(gpu_lk(ctx, big, seed=5, epochs=8), want)
 

@@ -159,6 +159,19 @@ def test_matrix_form_equals_on_the_fly_form_pr1002_size(ctx):
     assert_same(b, O.two_opt(None, packed, n, init=rp), n)
 
 
+@pytest.mark.parametrize("n,start", [(1002, "identity"), (1002, "nn"), (1500, "random"), (3000, "random"), (9000, "random")])
+def test_matrix_form_deferred_rows(ctx, n, start):
+    """Round 4: the matrix-form kernel defers the reversals of a dense row to the row's end and composes them (two_opt_dm.hip
+    dm_flush: every element and every edge length moves once; the k + 1 new edges come from the hits' lanes).  Starts with moves
+    every few candidates (identity, random), rows with many hits (more than one hit-register's worth: a mid-row flush) and, at
+    n = 9 000, regions beyond what a composed flush holds in registers (8 192 positions: reversed hit by hit).  Tour, cost bits,
+    sweeps, moves, reversal count against the oracle on the same matrix."""
+    xy = O.synth_xy(n, seed=31)
+    packed = O.dm_build_packed(xy)
+    init = None if start == "identity" else (O.nearest_neighbor(xy, None, n, 3)[1] if start == "nn" else O.restart_perm(n, 17, 0))
+    assert_same(gpu_two_opt(ctx, None, packed, n, init), O.two_opt(None, packed, n, init=init), n)
+
+
 def test_multistart_matches_per_restart_oracle(ctx):
     import teeline_amd as TA
     n, R, seed = 600, 12, 4242
