@@ -267,6 +267,13 @@ def drop_in_end_to_end(TA, with_cpu):
     O = None
     if with_cpu:
         import _oracle as O
+    # what starting ANY process costs from here (this interpreter is a large parent: fork + exec + pipes), measured with /bin/true
+    spawn = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        subprocess.run(["/bin/true"], capture_output=True)
+        spawn.append((time.perf_counter() - t0) * 1e3)
+    spawn_ms = float(np.median(spawn))
     rows = {}
     sizes = [("berlin52", None), ("synthetic_n200", 200), ("synthetic_n500", 500), ("synthetic_n1002", 1002), ("synthetic_n2000", 2000),
              ("synthetic_n5000", 5000), ("synthetic_n10000", 10000)]
@@ -294,8 +301,8 @@ def drop_in_end_to_end(TA, with_cpu):
             runs = tj["runs"]
             steady = min(runs[1:], key=lambda r: r["wall_ms"])
             extra = sum(r["wall_ms"] for r in runs[1:])
-            row = {"n": int(len(xy)), "fresh_process_wall_ms": wall - extra,
-                   "process_start_ms": tj.get("before_main"), "process_exit_ms": wall - tj["main_total"] - max(tj.get("before_main", 0.0), 0.0),
+            row = {"n": int(len(xy)), "fresh_process_wall_ms": wall - extra - spawn_ms,
+                   "process_start_ms": tj.get("before_main"), "process_exit_ms": wall - spawn_ms - tj["main_total"] - max(tj.get("before_main", 0.0), 0.0),
                    "read_input_ms": tj["read_input"], "tl_create_ms": tj["tl_create"],
                    "first_call_ms": runs[0]["wall_ms"], "steady_call_ms": steady["wall_ms"],
                    "steady_kernel_ms": sum(st["kernel_ms"] for st in steady["stages"]), "output_ms": tj["output"],
@@ -313,10 +320,12 @@ def drop_in_end_to_end(TA, with_cpu):
             if n == 1002:  # what leaving through exit() (the HIP runtime's static teardown) would add: the CLI leaves through _exit
                 t0 = time.perf_counter()
                 subprocess.run(cmd + ["--full-exit"], capture_output=True, text=True, timeout=300)
-                row["wall_ms_with_full_exit"] = (time.perf_counter() - t0) * 1e3 - extra
+                row["wall_ms_with_full_exit"] = (time.perf_counter() - t0) * 1e3 - extra - spawn_ms
             rows[name] = row
     out = {"command": "teeline_amd/teeline-gpu pipeline --steps=nn,2opt -i FILE --timing --repeat 3 (fresh process; best of two starts)", "instances": rows,
-           "note": "fresh_process_wall_ms = the process's wall with ONE run of the stage list (the two extra --repeat runs subtracted); process_start_ms = "
+           "spawn_overhead_ms": spawn_ms,
+           "note": "fresh_process_wall_ms = the process's wall with ONE run of the stage list (the two extra --repeat runs and spawn_overhead_ms — what "
+                   "starting /bin/true costs from this interpreter — subtracted); process_start_ms = "
                    "exec to main() (dynamic loading of libamdhip64 and libteeline_gpu, 10 ms resolution), process_exit_ms = the rest outside main(); "
                    "first_call = cold run (code-object load of the kernels used, workspace allocation, LDS attribute), steady_call = a later run "
                    "in the same process (what a long-lived caller such as teeline-api pays per request)"}
@@ -767,6 +776,19 @@ def main():
                 via[name] = {"kernel_ms": sc.stats["kernel_ms"], "candidates_per_s": sc.stats["candidates"] / (sc.stats["kernel_ms"] * 1e-3)}
             cfg1["drop_in_route_for_euc2d_problems"] = dict(via, note="the matrix of an EUC_2D problem equals the on-the-fly f32 distances bit for bit; "
                                                                       "the shim checks that once per call (tl_dm_is_euc2d) and runs the coordinate kernel")
+            # what a move costs here against what it can cost with one step per move.  The floor is MEASURED: the
+            # coordinate kernel walks the very same descent (same tours, asserted above) with every operand in LDS — its time per
+            # move is what the step around a move costs on this design with no matrix at all; 10^9 candidates/s from the identity
+            # start would need 3.5e6 candidates / 1e9 = 3.5 ms over 5 003 moves = 0.70 us per move, below that floor.
+            mv_id = max(cfg1["identity_start"]["moves"], 1)
+            cfg1["us_per_move_identity_start"] = cfg1["identity_start"]["kernel_ms"] * 1e3 / mv_id
+            cfg1["floor_us_per_move"] = via["identity_start"]["kernel_ms"] * 1e3 / mv_id
+            cfg1["us_per_move_needed_for_1e9_per_s"] = cfg1["identity_start"]["sweeps"] * ((n2 - 3) * (n2 - 2) // 2) / 1e9 * 1e6 / mv_id
+            cfg1["floor_note"] = ("floor_us_per_move = the coordinate kernel's time per move on the same descent (all operands in LDS, measured in this "
+                                  "run); the matrix form adds one dependent L2 gather of the new b's row per move.  The 1e9 candidates/s target from the "
+                                  "identity start needs us_per_move_needed_for_1e9_per_s, which is below the floor: unreachable with one step per move "
+                                  "(round 4 built the coordinate kernel's deferred-row structure for this kernel — commit b6c7f95 — parity green, 7.82 ms "
+                                  "against 7.74: not kept, NOTEBOOK.md)")
             cfg1["instance"] = label2
             cfg1["note"] = ("one descent = one workgroup on ONE CU; latency-bound (a step per move), the 4 MB full matrix stays in L2/MALL; "
                             "kernel_ms includes the packed -> full expansion")

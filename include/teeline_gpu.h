@@ -246,6 +246,16 @@ int tl_lk_trace(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed
                 const tl_lk_opts *opts, uint64_t seed, uint32_t *out_pos, float *out_cost, tl_stats *stats,
                 uint32_t *snap_pos, float *snap_dist, uint32_t snap_cap, uint32_t *snap_len);
 
+/* tl_lk_live (ABI v5) — the same messages WHILE the search runs: `progress` is called on the calling thread, between two polls of
+ * the device-side search (every 64 rounds: a few milliseconds at n = 13 509), once per best tour the ILS settles on, in order,
+ * with the tour (n positions, valid during the call only) and its best_dist — what teeline-qt's channel shows of a multi-second
+ * run (teeline-qt/src/solver_engine.rs:412-434).  The callback must not call into the same context (TL_ERR_BUSY does not apply:
+ * it is the owning thread) and should return quickly — the GPU idles while it runs.  With TL_FLAG_LK_ONE_WORKGROUP: one call, the
+ * final tour.  (The 2-opt / 3-opt / Or-opt descents are single launches of milliseconds: their messages are replayed, above.) */
+typedef void (*tl_lk_progress_fn)(void *user, const uint32_t *best_pos, uint32_t n, float best_dist);
+int tl_lk_live(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos, const tl_lk_opts *opts,
+               uint64_t seed, uint32_t *out_pos, float *out_cost, tl_stats *stats, tl_lk_progress_fn progress, void *user);
+
 /* ---- LK candidate lists: replaces lin_kernighan::build_candidates (lin_kernighan.rs:12-27) -- */
 /* out: n x min(k, n-1) u32 — the k-NN buffer of the reference's kd-tree query per city (kdtree.rs:193-212, mod.rs:1839-1889):
  * ascending f32 distance, equal distances in the tree's visiting order.  The tree is the reference's wherever its median

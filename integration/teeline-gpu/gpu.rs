@@ -14,7 +14,7 @@
 //! Behaviour that differs from the CPU functions, all of it documented in INTEGRATION.md:
 //!   * progress: every solver sends the reference's exact message sequence — CityChange per outer i and PathUpdate per move
 //!     (2-opt), PathUpdate per applied move (3-opt, or-opt), PathUpdate per best tour (LK), CityChange + growing path per step (NN) —
-//!     replayed from the records of `tl_two_opt_trace` / `tl_three_opt_trace` / `tl_or_opt_trace` / `tl_lk_trace` (NN: from the
+//!     replayed from the records of `tl_two_opt_trace` / `tl_three_opt_trace` / `tl_or_opt_trace` (LK: sent live through `tl_lk_live`; NN: from the
 //!     finished walk) AFTER the kernels return, not while they run — only the Qt front-end passes a sender;
 //!   * a library error (no gfx950 device, HIP failure) panics with the library's message, like the `.expect(..)`s of the CPU
 //!     code do on bad input: the solver functions are infallible by signature;
@@ -325,15 +325,15 @@ pub mod lin_kernighan {
             .and_then(|v| v.parse::<u64>().ok())
             .unwrap_or_else(|| rand::rng().random::<u64>());
         // lin_kernighan.rs sends PathUpdate(best_tour, best_dist) after the first lk_pass and for every improving epoch, never Done
-        // (:71,:90; nothing when n < 4, :57-59): with a channel the device-side state machine lists exactly those.
+        // (:71,:90; nothing when n < 4, :57-59): with a channel the device-side state machine files exactly those and tl_lk_live hands
+        // them over WHILE the search runs — teeline-qt sees a multi-second run progress as it does with the CPU solver.
         if let (Some(tx), true) = (progress_tx, problem.cities.len() >= 4) {
-            let (t, snaps) = unwrap_gpu("lin_kernighan (gpu)", ffi::with_context(|ctx| {
+            let t = unwrap_gpu("lin_kernighan (gpu)", ffi::with_context(|ctx| {
                 let dm = io.matrix(ctx)?;
-                ctx.lin_kernighan_trace(&io.xy, dm, init.as_deref(), lk, seed)
+                ctx.lin_kernighan_live(&io.xy, dm, init.as_deref(), lk, seed, |pos, dist| {
+                    let _ = tx.send(ProgressMessage::PathUpdate(Route::new(&io.ids(pos)), dist));
+                })
             }));
-            for (pos, dist) in &snaps {
-                let _ = tx.send(ProgressMessage::PathUpdate(Route::new(&io.ids(pos)), *dist));
-            }
             return finish(problem, &io, &t, None, false);
         }
         let t = unwrap_gpu("lin_kernighan (gpu)", ffi::with_context(|ctx| {

@@ -16,7 +16,7 @@
 //! There is no CPU fallback: without a gfx950 device every call returns `Err(Error { code: NoDevice, .. })`.
 
 use std::cell::RefCell;
-use std::ffi::{c_char, c_int, CStr};
+use std::ffi::{c_char, c_int, c_void, CStr};
 use std::fmt;
 use std::ptr;
 
@@ -49,6 +49,9 @@ pub struct LkOpts {
     pub max_depth: u32,
 }
 
+/// `tl_lk_progress_fn` (include/teeline_gpu.h): called by `tl_lk_live` on the calling thread while the search runs.
+pub type LkProgressFn = unsafe extern "C" fn(user: *mut c_void, best_pos: *const u32, n: u32, best_dist: f32);
+
 pub const MODE_REF_ORDER: c_int = 0;
 pub const MODE_BEST_SWEEP: c_int = 1;
 pub const DM_PACKED_LOWER: c_int = 0;
@@ -74,6 +77,8 @@ unsafe extern "C" {
     fn tl_lk_trace(ctx: *mut TlCtx, xy: *const f32, n: u32, dm_packed: *const f32, init_pos: *const u32, opts: *const LkOpts, seed: u64,
                    out_pos: *mut u32, out_cost: *mut f32, stats: *mut Stats, snap_pos: *mut u32, snap_dist: *mut f32, snap_cap: u32,
                    snap_len: *mut u32) -> c_int;
+    fn tl_lk_live(ctx: *mut TlCtx, xy: *const f32, n: u32, dm_packed: *const f32, init_pos: *const u32, opts: *const LkOpts, seed: u64,
+                  out_pos: *mut u32, out_cost: *mut f32, stats: *mut Stats, progress: LkProgressFn, user: *mut c_void) -> c_int;
     fn tl_three_opt(ctx: *mut TlCtx, xy: *const f32, n: u32, dm_packed: *const f32, init_pos: *const u32,
                     out_pos: *mut u32, out_cost: *mut f32, stats: *mut Stats) -> c_int;
     fn tl_or_opt(ctx: *mut TlCtx, xy: *const f32, n: u32, dm_packed: *const f32, init_pos: *const u32,
@@ -333,6 +338,30 @@ impl Context {
             }
             cap = len; // deterministic for a seed: once more with room for every snapshot
         }
+    }
+
+    /// `lin_kernighan::solve` with `on_best(best_tour positions, best_dist)` called WHILE the search runs, once per best tour the ILS
+    /// settles on, in order (lin_kernighan.rs:71,90) — `tl_lk_live`; what `gpu::lin_kernighan::solve` forwards to its channel.
+    pub fn lin_kernighan_live<F: FnMut(&[u32], f32)>(&self, xy: &[f32], dm_packed: Option<&[f32]>, init_pos: Option<&[u32]>, opts: LkOpts, seed: u64,
+                                                     mut on_best: F) -> Result<Tour, Error> {
+        unsafe extern "C" fn trampoline<F: FnMut(&[u32], f32)>(user: *mut c_void, best_pos: *const u32, n: u32, best_dist: f32) {
+            // SAFETY: `user` is the `&mut F` handed to tl_lk_live below, alive for the whole call; best_pos holds n positions for the
+            // duration of this callback.  A panic must not unwind into C: it aborts the process, like the reference's panics do not.
+            let f = unsafe { &mut *(user as *mut F) };
+            let tour = unsafe { std::slice::from_raw_parts(best_pos, n as usize) };
+            if std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| f(tour, best_dist))).is_err() {
+                std::process::abort();
+            }
+        }
+        let n = Self::n_of(xy);
+        Self::check_inputs(n, dm_packed, init_pos);
+        let mut t = Tour { pos: vec![0u32; n as usize], cost: 0.0, stats: Stats::default() };
+        // SAFETY: as in two_opt; the callback and its state outlive the call.
+        let rc = unsafe {
+            tl_lk_live(self.raw, xy.as_ptr(), n, opt_ptr(dm_packed), opt_ptr(init_pos), &opts, seed, t.pos.as_mut_ptr(), &mut t.cost, &mut t.stats,
+                       trampoline::<F>, &mut on_best as *mut F as *mut c_void)
+        };
+        self.check(rc).map(|_| t)
     }
 
     /// `three_opt::solve` (three_opt.rs:16-51).

@@ -39,6 +39,7 @@ SYMBOLS = [
     "tl_two_opt_batch_dev", "tl_last_kernel_ms", "tl_dm_build_dev", "tl_build_candidates", "tl_nearest_neighbor",
     "tl_or_opt", "tl_or_opt_find_best_move", "tl_selftest_sqrt", "tl_two_opt_population", "tl_dm_is_euc2d",
     "tl_two_opt_multistart_devices", "tl_two_opt_trace", "tl_three_opt_trace", "tl_lk_trace", "tl_or_opt_trace",
+    "tl_lk_live",
 ]
 
 
@@ -53,6 +54,10 @@ class TlStats(C.Structure):
 class TlLkOpts(C.Structure):
     _fields_ = [("epochs", C.c_uint32), ("platoo_epochs", C.c_uint32), ("n_nearest", C.c_uint32),
                 ("max_depth", C.c_uint32)]
+
+
+# tl_lk_progress_fn: void (*)(void *user, const uint32_t *best_pos, uint32_t n, float best_dist)
+LK_PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.c_float)
 
 
 class TeelineGpuError(RuntimeError):
@@ -106,6 +111,7 @@ def load():
     L.tl_three_opt_trace.argtypes = [vp, vp, u32, vp, vp, vp, f32p, C.POINTER(TlStats), vp, u32, C.POINTER(u32)]
     L.tl_or_opt_trace.argtypes = [vp, vp, u32, vp, vp, vp, f32p, C.POINTER(TlStats), vp, u32, C.POINTER(u32)]
     L.tl_lk_trace.argtypes = [vp, vp, u32, vp, vp, C.POINTER(TlLkOpts), u64, vp, f32p, C.POINTER(TlStats), vp, vp, u32, C.POINTER(u32)]
+    L.tl_lk_live.argtypes = [vp, vp, u32, vp, vp, C.POINTER(TlLkOpts), u64, vp, f32p, C.POINTER(TlStats), LK_PROGRESS_FN, vp]
     L.tl_pack_cost_key.argtypes = [C.c_float, u32]
     L.tl_pack_cost_key.restype = u64
     L.tl_two_opt_batch_dev.argtypes = [vp, vp, u32, vp, u64, u32, u32, i32, vp, vp, vp, vp]

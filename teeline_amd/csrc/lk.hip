@@ -1047,9 +1047,10 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
         if (!G.snap) return;
         const uint32_t sidx = S->snaps;
         TL_SYNC();  // every thread has read the count
-        if (sidx < G.snap_cap) {
-            for (uint32_t r = tid; r < n; r += kLkNT) G.snap[(size_t)sidx * n + r] = t[r];
-            if (tid == 0) G.snap_dist[sidx] = d;
+        if (G.snap_ring || sidx < G.snap_cap) {  // ring (tl_lk_live: the host drains it between polls) or a list of the first snap_cap
+            const uint32_t at = G.snap_ring ? sidx % G.snap_cap : sidx;
+            for (uint32_t r = tid; r < n; r += kLkNT) G.snap[(size_t)at * n + r] = t[r];
+            if (tid == 0) G.snap_dist[at] = d;
         }
         if (tid == 0) S->snaps = sidx + 1u;
     };

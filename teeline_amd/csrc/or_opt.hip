@@ -250,7 +250,8 @@ hipError_t launch_or_opt_pass(const OrOptArgs &A, bool dm, int apply, hipStream_
     }
     hipError_t e = allow_max_lds(reinterpret_cast<const void *>(k_or_pick));
     if (e != hipSuccess) return e;
-    const bool stage_lds = (size_t)A.n * 4 + 1024 <= (size_t)lds_budget;
+    // LDS up to 256 cities, the workspace beyond: both forms run in the parity tests at sizes the oracle affords
+    const bool stage_lds = A.n <= 256u && (size_t)A.n * 4 + 1024 <= (size_t)lds_budget;
     hipLaunchKernelGGL(k_or_pick, dim3(1), dim3(1024), stage_lds ? (size_t)A.n * 4 : 0, s, A, nblocks, apply, stage_lds ? 1 : 0);
     return hipGetLastError();
 }

@@ -178,10 +178,11 @@ __global__ __launch_bounds__(kT3) void k_three_opt_scan(ThreeOptArgs A)
 }
 
 // one workgroup: reduce the partials, publish the move, optionally apply it (apply_3opt, three_opt.rs:186-218)
-__global__ __launch_bounds__(1024) void k_three_opt_pick(ThreeOptArgs A, uint32_t nblocks, int apply)
+__global__ __launch_bounds__(1024) void k_three_opt_pick(ThreeOptArgs A, uint32_t nblocks, int apply, int stage_lds)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *tmp = reinterpret_cast<uint32_t *>(smem);  // n entries
+    // the two segments of the move: in LDS where n entries fit, else in the workspace (one workgroup: its own barrier orders the copy)
+    uint32_t *tmp = stage_lds ? reinterpret_cast<uint32_t *>(smem) : A.scratch;
     __shared__ float r_s[16];
     __shared__ uint32_t r_ij[16], r_kc[16];
     const uint32_t tid = threadIdx.x;
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(1024) void k_three_opt_pick(ThreeOptArgs A, uint32_
 
 size_t three_opt_scan_lds_bytes(uint32_t) { return 0; }  // the scan keeps its rows in registers
 
-hipError_t launch_three_opt_pass(const ThreeOptArgs &A, uint32_t nblocks, bool dm, int apply, hipStream_t s)
+hipError_t launch_three_opt_pass(const ThreeOptArgs &A, uint32_t nblocks, bool dm, int apply, hipStream_t s, int lds_budget)
 {
     const uint32_t pg = (A.n + 256u) / 256u;
     const size_t lds = three_opt_scan_lds_bytes(A.n);
@@ -253,7 +254,10 @@ hipError_t launch_three_opt_pass(const ThreeOptArgs &A, uint32_t nblocks, bool d
     hipLaunchKernelGGL(k_three_opt_scan, dim3(nblocks), dim3(kT3), lds, s, A);
     e = allow_max_lds(reinterpret_cast<const void *>(k_three_opt_pick));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_three_opt_pick, dim3(1), dim3(1024), (size_t)A.n * 4, s, A, nblocks, apply);
+    // LDS up to 256 cities, the workspace beyond: both forms run in the parity tests at sizes the oracle affords (the copy is one
+    // workgroup's and L2-resident either way; the scan is what a pass costs)
+    const bool stage_lds = A.n <= 256u && (size_t)A.n * 4 + 2048 <= (size_t)lds_budget;
+    hipLaunchKernelGGL(k_three_opt_pick, dim3(1), dim3(1024), stage_lds ? (size_t)A.n * 4 : 0, s, A, nblocks, apply, stage_lds ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -128,11 +128,12 @@ struct ThreeOptArgs {
     ThreeOptBest *partials;      // one per scan workgroup
     ThreeOptBest *best;          // result of the pass
     uint64_t *counters;          // passes, moves
+    uint32_t *scratch;           // [n] the move's two segments in k_three_opt_pick where they do not fit the LDS
     uint32_t n;
     uint32_t jc;                 // j values per scan workgroup
 };
 size_t three_opt_scan_lds_bytes(uint32_t n);
-hipError_t launch_three_opt_pass(const ThreeOptArgs &A, uint32_t nblocks, bool dm, int apply, hipStream_t s);
+hipError_t launch_three_opt_pass(const ThreeOptArgs &A, uint32_t nblocks, bool dm, int apply, hipStream_t s, int lds_budget);
 
 // or_opt.hip
 struct OrOptBest {
@@ -195,6 +196,7 @@ struct LkArgs {
     uint32_t *snap;         // optional [snap_cap][n]: every best tour the search settles on, in order — what the reference sends as
     float *snap_dist;       // PathUpdate(best_tour, best_dist) (lin_kernighan.rs:71,90) — and its best_dist; nullptr = not recorded
     uint32_t snap_cap;
+    uint32_t snap_ring;      // snap is a ring of snap_cap slots (tl_lk_live) instead of a list of the first snap_cap
     uint32_t persist_blocks; // fused three-level scan: workgroups of the persistent grid (k_lk_scan_persist); 0 = one workgroup per pair
 };
 // form: 0 = default (16 lanes per city up to n = 32 K, 4 beyond), 4 = four lanes per city, 1 = one lane per city

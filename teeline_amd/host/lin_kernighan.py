@@ -7,8 +7,9 @@ import numpy as np
 def solve(problem, opts=None, progress_tx=None, init_tour=None, *, ctx=None, seed=1):
     """progress_tx: optional callable(kind, payload) — the reference's mpsc::Sender<ProgressMessage>.  The reference sends
     PathUpdate(best_tour, best_dist) after the first lk_pass and after every epoch that improves on it, and no Done
-    (lin_kernighan.rs:71,90; nothing when n < 4, :57-59).  With a channel the solve goes through tl_lk_trace, whose device-side
-    state machine lists exactly those tours and distances, and they are sent in order once it is back."""
+    (lin_kernighan.rs:71,90; nothing when n < 4, :57-59).  With a channel the solve goes through tl_lk_live: the device-side state
+    machine files exactly those tours and distances and the host hands them on while the search runs (tl_lk_trace lists the same
+    ones after the fact)."""
     from . import LKOptions, Solution, default_context
     from .. import _capi
     ctx = ctx or default_context()
@@ -30,17 +31,20 @@ def solve(problem, opts=None, progress_tx=None, init_tour=None, *, ctx=None, see
     if progress_tx is None or n < 4:
         ctx.check(ctx.lib.tl_lk(*args))
     else:
-        cap = min(int(opts.heuristic.epochs) + 1, 64)  # at most one per epoch + the first pass; rarely more than a few
-        while True:
-            snaps = np.empty((cap, n), dtype=np.uint32)
-            dists = np.empty(cap, dtype=np.float32)
-            ln = C.c_uint32()
-            ctx.check(ctx.lib.tl_lk_trace(*args, snaps.ctypes.data_as(C.c_void_p), dists.ctypes.data_as(C.c_void_p), cap, C.byref(ln)))
-            if ln.value <= cap:
-                break
-            cap = int(ln.value)  # the search is deterministic for a seed: once more with room for every snapshot
-        for m in range(ln.value):
-            progress_tx("PathUpdate", ([int(v) for v in problem.ids[snaps[m]]], float(dists[m])))
+        # with a channel: tl_lk_live calls back WHILE the device-side search runs (between two polls of its state machine), once
+        # per best tour the ILS settles on, in order — the messages arrive as the reference's would, not after the solve
+        err = []
+
+        def on_best(_user, pos, nn, best_dist):
+            try:
+                progress_tx("PathUpdate", ([int(v) for v in problem.ids[np.ctypeslib.as_array(pos, shape=(nn,))]], float(best_dist)))
+            except BaseException as exc:  # an exception must not unwind through the C frames
+                err.append(exc)
+
+        cb = _capi.LK_PROGRESS_FN(on_best)
+        ctx.check(ctx.lib.tl_lk_live(*args, cb, None))
+        if err:
+            raise err[0]
     return Solution(cost.value, problem.ids[out], problem, st.as_dict())
 
 

@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <cstdlib>
+#include <exception>
 #include <fstream>
 #include <functional>
 #include <map>
@@ -464,24 +465,28 @@ inline Solution solve(Context &ctx, const TspProblem &problem, const LKOptions &
         ctx.check(tl_lk(ctx.get(), xy.data(), n, problem.explicit_packed(), init_tour ? init.data() : nullptr, &o, seed, out.data(), &cost, &st));
         return detail::finish(problem, out, cost, st, nullptr);
     }
-    // With a progress callback: the best tours the search settles on, in order (tl_lk_trace), sent as the reference sends them —
-    // PathUpdate(best_tour, best_dist) after the first lk_pass and per improving epoch, no Done (lin_kernighan.rs:71,90).
-    uint32_t cap = std::min<uint32_t>((uint32_t)opts.heuristic.epochs + 1u, 64u), len = 0;
-    std::vector<uint32_t> snaps;
-    std::vector<float> dists;
-    for (;;) {
-        snaps.assign((size_t)cap * n, 0u);
-        dists.assign(cap, 0.f);
-        ctx.check(tl_lk_trace(ctx.get(), xy.data(), n, problem.explicit_packed(), init_tour ? init.data() : nullptr, &o, seed, out.data(), &cost, &st,
-                              snaps.data(), dists.data(), cap, &len));
-        if (len <= cap) break;
-        cap = len;  // deterministic for a seed: once more with room for every snapshot
-    }
-    std::vector<size_t> route(n);
-    for (uint32_t m = 0; m < len; ++m) {
-        for (uint32_t q = 0; q < n; ++q) route[q] = problem.cities[snaps[(size_t)m * n + q]].id;
-        (*progress_tx)(ProgressKind::PathUpdate, route, dists[m]);
-    }
+    // With a progress callback: the best tours the search settles on, in order, handed on WHILE the search runs (tl_lk_live) as the
+    // reference sends them — PathUpdate(best_tour, best_dist) after the first lk_pass and per improving epoch, no Done
+    // (lin_kernighan.rs:71,90).
+    struct Live {
+        const TspProblem *problem;
+        const ProgressFn *tx;
+        std::vector<size_t> route;
+        std::exception_ptr err;
+    } live{&problem, progress_tx, std::vector<size_t>(n), nullptr};
+    auto on_best = [](void *user, const uint32_t *pos, uint32_t nn, float best_dist) {
+        Live *L = static_cast<Live *>(user);
+        if (L->err) return;
+        try {  // an exception must not unwind through the C frames of the library
+            for (uint32_t q = 0; q < nn; ++q) L->route[q] = L->problem->cities[pos[q]].id;
+            (*L->tx)(ProgressKind::PathUpdate, L->route, best_dist);
+        } catch (...) {
+            L->err = std::current_exception();
+        }
+    };
+    ctx.check(tl_lk_live(ctx.get(), xy.data(), n, problem.explicit_packed(), init_tour ? init.data() : nullptr, &o, seed, out.data(), &cost, &st,
+                         +on_best, &live));
+    if (live.err) std::rethrow_exception(live.err);
     return detail::finish(problem, out, cost, st, nullptr);
 }
 }  // namespace lin_kernighan

@@ -281,8 +281,9 @@ def test_lk_forms_at_the_chip_step_size():
 
 def test_progress_channel_carries_the_reference_messages(ctx, tsplib_dir):
     # lin_kernighan.rs:71,90: PathUpdate(best_tour, best_dist) after the first lk_pass and after every epoch that improves on it, no
-    # Done.  With a progress callback lin_kernighan::solve goes through tl_lk_trace: the device-side state machine lists exactly
-    # those tours and distances (oracle: tlo_lin_kernighan_trace, the same loop with the messages recorded).
+    # Done.  With a progress callback lin_kernighan::solve goes through tl_lk_live (round 4): the device-side state machine files
+    # exactly those tours and distances in a ring and the host hands them to the callback while the search runs (oracle:
+    # tlo_lin_kernighan_trace, the same loop with the messages recorded); tl_lk_trace lists the same ones after the fact (below).
     import ctypes as C
     import teeline_amd as TA
     from teeline_amd import _capi
@@ -305,6 +306,20 @@ def test_progress_channel_carries_the_reference_messages(ctx, tsplib_dir):
             assert route == [int(ids[v]) for v in spos] and np.float32(dist).tobytes() == np.float32(sdist).tobytes()
         assert list(sol.route()) == [int(ids[v]) for v in oroute] and np.float32(sol.total).tobytes() == np.float32(ocost).tobytes()
         assert got[-1][1][0] == list(sol.route())  # the last message carries the returned tour
+    # tl_lk_trace: the same list after the fact, through the C ABI directly (the mirrors use tl_lk_live)
+    xy, ids = b["xy"], b["ids"]
+    n = len(ids)
+    rc, oroute, ocost, ost, osnaps = O.lin_kernighan_trace(xy, epochs=60, seed=1)
+    out = np.empty(n, dtype=np.uint32)
+    snaps = np.zeros((64, n), dtype=np.uint32)
+    dists = np.zeros(64, dtype=np.float32)
+    c, st, ln = C.c_float(), _capi.TlStats(), C.c_uint32()
+    o = _capi.TlLkOpts(60, 10, 5, 5)
+    ctx.check(ctx.lib.tl_lk_trace(ctx.handle, xy.ctypes.data_as(C.c_void_p), n, None, None, C.byref(o), 1, out.ctypes.data_as(C.c_void_p), C.byref(c),
+                                  C.byref(st), snaps.ctypes.data_as(C.c_void_p), dists.ctypes.data_as(C.c_void_p), 64, C.byref(ln)))
+    assert ln.value == len(osnaps) and out.tolist() == oroute.tolist()
+    for m, (spos, sdist) in enumerate(osnaps):
+        assert snaps[m].tolist() == spos.tolist() and dists[m].tobytes() == np.float32(sdist).tobytes()
     # a short buffer holds the first snapshots and reports the full count
     xy, ids = b["xy"], b["ids"]
     n = len(ids)
@@ -318,6 +333,36 @@ def test_progress_channel_carries_the_reference_messages(ctx, tsplib_dir):
         ctx.check(ctx.lib.tl_lk_trace(ctx.handle, xy.ctypes.data_as(C.c_void_p), n, None, None, C.byref(o), 7, out.ctypes.data_as(C.c_void_p), C.byref(c),
                                       C.byref(st), snaps.ctypes.data_as(C.c_void_p), dists.ctypes.data_as(C.c_void_p), 1, C.byref(ln)))
         assert ln.value == len(osnaps) and snaps[0].tolist() == osnaps[0][0].tolist() and out.tolist() == oroute.tolist()
+
+
+def test_progress_messages_arrive_while_the_search_runs(ctx):
+    """VERDICT r03 "missing 5": the reference sends while it runs (lin_kernighan.rs:71,90; teeline-qt watches the channel).  tl_lk_live
+    calls back between two polls of the device-side search: on a run of a few hundred milliseconds the first message (the tour after
+    the first lk_pass) must arrive long before the call returns, the messages must be spread over the run, and more than a ring's
+    worth of them (64) must all arrive, in order — content against the oracle's record."""
+    import time
+    import teeline_amd as TA
+    n = 1000
+    xy = O.synth_xy(n, seed=12)
+    stamps, got = [], []
+
+    def tx(kind, payload):
+        stamps.append(time.perf_counter())
+        got.append((kind, payload))
+
+    h = TA.HeuristicOptions(epochs=1500, platoo_epochs=1500, n_nearest=5)   # ~18 000 rounds, ~0.5 s
+    t0 = time.perf_counter()
+    sol = TA.lin_kernighan.solve(prob(xy), TA.LKOptions(h, 5), tx, None, ctx=ctx, seed=4)
+    t1 = time.perf_counter()
+    rc, oroute, ocost, ost, osnaps = O.lin_kernighan_trace(xy, epochs=1500, platoo_epochs=1500, seed=4, cap=512)
+    assert rc == 0 and len(osnaps) > 64, "the instance should improve in more epochs than the ring holds"
+    assert len(got) == len(osnaps)
+    for (kind, (route, dist)), (spos, sdist) in zip(got, osnaps):
+        assert kind == "PathUpdate" and route == spos.tolist() and np.float32(dist).tobytes() == np.float32(sdist).tobytes()
+    assert list(sol.route()) == oroute.tolist()
+    run = t1 - t0
+    assert stamps[0] - t0 < 0.5 * run, (stamps[0] - t0, run)          # the first message is not held back until the end
+    assert stamps[-1] - stamps[0] > 0.1 * run, (stamps[0] - t0, stamps[-1] - t0, run)  # ... and the others come spread over the run
 
 
 def test_no_progress_messages_below_four_cities(ctx):

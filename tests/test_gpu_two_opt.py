@@ -161,11 +161,11 @@ def test_matrix_form_equals_on_the_fly_form_pr1002_size(ctx):
 
 @pytest.mark.parametrize("n,start", [(1002, "identity"), (1002, "nn"), (1500, "random"), (3000, "random"), (9000, "random")])
 def test_matrix_form_deferred_rows(ctx, n, start):
-    """Round 4: the matrix-form kernel defers the reversals of a dense row to the row's end and composes them (two_opt_dm.hip
-    dm_flush: every element and every edge length moves once; the k + 1 new edges come from the hits' lanes).  Starts with moves
-    every few candidates (identity, random), rows with many hits (more than one hit-register's worth: a mid-row flush) and, at
-    n = 9 000, regions beyond what a composed flush holds in registers (8 192 positions: reversed hit by hit).  Tour, cost bits,
-    sweeps, moves, reversal count against the oracle on the same matrix."""
+    """The matrix-form kernel on starts with moves every few candidates (identity, random: rows with many chained hits, one reversal
+    per hit behind the step's barrier), the NN start (wide 16-row steps) and sizes up to 9 000 (reversals longer than 8 192
+    positions).  Tour, cost bits, sweeps, moves, reversal count against the oracle on the same matrix.  (Written in round 4 for a
+    form of the kernel that defers a dense row's reversals to the row's end and composes them — commit b6c7f95, parity green, not
+    faster: NOTEBOOK.md round 4 — and kept as coverage of the kernel that stayed.)"""
     xy = O.synth_xy(n, seed=31)
     packed = O.dm_build_packed(xy)
     init = None if start == "identity" else (O.nearest_neighbor(xy, None, n, 3)[1] if start == "nn" else O.restart_perm(n, 17, 0))
