@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-descent / no-prune / matrix-build extras")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="skip extras.drop_in_end_to_end (it starts the CLI as child processes: not under a profiler)")
     ap.add_argument("--no-work-count", action="store_true",
                     help="skip the one untimed launch of the counting kernel variant (PMC passes: only the timed kernel runs)")
     ap.add_argument("--single-process", action="store_true",
@@ -881,10 +883,11 @@ def main():
                     "sample": f"one ILS epoch at n = {n13}: double-bridge kick of the GPU run's final tour, then the oracle's lk_pass to the next local optimum ({st_lk['moves']} moves, {st_lk['sweeps']} find_lk_move scans) on one core; wall {wc:.1f} s"}
         except Exception as exc:
             extras["error"] = repr(exc)
-        try:
-            extras["drop_in_end_to_end"] = drop_in_end_to_end(TA, not a.no_cpu_baseline)
-        except Exception as exc:
-            extras["drop_in_end_to_end"] = {"error": repr(exc)}
+        if not a.no_end_to_end:
+            try:
+                extras["drop_in_end_to_end"] = drop_in_end_to_end(TA, not a.no_cpu_baseline)
+            except Exception as exc:
+                extras["drop_in_end_to_end"] = {"error": repr(exc)}
         out["extras"] = extras
         if "no_prune_multistart" in extras and "candidates_per_s" in extras["no_prune_multistart"]:
             # `value` counts candidates DECIDED (82 % of them a tile at a time by the exact L0 bound); the two like-for-like rates beside it:

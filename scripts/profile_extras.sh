@@ -7,7 +7,7 @@ OUT=$PWD/gpurun_out/${R}_extras
 mkdir -p $OUT
 REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/extras -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/extras.log 2>&1 \
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/extras -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end > $OUT/extras.log 2>&1 \
 && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lk -- python3 $REPO/scripts/lk_profile.py > $OUT/lk.log 2>&1 \
 && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dm_stats -- python3 $REPO/scripts/dm_build_once.py > $OUT/dm_stats.log 2>&1 \
 && timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/dm_write -- python3 $REPO/scripts/dm_build_once.py > $OUT/dm_write.log 2>&1 \
