@@ -1,5 +1,5 @@
 """Developer probe: randomized parity campaign of LK (three-level split scan, kept chains, prefix window) and the NN seed
-against the oracle.   python tests/probes/fuzz_campaign_lk.py [seconds]"""
+against the oracle.   python tests/probes/fuzz_campaign_lk.py [seconds]      FUZZ_DEEP=1: max_depth 7..12 (the lk_deep build), n <= 400"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,7 +12,8 @@ with TA.Context(0) as ctx:
     while time.time() - t0 < budget:
         seed += 1
         rng = np.random.default_rng(1000 + seed)
-        n = int(rng.integers(5, 700)) if seed % 5 else int(rng.integers(700, 2500))
+        deep = bool(os.environ.get("FUZZ_DEEP"))
+        n = int(rng.integers(5, 400)) if deep else (int(rng.integers(5, 700)) if seed % 5 else int(rng.integers(700, 2500)))
         kind = seed % 4
         if kind == 0: xy = rng.random((n, 2)) * 1000
         elif kind == 1: xy = rng.integers(0, int(rng.integers(3, 30)), (n, 2))
@@ -21,7 +22,7 @@ with TA.Context(0) as ctx:
         else:
             a = rng.random(n) * 2 * np.pi; xy = np.stack([np.cos(a), np.sin(a)], 1) * 300 + 300
         xy = np.ascontiguousarray(xy, dtype=np.float32)
-        k = int(rng.integers(1, 9)); depth = int(rng.integers(1, 7)); epochs = int(rng.integers(0, 12)); s = int(rng.integers(1, 1 << 30))
+        k = int(rng.integers(1, 6 if deep else 9)); depth = int(rng.integers(7, 13) if deep else rng.integers(1, 7)); epochs = int(rng.integers(0, 12)); s = int(rng.integers(1, 1 << 30))
         h = TA.HeuristicOptions(epochs=epochs, platoo_epochs=4, n_nearest=k)
         sol = TA.lin_kernighan.solve(TA.TspProblem(np.arange(n), xy), TA.LKOptions(h, depth), ctx=ctx, seed=s)
         rc, route, cost, st = O.lin_kernighan(xy, seed=s, epochs=epochs, platoo_epochs=4, n_nearest=k, max_depth=depth)
