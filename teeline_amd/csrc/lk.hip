@@ -62,13 +62,16 @@ __host__ __device__ __forceinline__ uint32_t lk_subs(const LkArgs &G)  // sub-se
 
 constexpr int kLkMaxDepth = TL_LK_MAX_DEPTH;         // compile-time recursion bound (6: default max_depth = 5; 16: the deep build, lk_deep.hip)
 constexpr int kLkMaxChain = 2 * kLkMaxDepth + 2;
-// u32 words per pair in LkArgs::chains: length, the chain's cities, (chip-wide step) their tour positions — 32 at depth 6, 128-byte multiples
-constexpr uint32_t kLkSlot = ((1u + 2u * (uint32_t)kLkMaxChain + 31u) / 32u) * 32u;
+// u32 words per pair in LkArgs::chains: length, the chain's cities, (chip-wide step) their tour positions, then the segment count and
+// the move's segment table (src, len, dst, dir per segment: the scan's validating lane builds it, round 4) — 96 at depth 6
+constexpr uint32_t kLkMaxSeg = 2u * ((uint32_t)kLkMaxDepth + 2u);
+constexpr uint32_t kLkSlotSeg = 1u + 2u * (uint32_t)kLkMaxChain;  // word of the segment count; the table follows
+constexpr uint32_t kLkSlot = ((kLkSlotSeg + 1u + 4u * kLkMaxSeg + 31u) / 32u) * 32u;
 constexpr uint32_t kLkTailCap = 48, kLkTailWords = 10;  // parked depth-3 walks of one scan workgroup (k_lk_scan_sub)
 // u32 words per kept sub-search chain (len + kLkMaxChain cities, 64-byte slots): 16 at depth 6
 constexpr uint32_t kLkSubSlot = ((1u + (uint32_t)kLkMaxChain + 15u) / 16u) * 16u;
 static_assert(kLkMaxChain + 1 <= (int)kLkSubSlot && 1 + 2 * kLkMaxChain <= (int)kLkSlot, "chain slots");
-static_assert(TL_LK_MAX_DEPTH != 6 || (kLkSlot == 32u && kLkSubSlot == 16u), "the default build's layout is unchanged");
+static_assert(TL_LK_MAX_DEPTH != 6 || (kLkSlot == 96u && kLkSubSlot == 16u), "the default build's layout");
 
 template <int LEN>
 __device__ __forceinline__ bool in_chain(const uint32_t (&chain)[kLkMaxChain], uint32_t x)
@@ -215,6 +218,55 @@ struct LkSeg {
     uint32_t src, len, dst;
     int dir;
 };
+
+// apply_lk_chain (lin_kernighan.rs:397-450) as a table: the new flat tour is the old tour's arcs copied in walk order starting at
+// tour[0] — forward if the edge (tour[0], tour[1]) survives, else backward.  cpos: tour positions of the chain's cities.
+__device__ __forceinline__ uint32_t lk_build_segments(const uint32_t (&cpos)[kLkMaxChain], uint32_t clen, uint32_t n, LkSeg *seg)
+{
+    Arcs A;
+    arcs_build(cpos, clen, n, A);
+    bool first_removed = false;
+    for (uint32_t m = 0; m < A.k; ++m) first_removed |= (A.lo[m] == 0u);
+    uint32_t nseg = 0, emitted = 0, p = 0;
+    int dir = first_removed ? -1 : +1;
+    while (emitted < n && nseg < kLkMaxSeg) {
+        const uint32_t endp = dir > 0 ? arc_end_from_start(A, p) : arc_start_from_end(A, p, n);
+        uint32_t len = dir > 0 ? (endp >= p ? endp - p + 1u : endp + n - p + 1u) : (p >= endp ? p - endp + 1u : p + n - endp + 1u);
+        if (len > n - emitted) len = n - emitted;
+        seg[nseg].src = p;
+        seg[nseg].len = len;
+        seg[nseg].dst = emitted;
+        seg[nseg].dir = dir;
+        ++nseg;
+        emitted += len;
+        if (emitted >= n) break;
+        p = sel_at(cpos, partner_index(index_at(cpos, clen, endp), clen));  // position of the boundary city's added-edge partner
+        dir = arc_is_start(A, p, n) ? +1 : -1;
+    }
+    return nseg;
+}
+
+// What the chip-wide step needs of a pair's valid chain, filed in the pair's slot by the scan lane that validated it (a call, not
+// inlined: the scan kernel lives on 64 VGPRs, and this runs for the few pairs of a scan that hold a valid chain): the chain's tour
+// positions (the step kernel rebuilds pos[] while its other workgroups still read it) and the move's segment table — which used
+// to be ONE thread's serial prologue of every step workgroup (k_lk_control<true>: 8.5 us per round, of which ~3 were this).
+__device__ __attribute__((noinline)) void lk_file_move(uint32_t *slot, uint32_t clen, const uint32_t *pos, uint32_t n)
+{
+    uint32_t cpos[kLkMaxChain];
+#pragma unroll
+    for (int t = 0; t < kLkMaxChain; ++t) cpos[t] = (uint32_t)t < clen ? pos[slot[1 + t]] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int t = 0; t < kLkMaxChain; ++t) slot[1 + kLkMaxChain + t] = cpos[t];
+    LkSeg seg[kLkMaxSeg];
+    const uint32_t nseg = lk_build_segments(cpos, clen, n, seg);
+    slot[kLkSlotSeg] = nseg;
+    for (uint32_t q = 0; q < nseg; ++q) {
+        slot[kLkSlotSeg + 1u + 4u * q] = seg[q].src;
+        slot[kLkSlotSeg + 2u + 4u * q] = seg[q].len;
+        slot[kLkSlotSeg + 3u + 4u * q] = seg[q].dst;
+        slot[kLkSlotSeg + 4u + 4u * q] = (uint32_t)seg[q].dir;
+    }
+}
 
 }  // namespace
 
@@ -819,10 +871,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             uint32_t *slot = G.chains + (size_t)idx * kLkSlot;
             slot[0] = clen;
             for (uint32_t t = 0; t < clen; ++t) slot[1 + t] = chain[t];
-            if (G.chip_step) {  // the step kernel rebuilds pos[] while other workgroups still build their segment tables
-                // (a loop over the slot's own words: a register array here costs every lane of the scan 19 VGPRs of occupancy)
-#pragma unroll 1
-                for (uint32_t t = 0; t < kLkMaxChain; ++t) slot[1 + kLkMaxChain + t] = t < clen ? G.pos[slot[1 + t]] : 0xFFFFFFFFu;
+            if (G.chip_step) {  // the chain's tour positions and the move's segment table, for the step kernel (a call: see lk_file_move)
+                lk_file_move(slot, clen, G.pos, n);
                 atomicMin(&G.state->key2[G.parity], idx);
             } else {
                 atomicMin(&G.state->key, idx);
@@ -943,8 +993,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             slot[0] = clen;
             for (uint32_t t = 0; t < clen; ++t) slot[1 + t] = chain[t];
             if (G.chip_step) {
-#pragma unroll 1
-                for (uint32_t t = 0; t < kLkMaxChain; ++t) slot[1 + kLkMaxChain + t] = t < clen ? G.pos[slot[1 + t]] : 0xFFFFFFFFu;
+                lk_file_move(slot, clen, G.pos, n);
                 atomicMin(&G.state->key2[G.parity], idx);
             } else {
                 atomicMin(&G.state->key, idx);
@@ -1062,37 +1111,16 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
         // ---- apply_lk_chain (:397-450), then rescan (lk_pass loop :468-478)
         const uint32_t *slot = G.chains + (size_t)key * kLkSlot;
         const uint32_t clen = slot[0];
-        if (tid == 0) {
+        if (CHIP) {
+            // the scan lane that validated this chain filed the move's segment table in the slot (lk_file_move)
+            if (tid == 0) s_nseg = slot[kLkSlotSeg];
+            if (tid < 4u * kLkMaxSeg) reinterpret_cast<uint32_t *>(s_seg)[tid] = slot[kLkSlotSeg + 1u + tid];
+        } else if (tid == 0) {
             uint32_t chain[kLkMaxChain];
             for (uint32_t t = 0; t < clen; ++t) chain[t] = slot[1 + t];
             uint32_t cpos[kLkMaxChain];
-            if (CHIP) {
-#pragma unroll
-                for (int t = 0; t < kLkMaxChain; ++t) cpos[t] = slot[1 + kLkMaxChain + t];
-            } else {
-                chain_positions(chain, clen, pos, cpos);
-            }
-            Arcs A;
-            arcs_build(cpos, clen, n, A);
-            bool first_removed = false;
-            for (uint32_t m = 0; m < A.k; ++m) first_removed |= (A.lo[m] == 0u);
-            uint32_t nseg = 0, emitted = 0, p = 0;
-            int dir = first_removed ? -1 : +1;
-            while (emitted < n && nseg < 2 * (kLkMaxDepth + 2)) {
-                const uint32_t endp = dir > 0 ? arc_end_from_start(A, p) : arc_start_from_end(A, p, n);
-                uint32_t len = dir > 0 ? (endp >= p ? endp - p + 1u : endp + n - p + 1u) : (p >= endp ? p - endp + 1u : p + n - endp + 1u);
-                if (len > n - emitted) len = n - emitted;
-                s_seg[nseg].src = p;
-                s_seg[nseg].len = len;
-                s_seg[nseg].dst = emitted;
-                s_seg[nseg].dir = dir;
-                ++nseg;
-                emitted += len;
-                if (emitted >= n) break;
-                p = sel_at(cpos, partner_index(index_at(cpos, clen, endp), clen));  // position of the boundary city's added-edge partner
-                dir = arc_is_start(A, p, n) ? +1 : -1;
-            }
-            s_nseg = nseg;
+            chain_positions(chain, clen, pos, cpos);
+            s_nseg = lk_build_segments(cpos, clen, n, s_seg);
         }
         TL_SYNC();
         const uint32_t nseg = s_nseg;
