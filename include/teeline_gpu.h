@@ -206,7 +206,7 @@ int tl_or_opt(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed, 
 int tl_or_opt_find_best_move(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *path,
                              int *found, float *delta, uint32_t *i, uint32_t *j, uint32_t *seg_len, int *reversed);
 
-/* ---- the solvers with what their progress channel carries listed (ABI v4) ---------------------- */
+/* ---- the solvers with what their progress channel carries listed (ABI v4; tl_lk_live: v5) ------- */
 /* The reference's solve() functions take Option<&Sender<ProgressMessage>> (two_opt.rs:10, three_opt.rs:19, lin_kernighan.rs:38;
  * only teeline-qt passes one).  A descent here is one kernel launch (or a device-side state machine), so nothing can be sent
  * while it runs; the *_trace entries return, beside the plain entry's results, the record from which the caller replays the
