@@ -74,6 +74,7 @@ template <bool DM>
 __global__ __launch_bounds__(kOrWaves * 64) void k_or_scan(OrOptArgs A, uint32_t chunks)
 {
     __shared__ unsigned long long s_key[kOrWaves][2];
+    if (A.run && A.run->done) return;  // a later pass of a batch whose descent is over
     const uint32_t n = A.n;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(kOrWaves * 64) void k_or_scan(OrOptArgs A, uint32_t
 template <bool DM>
 __global__ __launch_bounds__(256) void k_or_prepare(OrOptArgs A)
 {
+    if (A.run && A.run->done) return;
     const uint32_t n = A.n;
     for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) {
         const uint32_t p = A.perm[k], q = A.perm[k + 1u == n ? 0u : k + 1u];
@@ -190,6 +192,7 @@ __global__ __launch_bounds__(1024) void k_or_pick(OrOptArgs A, uint32_t nblocks,
     __shared__ unsigned long long s_key[16][2];
     const uint32_t tid = threadIdx.x, n = A.n;
     const int lane = tid & 63, wave = tid >> 6;
+    if (A.run && A.run->done) return;
     key_t best = no_key();
     for (uint32_t b = tid; b < nblocks; b += 1024u) {
         const key_t k = make_key(A.partials[2u * (size_t)b], A.partials[2u * (size_t)b + 1u]);
@@ -218,6 +221,21 @@ __global__ __launch_bounds__(1024) void k_or_pick(OrOptArgs A, uint32_t nblocks,
         A.best->j = j;
         A.best->seg_len = seg_len;
         A.best->reversed = reversed;
+        if (A.run) {  // or_opt.rs:45 `while let Some(best) = find_best_move(..)`: count the pass, file the move or end the descent
+            A.run->passes += 1u;
+            if (!found) {
+                A.run->done = 1u;
+            } else {
+                const uint32_t m = A.run->moves;
+                if (m < A.run->log_cap) {
+                    A.log[4u * m + 0u] = i;
+                    A.log[4u * m + 1u] = j;
+                    A.log[4u * m + 2u] = seg_len;
+                    A.log[4u * m + 3u] = reversed;
+                }
+                A.run->moves = m + 1u;
+            }
+        }
     }
     if (!found || !apply) return;
     uint32_t *path = A.perm;

@@ -49,6 +49,7 @@ __device__ __forceinline__ float Dpos(const float2 *__restrict__ Pt, const float
 template <bool DM>
 __global__ __launch_bounds__(256) void k_three_opt_prepare(ThreeOptArgs A)
 {
+    if (A.run && A.run->done) return;  // a later pass of a batch whose descent is over
     const uint32_t n = A.n;
     for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k <= n; k += gridDim.x * 256u) {
         const uint32_t kk = k == n ? 0u : k;
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(256) void k_three_opt_prepare(ThreeOptArgs A)
 template <bool DM>
 __global__ __launch_bounds__(256) void k_three_opt_build_dt(ThreeOptArgs A)
 {
+    if (A.run && A.run->done) return;
     const uint32_t n = A.n, p = blockIdx.x, q = blockIdx.y * 256u + threadIdx.x;
     if (q > n) return;
     A.Dt[(size_t)p * (n + 1u) + q] = Dpos<DM>(A.Pt, A.dm, A.perm, p, q, n);
@@ -70,6 +72,7 @@ __global__ __launch_bounds__(256) void k_three_opt_build_dt(ThreeOptArgs A)
 
 __global__ __launch_bounds__(kT3) void k_three_opt_scan(ThreeOptArgs A)
 {
+    if (A.run && A.run->done) return;
     const uint32_t n = A.n;
     __shared__ uint32_t s_i;
     __shared__ float r_s[kT3 / 64];
@@ -186,6 +189,7 @@ __global__ __launch_bounds__(1024) void k_three_opt_pick(ThreeOptArgs A, uint32_
     __shared__ float r_s[16];
     __shared__ uint32_t r_ij[16], r_kc[16];
     const uint32_t tid = threadIdx.x;
+    if (A.run && A.run->done) return;
     float bs = 0.0f;
     uint32_t bij = 0xFFFFFFFFu, bkc = 0xFFFFFFFFu;
     for (uint32_t b = tid; b < nblocks; b += 1024u) {
@@ -211,6 +215,21 @@ __global__ __launch_bounds__(1024) void k_three_opt_pick(ThreeOptArgs A, uint32_
         if (apply) {
             A.counters[0] += 1;                  // passes
             if (found) A.counters[1] += 1;       // moves
+        }
+        if (A.run) {  // three_opt.rs:36-45: count the pass, file the move or end the descent
+            A.run->passes += 1u;
+            if (!found) {
+                A.run->done = 1u;
+            } else {
+                const uint32_t m = A.run->moves;
+                if (m < A.run->log_cap) {
+                    A.log[4u * m + 0u] = bij >> 16;
+                    A.log[4u * m + 1u] = bij & 0xFFFFu;
+                    A.log[4u * m + 2u] = bkc >> 3;
+                    A.log[4u * m + 3u] = bkc & 7u;
+                }
+                A.run->moves = m + 1u;
+            }
         }
     }
     if (!found || !apply) return;

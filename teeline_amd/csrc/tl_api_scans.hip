@@ -4,6 +4,8 @@
 using namespace tl;
 using namespace tlapi;
 
+static constexpr int kScanBatch = 16;  // passes of a 3-opt / Or-opt descent enqueued per host poll (later ones return at once when it ends)
+
 // ------------------------------------------------------------------------------------------------
 // 3-opt
 // ------------------------------------------------------------------------------------------------
@@ -132,29 +134,30 @@ static int three_opt_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm
     ThreeOptSetup S;
     int rc;
     if ((rc = three_opt_setup(c, xy, n, dm_packed, init_pos, S))) return rc;
+    // The descent runs as batches of passes enqueued back to back (tl_kernels.h ScanRunState): the pick kernel counts passes and
+    // moves, files every move (i, j, k, case) and sets `done` when a pass finds none; the host looks once per batch.
+    const uint32_t dev_log_cap = move_log ? log_cap : 0u;
+    if ((rc = ensure(c, c->misc, 256 + (size_t)(dev_log_cap ? dev_log_cap : 1u) * 16))) return rc;
+    S.A.run = (ScanRunState *)c->misc.p;
+    S.A.log = (uint32_t *)((unsigned char *)c->misc.p + 256);
+    const ScanRunState hs0{0u, 0u, 0u, dev_log_cap};
+    ScanRunState hs = hs0;
+    HIPCHK(c, hipMemcpyAsync(S.A.run, &hs0, sizeof(hs0), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    uint64_t passes = 0, moves = 0;
     const uint64_t cap = 64ull * n + 1024;  // safety cap, far above any observed pass count
     for (;;) {
-        HIPCHK(c, launch_three_opt_pass(S.A, S.nblocks, S.dm, 1, c->stream, c->lds_bytes));
-        ThreeOptBest b{};
-        HIPCHK(c, hipMemcpyAsync(&b, S.A.best, sizeof(b), hipMemcpyDeviceToHost, c->stream));
+        for (int b = 0; b < kScanBatch; ++b) HIPCHK(c, launch_three_opt_pass(S.A, S.nblocks, S.dm, 1, c->stream, c->lds_bytes));
+        HIPCHK(c, hipMemcpyAsync(&hs, S.A.run, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        ++passes;
-        if (!b.found) break;  // three_opt.rs:36-45
-        if (move_log && moves < log_cap) {
-            uint32_t *w = move_log + 4 * moves;
-            w[0] = b.ij >> 16;
-            w[1] = b.ij & 0xFFFFu;
-            w[2] = b.kc >> 3;
-            w[3] = b.kc & 7u;
-        }
-        ++moves;
-        if (passes > cap) return fail(c, TL_ERR_NO_CONVERGE, "three_opt: pass cap reached");
+        if (hs.done) break;  // three_opt.rs:36-45
+        if (hs.passes > cap) return fail(c, TL_ERR_NO_CONVERGE, "three_opt: pass cap reached");
     }
+    const uint64_t passes = hs.passes, moves = hs.moves;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->ev_valid = true;
     HIPCHK(c, hipMemcpyAsync(out_pos, S.A.perm, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (move_log && moves && dev_log_cap)
+        HIPCHK(c, hipMemcpyAsync(move_log, S.A.log, (size_t)(moves < dev_log_cap ? moves : dev_log_cap) * 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (out_cost) {
         // Solution::from_parts -> tour_length (mod.rs:1776-1789)
@@ -185,7 +188,7 @@ extern "C" int tl_three_opt(tl_ctx *c, const float *xy, uint32_t n, const float 
 }
 
 // three_opt::solve with its moves listed: the reference sends the path after every apply_3opt (three_opt.rs:34,42,47-49); the
-// host loop here already reads every move back (one word pair per pass), so the list costs nothing.
+// pick kernel files every move it applies, the list is read back once.
 extern "C" int tl_three_opt_trace(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
                                   uint32_t *out_pos, float *out_cost, tl_stats *stats, uint32_t *move_log, uint32_t log_cap, uint32_t *log_len)
 {
@@ -291,29 +294,29 @@ static int or_opt_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_pa
     bool dm;
     int rc;
     if ((rc = or_opt_setup(c, xy, n, dm_packed, init_pos, A, dm))) return rc;
+    // batches of passes enqueued back to back; k_or_pick counts, files every move (i, j, seg_len, reversed) and ends the descent
+    const uint32_t dev_log_cap = move_log ? log_cap : 0u;
+    if ((rc = ensure(c, c->misc, 256 + (size_t)(dev_log_cap ? dev_log_cap : 1u) * 16))) return rc;
+    A.run = (ScanRunState *)c->misc.p;
+    A.log = (uint32_t *)((unsigned char *)c->misc.p + 256);
+    const ScanRunState hs0{0u, 0u, 0u, dev_log_cap};
+    ScanRunState hs = hs0;
+    HIPCHK(c, hipMemcpyAsync(A.run, &hs0, sizeof(hs0), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    uint64_t passes = 0, moves = 0;
     const uint64_t cap = 64ull * n + 1024;
     for (;;) {  // or_opt.rs:45 while let Some(best) = find_best_move(..)
-        HIPCHK(c, launch_or_opt_pass(A, dm, 1, c->stream, c->lds_bytes));
-        OrOptBest b{};
-        HIPCHK(c, hipMemcpyAsync(&b, A.best, sizeof(b), hipMemcpyDeviceToHost, c->stream));
+        for (int b = 0; b < kScanBatch; ++b) HIPCHK(c, launch_or_opt_pass(A, dm, 1, c->stream, c->lds_bytes));
+        HIPCHK(c, hipMemcpyAsync(&hs, A.run, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        ++passes;
-        if (!b.found) break;
-        if (move_log && moves < log_cap) {
-            uint32_t *w = move_log + 4 * moves;
-            w[0] = b.i;
-            w[1] = b.j;
-            w[2] = b.seg_len;
-            w[3] = b.reversed;
-        }
-        ++moves;
-        if (passes > cap) return fail(c, TL_ERR_NO_CONVERGE, "or_opt: pass cap reached");
+        if (hs.done) break;
+        if (hs.passes > cap) return fail(c, TL_ERR_NO_CONVERGE, "or_opt: pass cap reached");
     }
+    const uint64_t passes = hs.passes, moves = hs.moves;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->ev_valid = true;
     HIPCHK(c, hipMemcpyAsync(out_pos, A.perm, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (move_log && moves && dev_log_cap)
+        HIPCHK(c, hipMemcpyAsync(move_log, A.log, (size_t)(moves < dev_log_cap ? moves : dev_log_cap) * 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (out_cost) {
         if ((rc = ensure(c, c->out_cost, 4))) return rc;
@@ -348,7 +351,7 @@ extern "C" int tl_or_opt(tl_ctx *c, const float *xy, uint32_t n, const float *dm
 }
 
 // or_opt::solve with its moves listed: the reference sends the path and its tour_length after every apply_relocation
-// (or_opt.rs:40-42,62-67,70-72); the host loop here already reads every move back.
+// (or_opt.rs:40-42,62-67,70-72); the pick kernel files every move it applies.
 extern "C" int tl_or_opt_trace(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos,
                                uint32_t *out_pos, float *out_cost, tl_stats *stats, uint32_t *move_log, uint32_t log_cap, uint32_t *log_len)
 {

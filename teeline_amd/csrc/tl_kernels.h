@@ -110,6 +110,16 @@ struct LargeTwoOptArgs {
 hipError_t launch_large_two_opt_init(const LargeTwoOptArgs &A, hipStream_t s);
 hipError_t launch_large_two_opt_round(const LargeTwoOptArgs &A, hipStream_t s);
 
+// A best-improvement descent (3-opt, Or-opt) runs as batches of passes enqueued back to back: the pick kernel of a pass that finds
+// no move sets `done`, every kernel of a later pass of the batch returns at once, and the host polls this block once per batch
+// instead of once per pass (round 4: the per-pass read-back was 40 % of an Or-opt descent at n = 5 000).
+struct ScanRunState {
+    uint32_t done;     // a pass found no improving move: the descent is over
+    uint32_t passes;   // find_best_move calls so far (the last one finds nothing)
+    uint32_t moves;    // moves applied; also the number of log entries offered
+    uint32_t log_cap;  // entries (4 words each) the move log holds
+};
+
 // three_opt.hip
 struct ThreeOptBest {
     float sav;
@@ -129,6 +139,8 @@ struct ThreeOptArgs {
     ThreeOptBest *best;          // result of the pass
     uint64_t *counters;          // passes, moves
     uint32_t *scratch;           // [n] the move's two segments in k_three_opt_pick where they do not fit the LDS
+    ScanRunState *run;           // a descent's batch state (nullptr: a single find_best_move)
+    uint32_t *log;               // [run->log_cap][4] applied moves: i, j, k, case
     uint32_t n;
     uint32_t jc;                 // j values per scan workgroup
 };
@@ -148,6 +160,8 @@ struct OrOptArgs {
     unsigned long long *partials;  // one packed key (two words: ~delta bits, loop-order index) per scan workgroup
     OrOptBest *best;
     uint32_t *scratch;             // [n] the pre-move tour of k_or_pick where it does not fit the LDS
+    ScanRunState *run;             // a descent's batch state (nullptr: a single find_best_move)
+    uint32_t *log;                 // [run->log_cap][4] applied moves: i, j, seg_len, reversed
     uint32_t n;
 };
 hipError_t launch_or_opt_pass(const OrOptArgs &A, bool dm, int apply, hipStream_t s, int lds_budget);
