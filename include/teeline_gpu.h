@@ -87,6 +87,9 @@ typedef enum tl_mode {
 #define TL_FLAG_2OPT_NT512 (1u << 14)      /* LDS 2-opt: every descent on 8 waves (default: only when two descents share a CU)   */
 #define TL_FLAG_2OPT_NT256 (1u << 15)      /* LDS 2-opt: every descent on 4 waves (default: only when four descents share a CU)  */
 #define TL_FLAG_2OPT_FX (1u << 16)         /* LDS 2-opt: the grid-coordinate form (5 B per point) wherever the instance lies on a decimal grid */
+#define TL_FLAG_2OPT_NO_NL (1u << 18)      /* LDS 2-opt: never read neighbour lists — every pruned row walks its tiles (default: rows of the
+                                              late sweeps of an instance with n >= 3000 read the lists, csrc/two_opt_nl.hip)               */
+#define TL_FLAG_2OPT_NL_ALWAYS (1u << 19)  /* LDS 2-opt: neighbour-list rows at every n they fit and from the second sweep on            */
 /* TUNING BUILDS ONLY (libteeline_gpu_tune.so, -DTL_TUNE: `python -m teeline_amd.build --tune`).  Forms that were measured and
  * rejected and stay as cross-checks for development; the product library does not carry them and tl_create
  * returns TL_ERR_UNSUPPORTED if one of these bits is set. */
@@ -156,6 +159,17 @@ uint32_t tl_two_opt_lds_max_n(const tl_ctx *ctx);
  * fix-up; this compares it on the device with the compiler's full expansion for the `count` f32 bit patterns
  * starting at `first_bits`.  *mismatches must come back 0. */
 int tl_selftest_sqrt(tl_ctx *ctx, uint32_t first_bits, uint64_t count, uint64_t *mismatches, uint32_t *first_bad_bits);
+
+/* ---- diagnostics: the neighbour lists of the LDS 2-opt descent's late sweeps ---------------------------------- */
+/* From its fifth sweep on, a descent of an instance with n >= 3000 (one descent per CU; TL_FLAG_2OPT_NO_NL: never) decides a
+ * row (a, b) from per-city lists instead of walking every tile (csrc/two_opt_nl.hip: improving => c is strictly closer to a than
+ * b, or b strictly closer to e than c).  This builds the lists for xy as a call would and copies them out, for tests:
+ * rec [n][64] u16 — per city: [0] high half of the bits of its KA-th smallest squared distance, [2] 1 if its reverse list is
+ * incomplete, [4, 4+KA) its KA nearest cities, [20, 20+RB) the cities that count it among their KB nearest (0xFFFF: empty);
+ * dkb2 [n] — bits of the KB-th smallest squared distance; knn_b [n][KB] — the KB nearest cities; rcnt [n] — reverse counts.
+ * KA, KB, RB come back in *ka, *kb, *rb.  TL_ERR_UNSUPPORTED where the lists do not apply (n <= KB + 1). */
+int tl_two_opt_neighbour_lists(tl_ctx *ctx, const float *xy, uint32_t n, uint16_t *rec, uint32_t *dkb2, uint16_t *knn_b, uint32_t *rcnt,
+                               uint32_t *ka, uint32_t *kb, uint32_t *rb);
 
 /* ---- distance matrix: replaces DistanceMatrix::build (distance_matrix.rs:122-153) ----------- */
 /* out_host may be NULL (matrix stays on the device for later calls on this context). */

@@ -6,7 +6,7 @@ import numpy as np, torch, teeline_amd as TA
 n, R = 10000, 256
 dev = torch.device("cuda", 0)
 xy = TA.synth.synth_xy(n)
-ctx = TA.Context(0)
+ctx = TA.Context(0, int(os.environ.get("FLAGS", 0)))
 d_xy = torch.from_numpy(xy).to(dev)
 d_pos = torch.empty((R, n), dtype=torch.int32, device=dev); d_cost = torch.empty(R, dtype=torch.float32, device=dev)
 d_st = torch.zeros((R, 16), dtype=torch.int64, device=dev)
@@ -25,4 +25,4 @@ a = min(TA.two_opt.solve(prob, None, None, nn.route(), ctx=ctx).stats["kernel_ms
 init = [int(v) for v in TA.synth.restart_perm(n, 12345, 0)]
 b = min(TA.two_opt.solve(prob, None, None, init, ctx=ctx).stats["kernel_ms"] for _ in range(3))
 crc = int(d_pos.to(torch.int64).sum().item()) ^ int(d_cost.view(torch.int32).to(torch.int64).sum().item())
-print(f"{os.path.basename(os.environ.get('TEELINE_GPU_LIB','default')):20s} batch256 {min(ms[1:]):8.2f} ms  nn-start {a:6.2f} ms  random-start {b:7.2f} ms  steps/descent {d_st[:,4].float().mean().item():.0f}  check {crc}")
+print(f"{os.path.basename(os.environ.get('TEELINE_GPU_LIB','default')):20s} flags {os.environ.get('FLAGS', 0)} batch256 {min(ms[1:]):8.2f} ms  nn-start {a:6.2f} ms  random-start {b:7.2f} ms  steps/descent {d_st[:,4].float().mean().item():.0f}  check {crc}")

@@ -25,6 +25,7 @@ TL_FLAG_LK_NO_GRAPH = 1 << 12  # tl_lk: no hipGraph replay of the round loop
 TL_FLAG_LK_SEPARATE_STEP = 1 << 13  # tl_lk: k_lk_control + k_lk_rebuild instead of the chip-wide step kernel
 TL_FLAG_2OPT_NT512, TL_FLAG_2OPT_NT256 = 1 << 14, 1 << 15  # LDS 2-opt: force the 8- / 4-wave form of a descent
 TL_FLAG_2OPT_FX = 1 << 16  # LDS 2-opt: grid-coordinate form of the tour (two tours of n = 10^4 per CU) wherever it is exact
+TL_FLAG_2OPT_NO_NL, TL_FLAG_2OPT_NL_ALWAYS = 1 << 18, 1 << 19  # LDS 2-opt: neighbour-list rows of the late sweeps off / wherever they fit
 TL_FLAG_LK_SCAN_PERSIST = 1 << 17  # tl_lk (tuning build): the fused scan as a persistent grid striding over the window's pairs
 TL_FLAG_LK_SMALL = 1 << 9  # tl_lk: the LDS-resident single-workgroup form wherever it fits
 TL_FLAG_COUNT_WORK = 1 << 8  # the LDS 2-opt kernel also counts the work of its cascade (stats words 5..8); ~8 % slower
@@ -39,7 +40,7 @@ SYMBOLS = [
     "tl_two_opt_batch_dev", "tl_last_kernel_ms", "tl_dm_build_dev", "tl_build_candidates", "tl_nearest_neighbor",
     "tl_or_opt", "tl_or_opt_find_best_move", "tl_selftest_sqrt", "tl_two_opt_population", "tl_dm_is_euc2d",
     "tl_two_opt_multistart_devices", "tl_two_opt_trace", "tl_three_opt_trace", "tl_lk_trace", "tl_or_opt_trace",
-    "tl_lk_live",
+    "tl_lk_live", "tl_two_opt_neighbour_lists",
 ]
 
 
@@ -120,6 +121,7 @@ def load():
     L.tl_build_candidates.argtypes = [vp, vp, u32, u32, vp]
     L.tl_nearest_neighbor.argtypes = [vp, vp, vp, u32, u32, vp, f32p]
     L.tl_selftest_sqrt.argtypes = [vp, u32, u64, C.POINTER(u64), C.POINTER(u32)]
+    L.tl_two_opt_neighbour_lists.argtypes = [vp, vp, u32, vp, vp, vp, vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.tl_or_opt.argtypes = [vp, vp, u32, vp, vp, vp, f32p, C.POINTER(TlStats)]
     L.tl_or_opt_find_best_move.argtypes = [vp, vp, u32, vp, vp, C.POINTER(i32), f32p, C.POINTER(u32), C.POINTER(u32),
                                            C.POINTER(u32), C.POINTER(i32)]

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libteeline_gpu.so")
 
-SOURCES = ["tl_api.hip", "tl_api_two_opt.hip", "tl_api_scans.hip", "tl_api_lk.hip", "two_opt_ref.hip", "two_opt_dm.hip", "dm_build.hip", "three_opt.hip", "lk.hip", "lk_deep.hip", "nn_knn.hip", "two_opt_best.hip", "or_opt.hip", "two_opt_large.hip", "kdtree.hip"]
+SOURCES = ["tl_api.hip", "tl_api_two_opt.hip", "tl_api_scans.hip", "tl_api_lk.hip", "two_opt_ref.hip", "two_opt_nl.hip", "two_opt_dm.hip", "dm_build.hip", "three_opt.hip", "lk.hip", "lk_deep.hip", "nn_knn.hip", "two_opt_best.hip", "or_opt.hip", "two_opt_large.hip", "kdtree.hip"]
 HEADERS = ["tl_device.h", "tl_kernels.h", "two_opt_common.h", "tl_api_common.h", os.path.join(ROOT, "include", "teeline_gpu.h")]
 
 # -ffp-contract=off: the reference never fuses mul+add (src/tsp/kdtree.rs:291-295); bit-exact parity

@@ -5,6 +5,10 @@
 using namespace tl;
 using namespace tlapi;
 
+#ifndef TL_NL_SWEEP_MIN
+#define TL_NL_SWEEP_MIN 6  // first sweep of a descent whose pruned blocks read the neighbour lists (tuning builds override it)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // 2-opt
 // ------------------------------------------------------------------------------------------------
@@ -74,10 +78,43 @@ static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uin
                 }
             }
         }
+        // Neighbour lists of the instance for the late sweeps (two_opt_nl.hip): built once per call, read by every descent of the
+        // batch — where the 16-wave float2 form runs, the lists' state fits the LDS beside the tour, and the instance is large
+        // enough for the lists (~0.3 ms at n = 10^4) to pay.
+        if (!A.fx_xy && !(c->flags & (TL_FLAG_NO_PRUNE | TL_FLAG_2OPT_NO_NL)) && (n >= 3000u || (c->flags & TL_FLAG_2OPT_NL_ALWAYS)) &&
+            two_opt_ref_nl_applies(n, count, c->cus, c->lds_bytes, force_nt)) {
+            int rc4;
+            if ((rc4 = ensure(c, c->nl, two_opt_nl_ws_bytes(n)))) return rc4;
+            HIPCHK(c, launch_two_opt_nl_build(d_xy, n, c->nl.p, &A.nl, s));
+            A.nl.sweep_min = (c->flags & TL_FLAG_2OPT_NL_ALWAYS) ? 2u : (uint32_t)TL_NL_SWEEP_MIN;
+        }
         HIPCHK(c, launch_two_opt_ref_lds(A, count, !(c->flags & TL_FLAG_NO_PRUNE), s, (c->flags & TL_FLAG_COUNT_WORK) != 0, c->cus, c->lds_bytes, force_nt));
     }
     HIPCHK(c, hipEventRecord(c->ev1, s));
     c->ev_valid = true;
+    return TL_OK;
+}
+
+extern "C" int tl_two_opt_neighbour_lists(tl_ctx *c, const float *xy, uint32_t n, uint16_t *rec, uint32_t *dkb2, uint16_t *knn_b, uint32_t *rcnt, uint32_t *ka,
+                                          uint32_t *kb, uint32_t *rb)
+{
+    TL_ENTER(c);
+    if (!c || !xy || !rec || !dkb2 || !knn_b || !rcnt) return fail(c, TL_ERR_BADARG, "tl_two_opt_neighbour_lists: NULL argument");
+    if (n <= (uint32_t)kNlKB + 1u || n > 65535u) return fail(c, TL_ERR_UNSUPPORTED, "tl_two_opt_neighbour_lists: n=%u outside (%d, 65535]", n, kNlKB + 1);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->nl, two_opt_nl_ws_bytes(n)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    TwoOptNl L{};
+    HIPCHK(c, launch_two_opt_nl_build((const float2 *)c->xy.p, n, c->nl.p, &L, c->stream));
+    HIPCHK(c, hipMemcpyAsync(rec, L.rec, (size_t)n * 128, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dkb2, L.dkb2, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(knn_b, L.knn_b, (size_t)n * kNlKB * 2, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(rcnt, L.rcnt, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (ka) *ka = kNlKA;
+    if (kb) *kb = kNlKB;
+    if (rb) *rb = kNlRB;
     return TL_OK;
 }
 

@@ -40,6 +40,28 @@ inline hipError_t allow_max_lds(const void *kern)
 
 enum : uint32_t { TL_INIT_IDENTITY = 0, TL_INIT_ARRAY = 1, TL_INIT_SEEDED = 2 };
 
+// Neighbour lists of an instance (two_opt_nl.hip): what the late sweeps of the LDS descent read instead of walking tiles.
+// One 128-byte record of 64 u16 per city, so that a row (a, b) is ONE wave-wide load of two cache lines — lane l reads word l of
+// a's record (l < kNlRecB0, except the count) or of b's:
+//   [0]       high half of the bits of the KA-th smallest squared distance from the city (i.e. rounded down)
+//   [2]       1 if more than kNlRB cities have this one among their KB nearest (the list below is then incomplete), else 0
+//   [4 .. 20) its KA nearest cities
+//   [20 .. 56) the cities that have it among their KB nearest (the first kNlRB of them), 0xFFFF = empty slot
+//   [56 .. 64) unused here: those lanes of a row's pass take the chunk's long cities
+constexpr int kNlKA = 16;        // nearest cities kept per city for "c closer to a than b" (rows with a longer (a, b) take the tile path)
+constexpr int kNlKB = 24;        // nearest cities per city behind the reverse lists ("b closer to e than c")
+constexpr int kNlRecA0 = 4, kNlRecB0 = 20, kNlRB = 36, kNlSurv0 = 56, kNlSurvSlots = 8;
+constexpr int kNlLongCap = 128;  // cities with a tour edge beyond their KB-th distance a descent can hold (more: tile path for the sweep)
+struct TwoOptNl {
+    const uint16_t *rec;     // [n][64] records; nullptr = no lists (tile path only)
+    const uint32_t *dkb2;    // [n] bits of the KB-th smallest squared distance
+    const uint16_t *knn_b;   // [n][kNlKB] the KB nearest cities of each city (the forward form of the reverse lists; diagnostics)
+    const uint32_t *rcnt;    // [n] reverse counts (diagnostics)
+    uint32_t sweep_min;      // first sweep of a descent that may run in the late phase (neighbour-list rows)
+};
+size_t two_opt_nl_ws_bytes(uint32_t n);
+hipError_t launch_two_opt_nl_build(const float2 *xy, uint32_t n, void *ws, TwoOptNl *out, hipStream_t s);
+
 struct TwoOptBatchArgs {
     const float2 *xy;        // n cities, city order
     const float *dm;         // packed lower triangle (matrix kernels) or nullptr
@@ -60,10 +82,14 @@ struct TwoOptBatchArgs {
                              // progress messages from; NULL = off
     const uint2 *fx_xy;      // LDS kernel, grid-coordinate form: per city {x (20 bits) | y low 12 bits << 20, y high 8 bits} (k_fx_encode)
     double fx_inv;           // ... fl64(1 / S) of its decimal grid, 0 = plain float2 form
+    TwoOptNl nl;             // LDS kernel, 16-wave float2 form: neighbour lists for the late sweeps (rec == nullptr: off)
 };
 
 // two_opt_ref.hip
 size_t two_opt_ref_lds_bytes(uint32_t n, uint32_t *n_pad_out, int nt);
+size_t two_opt_ref_nl_lds_bytes(uint32_t n);  // ... with the neighbour-list state (city -> position table, long list) beside the tour
+// would a batch of `count` descents run in the form that reads neighbour lists (16 waves, float2 points, lists + tour fit the LDS)?
+bool two_opt_ref_nl_applies(uint32_t n, uint32_t count, int cus, int lds_budget, int force_nt);
 hipError_t launch_two_opt_ref_lds(const TwoOptBatchArgs &A, uint32_t count, bool prune, hipStream_t s, bool count_work, int cus, int lds_budget,
                                   int force_nt);
 // grid-coordinate form (A.fx_xy / A.fx_inv set): would it let two tours share a CU where the float2 form cannot?

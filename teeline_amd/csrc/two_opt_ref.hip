@@ -62,7 +62,9 @@ struct Ctl {                     // kCtlBytes of LDS
     unsigned long long cnt[6];  // cascade work of the descent (TileCounts summed over the waves; counting instantiation)
     unsigned long long clk0, rt0;  // s_memtime / s_memrealtime at the start of the descent (kept here, not in SGPRs)
     uint32_t bad_init;
-    uint32_t pad_[3];
+    uint32_t nlong;             // late phase: entries of the long list (counted on beyond kNlLongCap: the list is then incomplete and unused)
+    uint32_t late_cur;          // late phase: the next row of the step's scan nobody has taken yet
+    uint32_t pad_[1];
     uint32_t pend[64];          // deferred hit columns of the current dense row (lane m of a flush reads hit m)
 };
 constexpr size_t kCtlBytes = 384;
@@ -165,8 +167,9 @@ __device__ __forceinline__ uint32_t flush_deferred(const PT &P, uint16_t *perm, 
 
 // two_opt.rs:50,69-79  swap_2opt(path, lo, hi): in-place reversal by the whole workgroup, two pairs per thread in flight.
 // The caller puts a barrier behind it.
+// `pos` (late phase): the city -> position table follows the tour where it is valid (nullptr: not kept).
 template <int NT, typename PT>
-__device__ __forceinline__ void reverse_segment(const PT &P, uint16_t *perm, uint32_t lo, uint32_t hi, int tid)
+__device__ __forceinline__ void reverse_segment(const PT &P, uint16_t *perm, uint32_t lo, uint32_t hi, int tid, uint16_t *pos = nullptr)
 {
     const uint32_t half = (hi - lo + 1u) >> 1;
     for (uint32_t t = (uint32_t)tid; t < half; t += 2 * NT) {
@@ -186,11 +189,19 @@ __device__ __forceinline__ void reverse_segment(const PT &P, uint16_t *perm, uin
         pt_put(P, hi - t, x);
         perm[lo + t] = v;
         perm[hi - t] = u;
+        if (pos) {
+            pos[v] = (uint16_t)(lo + t);
+            pos[u] = (uint16_t)(hi - t);
+        }
         if (two) {
             pt_put(P, lo + t2, y2);
             pt_put(P, hi - t2, x2);
             perm[lo + t2] = v2;
             perm[hi - t2] = u2;
+            if (pos) {
+                pos[v2] = (uint16_t)(lo + t2);
+                pos[u2] = (uint16_t)(hi - t2);
+            }
         }
     }
 }
@@ -330,15 +341,391 @@ __device__ __forceinline__ bool step_boundary(Cursor &c, Acct &a, const PT &P, u
     return c.i0 >= nrows || req != 0u;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Late phase: the sweeps from TwoOptNl::sweep_min on (two_opt_nl.hip has the argument).
+// By then a sweep applies a few hundred moves at most and nearly every row is decided "no move"; what such a row costs in the
+// main loop is L0 over every tile plus L1 over its ~3 live ones (~200 instructions).  Here a row (a, b) reads ONE 128-byte
+// record pair — the KA nearest cities of a (as c), the cities that have b among their KB nearest (as e) — adds the few "long"
+// cities whose disc reaches the block, and runs the same exact cascade once over those <= 64 candidates; rows the lists cannot
+// cover (an (a, b) longer than a's KA-th distance, a b with too long a reverse list) and sweeps with too many long cities walk
+// their tiles as before.  The loop is the main loop's pruned shape only (any block shape gives the reference's moves), without a
+// descriptor: every wave carries the whole cursor — row, column, key slot, dirty tiles, `improved` — and meets the same barriers;
+// wave 0 does not scan: it keeps the accounting, resets the next key slot and enters each move's new edges in the long list.
+// State of a descent beside the tour: pos (city -> tour position), the long list (cities with a tour edge beyond their KB-th
+// squared distance: x, y, the larger of their two tour edges squared, city) and one scratch row per wave.
+struct NlLds {
+    uint16_t *pos;
+    uint4 *longe;
+    uint16_t *surv;
+};
+
+// the larger of the two tour edges at position k, squared, as bits (squares are >= +0: bits order like the values, NaNs last);
+// the closing edge p[n-1] -> p[0] is never a candidate's (c, e) and does not count
+template <typename PT>
+__device__ __forceinline__ uint32_t nl_r2_bits(const PT &P, uint32_t k, uint32_t n)
+{
+    const float2 pk = pt_get(P, k);
+    uint32_t r2 = 0u;
+    if (k >= 1u) r2 = __builtin_bit_cast(uint32_t, sqdist(pt_get(P, k - 1u), pk));
+    if (k + 1u < n) {
+        const uint32_t s = __builtin_bit_cast(uint32_t, sqdist(pk, pt_get(P, k + 1u)));
+        r2 = s > r2 ? s : r2;
+    }
+    return r2;
+}
+
+// After the hit (fi, fj) — reversal of [fi+1 .. fj] — the tour edges at positions fi, fi+1, fj, fj+1 are new: their four cities
+// get their entry's edge length refreshed, or an entry if they have become long.  One wave.
+template <typename PT>
+__device__ __forceinline__ void nl_fix(uint32_t fi, uint32_t fj, const PT &P, const uint16_t *perm, uint32_t n, Ctl *ctl, uint4 *longe, const uint32_t *__restrict__ dkb2,
+                                       int lane)
+{
+    uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->nlong);
+    if (cnt > (uint32_t)kNlLongCap) return;  // an incomplete list stays unused until the next rebuild
+    uint32_t p = lane == 0 ? fi : lane == 1 ? fi + 1u : lane == 2 ? fj : fj + 1u;
+    p = p < n ? p : n - 1u;
+    const uint32_t u = perm[p];
+    const uint32_t r2 = nl_r2_bits(P, p, n);
+    const float2 pk = pt_get(P, p);
+    const uint32_t lng = r2 > dkb2[u] ? 1u : 0u;
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t uq = readlane_u(u, (uint32_t)q), r2q = readlane_u(r2, (uint32_t)q);
+        bool found = false;
+        for (uint32_t base = 0; base < cnt && base < (uint32_t)kNlLongCap; base += 64u) {
+            const uint32_t idx = base + (uint32_t)lane;
+            const uint32_t city = idx < cnt ? longe[idx].w : 0xFFFFFFFFu;
+            const uint64_t m = __builtin_amdgcn_ballot_w64(city == uq);
+            if (m) {
+                if (lane == 0) longe[base + (uint32_t)(__builtin_ffsll((long long)m) - 1)].z = r2q;
+                found = true;
+            }
+        }
+        if (!found && readlane_u(lng, (uint32_t)q)) {
+            if (cnt < (uint32_t)kNlLongCap && lane == 0)
+                longe[cnt] = make_uint4(readlane_u(__builtin_bit_cast(uint32_t, pk.x), (uint32_t)q), readlane_u(__builtin_bit_cast(uint32_t, pk.y), (uint32_t)q), r2q, uq);
+            cnt += 1u;
+        }
+    }
+    if (lane == 0) ctl->nlong = cnt;
+}
+
+// one row of the tile path: L0 (lanes = tiles) over the groups from the row's first column on, L1.. on the live tiles; the row's
+// first improving column or 0xFFFFFFFF  (the main loop has the same code inline)
+template <bool PRUNE, typename TC, typename PT>
+__device__ __forceinline__ uint32_t row_tiles(const PT &P, uint32_t n, int G, const float4 *box, const float *msq, uint32_t jmin, float rax, float ray, float rbx,
+                                              float rby, float rsqab, int lane, TC &tc)
+{
+    const uint32_t tmin = jmin >> 6;
+#pragma unroll
+    for (int gI = 0; gI < kMaxGroups; ++gI) {
+        if (gI < G && (((uint32_t)gI + 1u) << 6) > tmin) {
+            const uint32_t tl = ((uint32_t)gI << 6) + (uint32_t)lane;
+            uint64_t m = __builtin_amdgcn_ballot_w64(tl >= tmin) &
+                         (__builtin_amdgcn_ballot_w64(box_lb(rax, ray, box[gI]) < rsqab) | __builtin_amdgcn_ballot_w64(box_lb(rbx, rby, box[gI]) < msq[gI]));
+            tc.l0 += 64u;
+            while (m != 0) {
+                const uint32_t t = ((uint32_t)gI << 6) + (uint32_t)(__builtin_ffsll((long long)m) - 1);
+                m &= m - 1;
+                tc.ptile += 1u;
+                const uint64_t hm = tile_improving_mask<PRUNE>(P, n, t << 6, jmin, rax, ray, rbx, rby, rsqab, lane, tc);
+                if (hm) return (t << 6) + (uint32_t)(__builtin_ffsll((long long)hm) - 1);
+            }
+        }
+    }
+    return 0xFFFFFFFFu;
+}
+
+// the first improving column among per-lane candidates (c = p[j], e = p[j+1], invalid lanes: j = 0xFFFFFFFF), or 0xFFFFFFFF
+template <typename TC, typename PT>
+__device__ __forceinline__ uint32_t nl_pass(const PT &P, uint32_t n, uint32_t j, uint32_t jmin, float rax, float ray, float rbx, float rby, float rsqab, int lane, TC &tc)
+{
+    const uint32_t jl = j < n - 2u ? j : n - 2u;  // (out-of-range columns are masked by the cascade's range test)
+    const uint64_t m = tile_mask_core<true>(pt_get(P, jl), pt_get(P, jl + 1u), j, n, jmin, rax, ray, rbx, rby, rsqab, tc);
+    if (!m) return 0xFFFFFFFFu;
+    const uint32_t key = ((m >> lane) & 1ull) ? ~j : 0u;
+    return ~readlane_u(wave_max_key_lane63(key), 63u);
+}
+
+template <int NT, typename TC, typename PT>
+__device__ __forceinline__ void late_phase(const TwoOptBatchArgs &A, const PT &P, uint16_t *perm, float4 *tbox, float *tmsq, Ctl *ctl, const NlLds &L, uint32_t d,
+                                           uint32_t n, uint32_t nrows, uint32_t ntile, int G, uint32_t dirty_lo, uint32_t dirty_hi, Acct &acct, uint32_t &sweeps,
+                                           uint32_t &step, uint32_t &status, uint32_t &n_late_steps, TC &tc, int lane, int wave, int tid)
+{
+    constexpr int NW = NT / 64;
+    constexpr int kLateRowsPerWave = 64 / NW;  // a chunk of 64 rows over the NW waves
+    const uint16_t *__restrict__ rec = A.nl.rec;
+    const uint32_t *__restrict__ dkb2 = A.nl.dkb2;
+    const bool control = wave == 0;  // wave 0 scans like the others and keeps the accounting beside it
+    if (tid < 3) ctl->kr[tid] = make_uint2(kNoKey, 0u);
+    TL_SYNC();
+    uint32_t i0 = nrows, j0 = 2u, slot = 0u;  // handed over at the end of a sweep that moved something
+    uint32_t fi = 0u, fj = 0u;
+    bool improved = true, nl_ok = false, fix = false;
+#ifdef TL_PROFILE_LATE
+    uint64_t lq[6] = {0, 0, 0, 0, 0, 0};  // wave 1 of descent 0: cycles of chunk set-up, long-list prefilter, rows; rows; wait at B2; rest of the scan loop
+#endif
+    for (;;) {
+        if (i0 >= nrows) {  // sweep finished (two_opt.rs:26-28)
+            if (!improved) break;
+            if (sweeps >= A.max_sweeps) {
+                status = 1;
+                break;
+            }
+            improved = false;
+            ++sweeps;
+            i0 = 0u;
+            j0 = 2u;
+            nl_ok = false;  // the long list is rebuilt once per sweep (entries that are no longer long go)
+            if (control && acct.log) {
+                if (lane == 0 && acct.log_n < acct.log_cap) acct.log[acct.log_n] = 0xFFFFFFFFu;
+                acct.log_n += 1u;
+            }
+        }
+        // A step scans the REST of the sweep under "no move yet": rows are dealt in chunks of 64 (the lane-resident row table), wave w
+        // takes rows 4w .. 4w+3 of every chunk and goes from chunk to chunk without a barrier — the tour does not change while a
+        // step scans — until it has posted a hit or finds one posted in an earlier row.  So a sweep costs one barrier per move.
+        const uint32_t R = nrows - i0;
+        uint32_t *keyslot = &ctl->kr[slot].x;
+        const uint32_t slot_next = slot == 2u ? 0u : slot + 1u;
+        if (control) {
+            if (lane == 0) ctl->kr[slot_next].x = kNoKey;  // (its last readers are two barriers behind)
+            ++step;
+            ++n_late_steps;
+        }
+        // ---- in front of the scan, by every wave alike: stale tile boxes (each wave its share), the city -> position table and the
+        // long list (rebuilt at a sweep's start, brought up to date after a move), one barrier (a rebuild: two)
+        const bool dirty = dirty_lo <= dirty_hi;
+        if (tid == 0) ctl->late_cur = i0;
+        {
+            if (dirty) {
+                for (uint32_t t = dirty_lo + (uint32_t)wave; t <= dirty_hi; t += (uint32_t)NW) build_tile_meta(P, n, t, lane, tbox, tmsq);
+                dirty_lo = 0xFFFFFFFFu;
+                dirty_hi = 0;
+            }
+            if (!nl_ok) {
+                for (uint32_t k = (uint32_t)tid; k < n; k += (uint32_t)NT) L.pos[perm[k]] = (uint16_t)k;
+                if (tid == 0) ctl->nlong = 0u;
+                TL_SYNC();
+                for (uint32_t k = (uint32_t)tid; k < n; k += (uint32_t)NT) {
+                    const uint32_t u = perm[k];
+                    const uint32_t r2 = nl_r2_bits(P, k, n);
+                    if (r2 > dkb2[u]) {
+                        const uint32_t idx = atomicAdd(&ctl->nlong, 1u);
+                        if (idx < (uint32_t)kNlLongCap) {
+                            const float2 pk = pt_get(P, k);
+                            L.longe[idx] = make_uint4(__builtin_bit_cast(uint32_t, pk.x), __builtin_bit_cast(uint32_t, pk.y), r2, u);
+                        }
+                    }
+                }
+                nl_ok = true;
+            } else if (fix) {
+                if (control) nl_fix(fi, fj, P, perm, n, ctl, L.longe, dkb2, lane);
+            }
+            fix = false;
+            TL_SYNC();
+        }
+        {
+            const uint32_t nlong = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->nlong);
+            const bool use_nl = nlong <= (uint32_t)kNlLongCap;
+            const uint32_t iend = i0 + R;
+            uint16_t *sv = L.surv + ((uint32_t)wave << 6);
+            // the cities at the chunk's positions (lane l: position c0 + l, and c0 + l + 1 for the rows' b), one chunk ahead of the scan:
+            // the first record of the next chunk is requested while this chunk's last row is decided
+            auto load_ids = [&](uint32_t c0, uint32_t &ida, uint32_t &idb) {
+                const uint32_t pa = c0 + (uint32_t)lane, pb = pa + 1u;
+                ida = perm[pa < n ? pa : n - 1u];
+                idb = perm[pb < n ? pb : n - 1u];
+            };
+            // a row's record pair: word l of a's record (the KA-th distance, a's nearest), of b's for the count and the reverse list
+            auto load_rec = [&](uint32_t ida, uint32_t idb, uint32_t r) -> uint32_t {
+                const uint32_t a_id = readlane_u(ida, r), b_id = readlane_u(idb, r);
+                const uint32_t src = (lane < kNlRecB0 && lane != 2) ? a_id : b_id;
+                return rec[(size_t)src * 64u + (uint32_t)lane];
+            };
+            // rows are taken kLateRowsPerWave at a time from a counter, in order: a wave that meets an expensive row (tiles) simply takes
+            // fewer; the next take is made, and its first record requested, while the current rows are decided
+            auto grab = [&]() -> uint32_t {
+                uint32_t v = 0u;
+                if (lane == 0) v = atomicAdd(&ctl->late_cur, (uint32_t)kLateRowsPerWave);
+                return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+            };
+            uint32_t g = grab();
+            uint32_t ida = 0u, idb = 0u, recw = 0u;
+            if (g < iend) {
+                load_ids(i0 + ((g - i0) & ~63u), ida, idb);
+                if (use_nl) recw = load_rec(ida, idb, (g - i0) & 63u);
+            }
+            bool stop = false;
+#ifdef TL_PROFILE_LATE
+            uint64_t tq = __builtin_amdgcn_s_memtime();
+#define TL_LSTAMP(k) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); lq[k] += t_ - tq; tq = t_; } while (0)
+#else
+#define TL_LSTAMP(k) do { } while (0)
+#endif
+            while (g < iend && !stop) {
+                const uint32_t c0 = i0 + ((g - i0) & ~63u), r0 = (g - i0) & 63u;  // the chunk of 64 rows (the lane-resident row table) these rows lie in
+                const uint32_t gn = grab();
+                const uint32_t r0n = (gn - i0) & 63u;
+                TL_LSTAMP(5);
+                // lane-resident row table: lane l holds P[c0+l], P[c0+l+1] and their squared distance
+                const float2 rp = pt_get(P, c0 + (uint32_t)lane);
+                const float2 rq = pt_get(P, c0 + (uint32_t)lane + 1u);
+                const float rowsq = sqdist(rp, rq);
+                const uint32_t cida = ida, cidb = idb;
+                if (gn < iend) load_ids(i0 + ((gn - i0) & ~63u), ida, idb);
+                // the long cities that can matter for this chunk: sq(b, e) >= lb(e, box of the chunk's b's) >= r2(e) >= sq(c, e) rules e
+                // out for every row of it.  Every b of the chunk lies in the boxes of the (at most two) tiles its positions fall in.
+                uint32_t surv8 = 0u, ns = 0u;
+                TL_LSTAMP(0);
+                if (use_nl && nlong) {
+                    const uint32_t tA = c0 >> 6, tB1 = (c0 + 64u) >> 6, tB = tB1 < ntile ? tB1 : ntile - 1u;
+                    const float4 ba = tbox[tA], bb = tbox[tB];
+                    const float4 bu = make_float4(fminf(ba.x, bb.x), fminf(ba.y, bb.y), fmaxf(ba.z, bb.z), fmaxf(ba.w, bb.w));
+                    for (uint32_t base = 0; base < nlong; base += 64u) {
+                        const uint32_t idx = base + (uint32_t)lane;
+                        const uint4 le = L.longe[idx < nlong ? idx : 0u];
+                        const float lb = box_lb(__builtin_bit_cast(float, le.x), __builtin_bit_cast(float, le.y), bu);
+                        const bool live = idx < nlong && !(lb >= __builtin_bit_cast(float, le.z));
+                        const uint64_t m = __builtin_amdgcn_ballot_w64(live);
+                        if (m) {
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                            if (live && ns + rank < 64u) sv[ns + rank] = (uint16_t)le.w;
+                            ns += (uint32_t)__builtin_popcountll(m);
+                        }
+                    }
+                    if (ns) surv8 = sv[lane >= kNlSurv0 ? lane - kNlSurv0 : 0];
+                }
+                const bool nl_rows = use_nl && ns <= 64u;  // (more survivors than a pass holds: this wave walks tiles, and decides the same)
+                if (ns < (uint32_t)kNlSurvSlots) surv8 = (uint32_t)lane >= (uint32_t)kNlSurv0 + ns ? 0xFFFFu : surv8;  // (0xFFFF: no city)
+                TL_LSTAMP(1);
+                {   // a hit posted in a row before this wave's rows of the chunk makes them, and every later one, moot
+                    const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot);
+                    if (kb != kNoKey && (kb >> 16) < g) break;
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < (uint32_t)kLateRowsPerWave; ++q) {
+                    const uint32_t r = r0 + q, i = c0 + r;
+                    if (i >= iend) break;
+                    const uint32_t cur = recw;
+                    if (use_nl) {  // the next row's record is on its way while this one is decided
+                        if (q + 1u < (uint32_t)kLateRowsPerWave) recw = load_rec(cida, cidb, r + 1u);  // (past the sweep's end: some valid city's, unused)
+                        else recw = load_rec(ida, idb, r0n);                                           // (no next take: this chunk's cities again, unused)
+                    }
+                    const float rax = readlane_f(rp.x, r), ray = readlane_f(rp.y, r);
+                    const float rbx = readlane_f(rq.x, r), rby = readlane_f(rq.y, r);
+                    const float rsqab = readlane_f(rowsq, r);
+                    const uint32_t jmin = (i == i0) ? j0 : (i + 2u);
+                    tc.prow += 1u;
+                    uint32_t col = 0xFFFFFFFFu;
+                    bool listed = false;
+                    if (nl_rows) {
+                        // word 0 (a's): the high half of a's KA-th squared distance — an (a, b) that is not below it could have a closer
+                        // c outside a's list; word 2 (b's): set when b's reverse list is incomplete.  Either way: tiles.
+                        const uint32_t w = cur & 0xFFFFu;
+                        const bool bad = lane == 0 ? !((__builtin_bit_cast(uint32_t, rsqab) >> 16) < w) : (lane == 2 && w != 0u);
+                        if (!__builtin_amdgcn_ballot_w64(bad)) {
+                            listed = true;
+                            uint32_t u = lane >= kNlSurv0 ? surv8 : w;
+                            const bool valid = lane >= kNlRecA0 && u != 0xFFFFu;  // (empty slots hold 0xFFFF)
+                            u = valid ? u : 0u;
+                            const uint32_t pu = L.pos[u];
+                            uint32_t j = lane < kNlRecB0 ? pu : pu - 1u;  // a's neighbour is c = p[j]; the others are e = p[j+1]
+                            j = valid ? j : 0xFFFFFFFFu;
+                            col = nl_pass(P, n, j, jmin, rax, ray, rbx, rby, rsqab, lane, tc);
+                            if (ns > (uint32_t)kNlSurvSlots) {  // more long cities than the pass has spare lanes: one more pass
+                                const uint32_t q2 = (uint32_t)kNlSurvSlots + (uint32_t)lane;
+                                const bool v2 = q2 < ns;
+                                const uint32_t u2 = v2 ? sv[q2 < 64u ? q2 : 0u] : 0u;
+                                const uint32_t p2 = L.pos[u2];
+                                const uint32_t c2 = nl_pass(P, n, v2 ? p2 - 1u : 0xFFFFFFFFu, jmin, rax, ray, rbx, rby, rsqab, lane, tc);
+                                col = c2 < col ? c2 : col;
+                            }
+                        }
+                    }
+                    if (!listed) {  // the tile path: L0 (lanes = tiles) against the boxes, L1.. on the live tiles
+                        float4 box[kMaxGroups];
+                        float msq[kMaxGroups];
+#pragma unroll
+                        for (int gI = 0; gI < kMaxGroups; ++gI) {
+                            if (gI < G) {
+                                box[gI] = tbox[((uint32_t)gI << 6) + (uint32_t)lane];
+                                msq[gI] = tmsq[((uint32_t)gI << 6) + (uint32_t)lane];
+                            }
+                        }
+                        col = row_tiles<true>(P, n, G, box, msq, jmin, rax, ray, rbx, rby, rsqab, lane, tc);
+                    }
+                    TL_LSTAMP(2);
+#ifdef TL_PROFILE_LATE
+                    lq[3] += 1;
+#endif
+                    if (col == 0xFFFFFFFFu) continue;  // nothing in this row
+                    // (fenced: the way from here to the barrier holds no tracked LDS operation of this wave, tl_device.h)
+                    if (lane == 0) lds_min_u32_fenced(keyslot, (i << 16) | col);
+                    stop = true;  // this wave's later rows are later rows
+                    break;
+                }
+                g = gn;
+            }
+            TL_LSTAMP(5);
+        }
+#ifdef TL_PROFILE_LATE
+        const uint64_t tb2 = __builtin_amdgcn_s_memtime();
+#endif
+        TL_SYNC();  // B2
+#ifdef TL_PROFILE_LATE
+        lq[4] += __builtin_amdgcn_s_memtime() - tb2;
+#endif
+        const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->kr[slot].x);
+        if (key == kNoKey) {
+            i0 += R;
+            j0 = i0 + 2u;
+        } else {
+            const uint32_t is = key >> 16, js = key & 0xFFFFu;
+            reverse_segment<NT>(P, perm, is + 1u, js, tid, L.pos);  // two_opt.rs:50,69-79  swap_2opt(path, i+1, j)
+            TL_SYNC();
+            if (control) {
+                if (acct.log) {
+                    if (lane == 0 && acct.log_n < acct.log_cap) acct.log[acct.log_n] = key;  // row << 16 | column
+                    acct.log_n += 1u;
+                }
+                acct.moves += 1u;
+                acct.reversed += (uint64_t)(js - is);
+            }
+            improved = true;
+            const uint32_t t0 = is >> 6, t1 = js >> 6;  // L0 metadata of every tile that saw a changed position or tour-edge
+            dirty_lo = t0 < dirty_lo ? t0 : dirty_lo;
+            dirty_hi = t1 > dirty_hi ? t1 : dirty_hi;
+            fix = true;  // the move's two new edges are entered in the long list in front of the next scan
+            fi = is;
+            fj = js;
+            i0 = is;
+            j0 = js + 1u;
+            if (j0 > n - 2u) {
+                i0 += 1u;
+                j0 = i0 + 2u;
+            }
+        }
+        slot = slot_next;
+    }
+#ifdef TL_PROFILE_LATE
+    if (d == 0 && lane == 0 && (wave == 1 || wave == 9))
+        printf("late phase, wave %d: chunk set-up %lu, prefilter %lu, rows %lu cycles in %lu rows (%lu per row), B2 wait %lu, other %lu\n", wave, lq[0], lq[1], lq[2], lq[3],
+               lq[2] / (lq[3] ? lq[3] : 1), lq[4], lq[5]);
+#endif
+    (void)d;
+}
+
 }  // namespace
 
 // NT = 1024 (16 waves) is the form of a descent that has a CU to itself.  Where the LDS holds two or four tours (n <= ~7100 /
 // ~3000) and the batch has more descents than the chip has CUs, the 8- or 4-wave forms run 2 or 4 descents per CU: a descent
 // leaves its SIMDs idle ~80 % of the time and half the waves cost it only 7 %, so a neighbour's descent
 // fills the issue slots — 1.57 x the restarts per second at n = 7000.  At most 128 VGPRs (4 waves per SIMD) in every form.
-template <int NT, bool PRUNE, bool COUNT, bool FX>
+template <int NT, bool PRUNE, bool COUNT, bool FX, bool NL = false>
 __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 {
+    static_assert(!NL || (PRUNE && !FX && NT == 1024), "late phase: the 16-wave float2 form with pruning");
     constexpr int kSlots = FX ? kFlushSlotsFx : kFlushSlots;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = NT / 64;
@@ -368,6 +755,13 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     // hit lists (kQCap words per (wave, step parity)) during the descent; reused as NT floats for the cost sum
     uint32_t *queues = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(ctl) + kCtlBytes);
     float *scratch = reinterpret_cast<float *>(queues);
+    NlLds L{nullptr, nullptr, nullptr};  // late phase: city -> position, long list, per-wave scratch (behind the hit lists)
+    if constexpr (NL) {
+        unsigned char *nlp = reinterpret_cast<unsigned char *>(queues) + 32 * kQCap * 4;
+        L.pos = reinterpret_cast<uint16_t *>(nlp);
+        L.longe = reinterpret_cast<uint4 *>(nlp + (size_t)npad * 2);
+        L.surv = reinterpret_cast<uint16_t *>(nlp + (size_t)npad * 2 + (size_t)kNlLongCap * 16);
+    }
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> SGPR loop control
@@ -423,6 +817,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     if (tid < 4) ctl->kr[tid] = make_uint2(kNoKey, 0u);
     if (tid < 6) ctl->cnt[tid] = 0ull;
     if (tid == 0) {
+        ctl->nlong = 0u;
         ctl->clk0 = __builtin_amdgcn_s_memtime();
         ctl->rt0 = __builtin_amdgcn_s_memrealtime();
     }
@@ -473,7 +868,10 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
     // second word is the request, so a wave reads both with one 8-byte LDS read — and
     // every wave has two hit lists, used by the step's parity (a list is read after B2 while its owner may already write the
     // next step's).  The owner of a step's hits files them in ctl->pend itself (it still holds them in a register).
-    enum : uint32_t { OP_GO = 0u, OP_EXIT = 2u };
+    enum : uint32_t { OP_GO = 0u, OP_LATE = 1u, OP_EXIT = 2u };  // OP_LATE: the main loop ends here, the late phase takes the next sweep
+    bool go_late = false;
+    uint32_t n_late_steps = 0;
+    uint64_t late_clk = 0;  // shader clocks of the late phase (stats word 13, high part)
     constexpr int NWK = NW - 1;                                  // workers
     constexpr uint32_t kLead = kDenseLead < (uint32_t)NWK ? kDenseLead : (uint32_t)NWK;
     static_assert(4u <= kQCap, "a hit list fits its slot");
@@ -507,6 +905,8 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                     } else if (sweeps >= A.max_sweeps) {
                         status = 1;
                         done = true;
+                    } else if (NL && sweeps + 1u >= A.nl.sweep_min) {
+                        go_late = true;
                     } else {
 #ifdef TL_PROFILE4
                         if (d == 0 && lane == 0)
@@ -529,8 +929,10 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 }
                 // block shape: dense (moves every few rows: one row, every tile) or pruned (up to kRMax rows, L0)
                 c.pruned = PRUNE && !done && fmaxf(acct.gap_est, acct.since) > TL_DENSE_ROWS * (float)(n - 2u - c.i0);
-                if (lane == 0)
-                    *reinterpret_cast<uint2 *>(ctl->desc) = make_uint2((done ? OP_EXIT : OP_GO) | (c.pruned ? 4u : 0u), c.i0 | (c.j0 << 16));
+                if (lane == 0) {
+                    *reinterpret_cast<uint2 *>(ctl->desc) = make_uint2((done ? OP_EXIT : go_late ? OP_LATE : OP_GO) | (c.pruned ? 4u : 0u), c.i0 | (c.j0 << 16));
+                    if (NL) ctl->desc[2] = sweeps;
+                }
                 TL_SYNC();  // B0
                 if (lane == 0) {  // behind B0: a slow worker may have been reading its request word until it got here
                     ctl->kr[0].y = 0u;
@@ -538,7 +940,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                     ctl->kr[2].y = 0u;
                 }
                 if (c.np) flush_pending<true, NT, kSlots>(c, acct, P, perm, ctl, lane, wave, false);
-                if (done) break;
+                if (done || go_late) break;
             }
             const uint32_t slot_next = c.slot == 2u ? 0u : c.slot + 1u;
             if (lane == 0) ctl->kr[slot_next].x = kNoKey;  // slot of the next step (its last readers are two barriers behind)
@@ -628,6 +1030,13 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             }
 #endif
         }
+        if constexpr (NL) {
+            if (go_late) {
+                late_clk = __builtin_amdgcn_s_memtime();
+                late_phase<NT>(A, P, perm, tbox, tmsq, ctl, L, d, n, nrows, ntile, G, c.dirty_lo, c.dirty_hi, acct, sweeps, step, status, n_late_steps, tc, lane, wave, tid);
+                late_clk = __builtin_amdgcn_s_memtime() - late_clk;
+            }
+        }
         moves = acct.moves;
         reversed = acct.reversed;
         rev_lane = acct.rev_lane;
@@ -645,8 +1054,8 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #if !defined(TL_PROFILE2) && !defined(TL_PROFILE3)
         if (tid == 0) {
             uint64_t *st = A.out_stats + (size_t)d * TL_STATS_STRIDE;
-            st[13] = n_desc;          // descriptors published (sweep ends + block-shape changes)
-            st[14] = n_pruned_steps;  // steps in pruned shape
+            st[13] = (uint64_t)n_desc | (late_clk << 24);  // descriptors published (sweep ends + block-shape changes) | shader clocks of the late phase << 24
+            st[14] = (uint64_t)(n_pruned_steps + n_late_steps) | ((uint64_t)n_late_steps << 32);  // steps in pruned shape | of those, late-phase steps << 32
             st[15] = acct.log_n;      // words offered to the move log: moves + sweep marks (more than its capacity: the log is a prefix)
         }
 #endif
@@ -681,7 +1090,11 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 const uint2 dv = *reinterpret_cast<const uint2 *>(ctl->desc);
                 const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dv.x), w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dv.y);
                 if (c.np) flush_pending<false, NT, kSlots>(c, acct, P, perm, ctl, lane, wave, false);
-                if ((w0 & 3u) == OP_EXIT) break;
+                if ((w0 & 3u) != OP_GO) {
+                    go_late = NL && (w0 & 3u) == OP_LATE;
+                    if (NL) sweeps = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->desc[2]);
+                    break;
+                }
                 c.pruned = (w0 & 4u) != 0u;
                 c.i0 = w1 & 0xFFFFu;
                 c.j0 = w1 >> 16;
@@ -794,6 +1207,9 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
             }
 #endif
             need_desc = step_boundary<false, NT, kSlots>(c, acct, P, perm, ctl, queues, n, nrows, R, lane, wave, tid, my_hits, bx, by, reload);
+        }
+        if constexpr (NL) {
+            if (go_late) late_phase<NT>(A, P, perm, tbox, tmsq, ctl, L, d, n, nrows, ntile, G, c.dirty_lo, c.dirty_hi, acct, sweeps, step, status, n_late_steps, tc, lane, wave, tid);
         }
 #ifdef TL_PROFILE3
         if (d == 0 && lane == 0 && (wave == 1 || wave == 6))  // a lead wave and a non-lead one
@@ -936,10 +1352,10 @@ hipError_t launch_fx_encode(const float2 *xy, uint32_t n, double scale, uint2 *o
     return hipGetLastError();
 }
 
-template <int NT, bool PRUNE, bool COUNT, bool FX>
+template <int NT, bool PRUNE, bool COUNT, bool FX, bool NL = false>
 static hipError_t launch_one(const TwoOptBatchArgs &A, uint32_t count, size_t lds, hipStream_t s)
 {
-    auto kern = k_two_opt_ref_lds<NT, PRUNE, COUNT, FX>;
+    auto kern = k_two_opt_ref_lds<NT, PRUNE, COUNT, FX, NL>;
     hipError_t e = allow_max_lds(reinterpret_cast<const void *>(kern));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(count), dim3(NT), lds, s, A);
@@ -951,6 +1367,10 @@ static hipError_t launch_nt(const TwoOptBatchArgs &B, uint32_t count, size_t lds
 {
     // the counting instantiation (TL_FLAG_COUNT_WORK) exists for the form bench.py counts — one descent per CU on 16 waves, plain
     // points; the narrower / grid-coordinate forms run uncounted (stats words 5..8 stay 0): 14 instantiations to compile, not 24
+    if constexpr (NT == 1024 && !FX) {
+        if (prune && B.nl.rec)  // neighbour lists for the late sweeps (the caller has sized `lds` for their state)
+            return count_work ? launch_one<NT, true, true, FX, true>(B, count, lds, s) : launch_one<NT, true, false, FX, true>(B, count, lds, s);
+    }
     if constexpr (NT == TL_TWO_OPT_NT && !FX) {
         if (count_work) return prune ? launch_one<NT, true, true, FX>(B, count, lds, s) : launch_one<NT, false, true, FX>(B, count, lds, s);
     }
@@ -982,9 +1402,29 @@ hipError_t launch_two_opt_ref_lds(const TwoOptBatchArgs &A, uint32_t count, bool
         else if (fit >= 2) nt = 512;
     }
     while (nt < TL_TWO_OPT_NT && (size_t)A.n > (size_t)kFlushSlots * (size_t)nt) nt *= 2;
+    if (nt != 1024 || !prune || two_opt_ref_nl_lds_bytes(A.n) > (size_t)lds_budget) B.nl.rec = nullptr;  // the lists are read by the 16-wave form only
     if (nt == 256) return launch_nt<256, false>(B, count, lds, prune, count_work, s);
     if (nt == 512) return launch_nt<512, false>(B, count, lds, prune, count_work, s);
-    return launch_nt<TL_TWO_OPT_NT, false>(B, count, lds, prune, count_work, s);
+    return launch_nt<TL_TWO_OPT_NT, false>(B, count, B.nl.rec ? two_opt_ref_nl_lds_bytes(A.n) : lds, prune, count_work, s);
+}
+
+size_t two_opt_ref_nl_lds_bytes(uint32_t n)
+{
+    uint32_t n_pad = 0;
+    const size_t base = two_opt_ref_lds_bytes(n, &n_pad, TL_TWO_OPT_NT);
+    if (base == ~(size_t)0) return base;
+    return base + (size_t)n_pad * 2 + (size_t)kNlLongCap * 16 + (size_t)16 * 64 * 2;
+}
+
+bool two_opt_ref_nl_applies(uint32_t n, uint32_t count, int cus, int lds_budget, int force_nt)
+{
+    if (TL_TWO_OPT_NT != 1024 || (force_nt && force_nt != 1024)) return false;
+    if (n <= (uint32_t)kNlKB + 1u || n > 65535u || two_opt_ref_nl_lds_bytes(n) > (size_t)lds_budget) return false;
+    if (!force_nt && cus > 0 && count > (uint32_t)cus) {  // (the batch would run two or four descents per CU on 8 / 4 waves)
+        const size_t lds = two_opt_ref_lds_bytes(n, nullptr, TL_TWO_OPT_NT);
+        if (lds && (size_t)lds_budget / lds >= 2) return false;
+    }
+    return true;
 }
 
 }  // namespace tl

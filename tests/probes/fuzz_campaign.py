@@ -8,7 +8,8 @@ import numpy as np, _oracle as O, teeline_amd as TA
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 t0 = time.time(); runs = fails = 0
 with TA.Context(0) as ctx, TA.Context(0, TA.TL_FLAG_NO_PRUNE) as ctx2, TA.Context(0, TA.TL_FLAG_2OPT_NT512) as ctx3, \
-        TA.Context(0, TA.TL_FLAG_2OPT_NT256) as ctx4, TA.Context(0, TA.TL_FLAG_2OPT_FX) as ctx5:
+        TA.Context(0, TA.TL_FLAG_2OPT_NT256) as ctx4, TA.Context(0, TA.TL_FLAG_2OPT_FX) as ctx5, TA.Context(0, TA.TL_FLAG_2OPT_NL_ALWAYS) as ctx6, \
+        TA.Context(0, TA.TL_FLAG_2OPT_NO_NL) as ctx7:
     seed = 0
     while time.time() - t0 < budget:
         seed += 1
@@ -42,6 +43,10 @@ with TA.Context(0) as ctx, TA.Context(0, TA.TL_FLAG_NO_PRUNE) as ctx2, TA.Contex
         # grid-coordinate form of the tour (used where the instance lies on a decimal grid: kinds 0 / 2 / 4 / 5 mostly do not, kind 1
         # — integer lattices — does; the library falls back to float2 by itself)
         if seed % 2 == 1: cases.append(("fx", prob, ctx5))
+        # the late phase (neighbour-list rows, csrc/two_opt_nl.hip) from the second sweep on at every n it takes (n >= 26; by default
+        # it starts later in a descent and only from n = 3000), and the kernel without it
+        cases.append(("nl", prob, ctx6))
+        if seed % 4 == 0: cases.append(("no_nl", prob, ctx7))
         if n <= 1500 and seed % 3 == 0:
             dm = TA.distance_matrix.build(np.arange(n), xy, ctx=ctx)
             cases.append(("matrix", TA.TspProblem(np.arange(n), xy, TA.distance_matrix.DistanceMatrix(n, dm.items, np.arange(n), "explicit")), ctx))

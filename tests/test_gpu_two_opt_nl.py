@@ -1,0 +1,166 @@
+"""The late phase of the LDS 2-opt descent (neighbour-list rows, teeline_amd/csrc/two_opt_nl.hip): the lists against a numpy
+restatement, and the descent with the lists in use from the second sweep on (TL_FLAG_2OPT_NL_ALWAYS) against the oracle.
+Reference: src/tsp/two_opt.rs:26-61 — the lists only change WHICH candidates a row looks at, never a decision."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nl_ctx():
+    import teeline_amd as TA
+    c = TA.Context(0, TA.TL_FLAG_2OPT_NL_ALWAYS)
+    yield c
+    c.close()
+
+
+def sq_bits(xy, u):
+    """bits of fl(fl(dx*dx) + fl(dy*dy)) from city u to every city, the kernels' sqdist (tl_device.h)"""
+    d = xy[u][None, :] - xy
+    d = (d * d).astype(np.float32)
+    return (d[:, 0] + d[:, 1]).astype(np.float32).view(np.uint32).astype(np.int64)
+
+
+def lists(ctx, xy):
+    n = len(xy)
+    ka, kb, rb = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    rec = np.empty((n, 64), np.uint16)
+    dkb2 = np.empty(n, np.uint32)
+    knn_b = np.empty((n, 24), np.uint16)
+    rcnt = np.empty(n, np.uint32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    ctx.check(ctx.lib.tl_two_opt_neighbour_lists(ctx.handle, p(xy), n, p(rec), p(dkb2), p(knn_b), p(rcnt), C.byref(ka), C.byref(kb), C.byref(rb)))
+    assert (ka.value, kb.value, rb.value) == (16, 24, 36)
+    return rec, dkb2, knn_b, rcnt
+
+
+@pytest.mark.parametrize("kind,n", [("uniform", 3000), ("lattice", 900), ("clusters", 1500), ("duplicates", 400)])
+def test_neighbour_lists_match_numpy(ctx, kind, n):
+    rng = np.random.default_rng(5)
+    if kind == "uniform":
+        xy = rng.random((n, 2)) * 1000
+    elif kind == "lattice":  # ties at every distance
+        xy = np.stack(np.meshgrid(np.arange(30), np.arange(30)), -1).reshape(-1, 2)[rng.permutation(900)]
+    elif kind == "clusters":  # reverse lists far beyond their 36 slots
+        c = rng.random((5, 2)) * 1000
+        xy = c[rng.integers(0, 5, n)] + rng.normal(0, 1.0, (n, 2))
+    else:  # many cities at the same point
+        xy = rng.integers(0, 6, (n, 2))
+    xy = np.ascontiguousarray(xy, dtype=np.float32)
+    rec, dkb2, knn_b, rcnt = lists(ctx, xy)
+    want_cnt = np.zeros(n, np.int64)
+    for u in range(n):
+        d = sq_bits(xy, u)
+        d[u] = 1 << 40
+        srt = np.sort(d)
+        # the KB nearest: everything strictly closer than the KB-th distance, the rest of the list at exactly that distance
+        assert int(dkb2[u]) == srt[23]
+        lb = knn_b[u].astype(np.int64)
+        assert len(set(lb.tolist())) == 24 and u not in lb
+        assert set(np.nonzero(d < srt[23])[0].tolist()) <= set(lb.tolist()) and (d[lb] <= srt[23]).all()
+        np.add.at(want_cnt, lb, 1)
+        la = rec[u, 4:20].astype(np.int64)
+        assert len(set(la.tolist())) == 16 and u not in la
+        assert set(np.nonzero(d < srt[15])[0].tolist()) <= set(la.tolist()) and (d[la] <= srt[15]).all()
+        assert int(rec[u, 0]) == srt[15] >> 16
+    assert rcnt.astype(np.int64).tolist() == want_cnt.tolist()
+    rev = [set() for _ in range(n)]
+    for u in range(n):
+        for v in knn_b[u]:
+            rev[int(v)].add(u)
+    for v in range(n):
+        got = [int(x) for x in rec[v, 20:56] if x != 0xFFFF]
+        assert len(got) == min(len(rev[v]), 36) and len(set(got)) == len(got) and set(got) <= rev[v]
+        assert int(rec[v, 2]) == (1 if len(rev[v]) > 36 else 0)
+    if kind == "clusters":
+        assert (rec[:, 2] == 1).any()
+
+
+def solve(ctx, xy, init):
+    import teeline_amd as TA
+    n = len(xy)
+    sol = TA.two_opt.solve(TA.TspProblem(np.arange(n), xy), None, None, None if init is None else [int(v) for v in init], ctx=ctx)
+    return np.asarray(sol.route(), dtype=np.uint32), sol.total, sol.stats
+
+
+def same(gpu, ora):
+    route, cost, st = gpu
+    rc, oroute, ocost, ost = ora
+    assert rc == 0 and route.tolist() == oroute.tolist(), "tour differs from the oracle"
+    assert np.float32(cost).tobytes() == np.float32(ocost).tobytes()
+    for k in ("sweeps", "candidates", "moves", "reversed"):
+        assert st[k] == ost[k], f"{k}: gpu {st[k]} != oracle {ost[k]}"
+
+
+@pytest.mark.parametrize("n,seed", [(27, 3), (64, 1), (257, 2), (1002, 0), (2500, 7), (4097, 4)])
+def test_late_phase_from_the_second_sweep_on(nl_ctx, n, seed):
+    xy = O.synth_xy(n, seed=seed)
+    rp = O.restart_perm(n, 777, seed)
+    same(solve(nl_ctx, xy, rp), O.two_opt(xy, None, n, init=rp))
+    rc, nn, _ = O.nearest_neighbor(xy, None, n, 3)
+    same(solve(nl_ctx, xy, nn), O.two_opt(xy, None, n, init=nn))
+    same(solve(nl_ctx, xy, None), O.two_opt(xy, None, n, init=None))
+
+
+def test_late_phase_on_ties_duplicates_and_clusters(nl_ctx):
+    rng = np.random.default_rng(11)
+    # a lattice (every decision a near-tie), a handful of distinct points (most rows are zero-length edges), tight clusters far
+    # apart (reverse lists overflow, long edges between the clusters: rows fall back to tiles, the long list overflows)
+    lat = np.stack(np.meshgrid(np.arange(33), np.arange(31)), -1).reshape(-1, 2).astype(np.float32)
+    lat = np.ascontiguousarray(lat[rng.permutation(len(lat))])
+    dup = np.ascontiguousarray(rng.integers(0, 7, (600, 2)).astype(np.float32))
+    c = rng.random((6, 2)) * 10000
+    clu = np.ascontiguousarray((c[rng.integers(0, 6, 2000)] + rng.normal(0, 1.0, (2000, 2))).astype(np.float32))
+    line = np.sort(rng.random(800)).astype(np.float32) * 1000
+    col = np.ascontiguousarray(np.stack([line, 0.25 * line], 1).astype(np.float32))
+    for xy in (lat, dup, clu, col):
+        n = len(xy)
+        for init in (None, O.restart_perm(n, 5, 1)):
+            same(solve(nl_ctx, xy, init), O.two_opt(xy, None, n, init=init))
+
+
+def test_late_phase_move_list(nl_ctx):
+    # tl_two_opt_trace through the late phase: every move and every sweep mark in the reference's order
+    import teeline_amd as TA
+    from teeline_amd import _capi
+    for n, seed in ((700, 3), (3000, 4)):
+        xy = O.synth_xy(n, seed=seed)
+        init = O.restart_perm(n, 12345, 0)
+        rc, route, cost, st, ij, dist, sw = O.two_opt_trace(xy, None, n, init=init)
+        words, last = O.trace_words(ij, sw)
+        words += [0xFFFFFFFF] * (st["sweeps"] - last)
+        want = np.asarray(words, dtype=np.uint32)
+        out = np.empty(n, dtype=np.uint32)
+        c, stt, ln = C.c_float(), _capi.TlStats(), C.c_uint32()
+        log = np.zeros(len(want) + 3, dtype=np.uint32)
+        nl_ctx.check(nl_ctx.lib.tl_two_opt_trace(nl_ctx.handle, xy.ctypes.data_as(C.c_void_p), n, None, init.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                                 C.byref(c), C.byref(stt), log.ctypes.data_as(C.c_void_p), len(log), C.byref(ln)))
+        assert ln.value == len(want) and out.tolist() == route.tolist() and log[:len(want)].tolist() == want.tolist()
+
+
+def test_default_late_phase_equals_the_tile_only_kernel_on_a_batch(ctx):
+    # n = 10^4, eight seeded restarts: the default context (late phase from the fifth sweep on) against TL_FLAG_2OPT_NO_NL
+    import torch
+    import teeline_amd as TA
+    n, R = 10000, 8
+    xy = O.synth_xy(n)
+    dev = torch.device("cuda", 0)
+    d_xy = torch.from_numpy(xy).to(dev)
+    s = torch.cuda.current_stream()
+    res = []
+    with TA.Context(0, TA.TL_FLAG_2OPT_NO_NL) as plain:
+        for c in (ctx, plain):
+            d_pos = torch.empty((R, n), dtype=torch.int32, device=dev)
+            d_cost = torch.empty(R, dtype=torch.float32, device=dev)
+            d_st = torch.zeros((R, 16), dtype=torch.int64, device=dev)
+            c.check(c.lib.tl_two_opt_batch_dev(c.handle, d_xy.data_ptr(), n, None, 12345, 100, R, 0, d_pos.data_ptr(), d_cost.data_ptr(), d_st.data_ptr(), C.c_void_p(s.cuda_stream)))
+            torch.cuda.synchronize()
+            res.append((d_pos.cpu().numpy(), d_cost.cpu().numpy().view(np.uint32), d_st.cpu().numpy()))
+    (pa, ca, sa), (pb, cb, sb) = res
+    assert (pa == pb).all() and (ca == cb).all() and (sa[:, :4] == sb[:, :4]).all()
+    assert (sa[:, 14] >> 32).min() > 0 and (sb[:, 14] >> 32).max() == 0  # the default really went through the late phase
