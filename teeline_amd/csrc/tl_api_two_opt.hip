@@ -84,8 +84,11 @@ static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uin
         if (!A.fx_xy && !(c->flags & (TL_FLAG_NO_PRUNE | TL_FLAG_2OPT_NO_NL)) && (n >= 3000u || (c->flags & TL_FLAG_2OPT_NL_ALWAYS)) &&
             two_opt_ref_nl_applies(n, count, c->cus, c->lds_bytes, force_nt)) {
             int rc4;
+            const void *had = c->nl.p;
+            const size_t had_cap = c->nl.cap;
             if ((rc4 = ensure(c, c->nl, two_opt_nl_ws_bytes(n)))) return rc4;
-            HIPCHK(c, launch_two_opt_nl_build(d_xy, n, c->nl.p, &A.nl, s));
+            // (built once per instance: a later call with the same coordinates — compared on the device — finds them in place)
+            HIPCHK(c, launch_two_opt_nl_build(d_xy, n, c->nl.p, had != c->nl.p || had_cap != c->nl.cap, &A.nl, s));
             A.nl.sweep_min = (c->flags & TL_FLAG_2OPT_NL_ALWAYS) ? 2u : (uint32_t)TL_NL_SWEEP_MIN;
         }
         HIPCHK(c, launch_two_opt_ref_lds(A, count, !(c->flags & TL_FLAG_NO_PRUNE), s, (c->flags & TL_FLAG_COUNT_WORK) != 0, c->cus, c->lds_bytes, force_nt));
@@ -106,7 +109,8 @@ extern "C" int tl_two_opt_neighbour_lists(tl_ctx *c, const float *xy, uint32_t n
     if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->nl, two_opt_nl_ws_bytes(n)))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     TwoOptNl L{};
-    HIPCHK(c, launch_two_opt_nl_build((const float2 *)c->xy.p, n, c->nl.p, &L, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->nl.p, 0, 256, c->stream));  // (always a fresh build here)
+    HIPCHK(c, launch_two_opt_nl_build((const float2 *)c->xy.p, n, c->nl.p, true, &L, c->stream));
     HIPCHK(c, hipMemcpyAsync(rec, L.rec, (size_t)n * 128, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(dkb2, L.dkb2, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(knn_b, L.knn_b, (size_t)n * kNlKB * 2, hipMemcpyDeviceToHost, c->stream));

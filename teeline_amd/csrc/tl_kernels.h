@@ -60,7 +60,7 @@ struct TwoOptNl {
     uint32_t sweep_min;      // first sweep of a descent that may run in the late phase (neighbour-list rows)
 };
 size_t two_opt_nl_ws_bytes(uint32_t n);
-hipError_t launch_two_opt_nl_build(const float2 *xy, uint32_t n, void *ws, TwoOptNl *out, hipStream_t s);
+hipError_t launch_two_opt_nl_build(const float2 *xy, uint32_t n, void *ws, bool fresh, TwoOptNl *out, hipStream_t s);
 
 struct TwoOptBatchArgs {
     const float2 *xy;        // n cities, city order

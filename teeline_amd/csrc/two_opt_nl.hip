@@ -123,9 +123,46 @@ __device__ __forceinline__ void emit_list(const uint32_t *d, uint32_t n, uint32_
 
 // one workgroup per city u: squared distances to every other city as bit patterns (squares are >= +0: their bits order like
 // unsigned ints, NaNs last), the KB-th and KA-th smallest, the two lists
-__global__ __launch_bounds__(kKnnThreads) void k_nl_knn(const float2 *__restrict__ xy, uint32_t n, uint32_t ka, uint32_t kb, uint16_t *__restrict__ rec,
-                                                        uint16_t *__restrict__ knn_b, uint32_t *__restrict__ dkb2, uint32_t *__restrict__ rcnt)
+// The lists are kept in the context's workspace together with the coordinates they were built from.  A later call compares its
+// coordinates with that copy, bit for bit, on the device (k_nl_check: state[0] = 1 where everything is equal) and every kernel
+// of the build returns at once where the lists are still the instance's — a multi-start loop builds them once, not per batch.
+// state[0]: lists valid for this call's xy; state[1]: the n they were built for.
+__global__ __launch_bounds__(256) void k_nl_check(const float2 *__restrict__ xy, uint32_t n, const uint2 *__restrict__ kept, uint32_t *__restrict__ state)
 {
+    // (launched with state[0] preset to 1 by k_nl_begin; any difference clears it)
+    const uint32_t v = blockIdx.x * 256u + threadIdx.x;
+    if (v >= n) return;
+    const float2 p = xy[v];
+    const uint2 q = kept[v];
+    if (__builtin_bit_cast(uint32_t, p.x) != q.x || __builtin_bit_cast(uint32_t, p.y) != q.y) state[0] = 0u;
+}
+__global__ void k_nl_begin(uint32_t n, uint32_t *__restrict__ state)
+{
+    state[0] = state[1] == n ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_nl_clear(uint32_t n, uint32_t *__restrict__ rcnt, uint32_t *__restrict__ rec32, const uint32_t *__restrict__ state)
+{
+    if (state[0]) return;
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g < n) rcnt[g] = 0u;
+    if (g < n * 32u) rec32[g] = 0xFFFFFFFFu;  // (0xFFFF: an empty slot)
+}
+__global__ __launch_bounds__(256) void k_nl_commit(const float2 *__restrict__ xy, uint32_t n, uint2 *__restrict__ kept, uint32_t *__restrict__ state)
+{
+    if (state[0]) return;
+    const uint32_t v = blockIdx.x * 256u + threadIdx.x;
+    if (v < n) {
+        const float2 p = xy[v];
+        kept[v] = make_uint2(__builtin_bit_cast(uint32_t, p.x), __builtin_bit_cast(uint32_t, p.y));
+    }
+    if (v == 0) state[1] = n;  // (state[0] stays 0 until the next call's k_nl_begin: the kernels behind this one still see "rebuilt")
+}
+
+__global__ __launch_bounds__(kKnnThreads) void k_nl_knn(const float2 *__restrict__ xy, uint32_t n, uint32_t ka, uint32_t kb, uint16_t *__restrict__ rec,
+                                                        uint16_t *__restrict__ knn_b, uint32_t *__restrict__ dkb2, uint32_t *__restrict__ rcnt,
+                                                        const uint32_t *__restrict__ state)
+{
+    if (state[0]) return;
     extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
     uint32_t *d = sm;
     uint32_t *hist = sm + ((n + 63u) & ~63u);
@@ -147,8 +184,9 @@ __global__ __launch_bounds__(kKnnThreads) void k_nl_knn(const float2 *__restrict
 }
 
 // "reverse list incomplete" into the records of the cities that more than kNlRB others count among their nearest
-__global__ __launch_bounds__(256) void k_nl_counts(const uint32_t *__restrict__ rcnt, uint32_t n, uint16_t *__restrict__ rec)
+__global__ __launch_bounds__(256) void k_nl_counts(const uint32_t *__restrict__ rcnt, uint32_t n, uint16_t *__restrict__ rec, const uint32_t *__restrict__ state)
 {
+    if (state[0]) return;
     const uint32_t v = blockIdx.x * 256u + threadIdx.x;
     if (v >= n) return;
     rec[(size_t)v * 64u + 2u] = rcnt[v] > (uint32_t)kNlRB ? 1u : 0u;
@@ -160,16 +198,20 @@ constexpr size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 size_t two_opt_nl_ws_bytes(uint32_t n)
 {
-    return al256((size_t)n * 128) + al256((size_t)n * kNlKB * 2) + 2 * al256((size_t)n * 4);
+    return al256((size_t)n * 128) + al256((size_t)n * kNlKB * 2) + 2 * al256((size_t)n * 4) + al256((size_t)n * 8) + 256;
 }
 
-// lays the lists out in `ws` (two_opt_nl_ws_bytes), builds them on `s`, returns the pointers the descent kernel reads
-hipError_t launch_two_opt_nl_build(const float2 *xy, uint32_t n, void *ws, TwoOptNl *out, hipStream_t s)
+// Lays the lists out in `ws` (two_opt_nl_ws_bytes; `fresh`: the buffer has just been (re)allocated and holds nothing), builds them on
+// `s` unless they are already there for these very coordinates, returns the pointers the descent kernel reads.
+hipError_t launch_two_opt_nl_build(const float2 *xy, uint32_t n, void *ws, bool fresh, TwoOptNl *out, hipStream_t s)
 {
     static_assert(kNlRecA0 + kNlKA == kNlRecB0 && kNlRecB0 + kNlRB == kNlSurv0 && kNlSurv0 + kNlSurvSlots == 64, "record layout");
     const uint32_t ka = kNlKA, kb = kNlKB;
     if (n <= kb + 1u || n > 65535u) return hipErrorInvalidValue;
+    // (the state block first: its place does not depend on n)
     unsigned char *p = (unsigned char *)ws;
+    uint32_t *state = (uint32_t *)p;
+    p += 256;
     uint16_t *rec = (uint16_t *)p;
     p += al256((size_t)n * 128);
     uint16_t *knn_b = (uint16_t *)p;
@@ -177,14 +219,20 @@ hipError_t launch_two_opt_nl_build(const float2 *xy, uint32_t n, void *ws, TwoOp
     uint32_t *dkb2 = (uint32_t *)p;
     p += al256((size_t)n * 4);
     uint32_t *rcnt = (uint32_t *)p;
-    hipError_t e = hipMemsetAsync(rcnt, 0, (size_t)n * 4, s);
-    if (e != hipSuccess) return e;
-    if ((e = hipMemsetAsync(rec, 0xFF, (size_t)n * 128, s)) != hipSuccess) return e;  // (0xFFFF: an empty slot)
+    p += al256((size_t)n * 4);
+    uint2 *kept = (uint2 *)p;
+    hipError_t e;
+    if (fresh && (e = hipMemsetAsync(state, 0, 256, s)) != hipSuccess) return e;  // state[1] = 0: no n matches
     const size_t lds = ((size_t)((n + 63u) & ~63u) + kHistBins + 16) * 4;
     e = allow_max_lds(reinterpret_cast<const void *>(k_nl_knn));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_nl_knn, dim3(n), dim3(kKnnThreads), lds, s, xy, n, ka, kb, rec, knn_b, dkb2, rcnt);
-    hipLaunchKernelGGL(k_nl_counts, dim3((n + 255u) / 256u), dim3(256), 0, s, rcnt, n, rec);
+    const dim3 per_city((n + 255u) / 256u);
+    hipLaunchKernelGGL(k_nl_begin, dim3(1), dim3(1), 0, s, n, state);
+    hipLaunchKernelGGL(k_nl_check, per_city, dim3(256), 0, s, xy, n, kept, state);
+    hipLaunchKernelGGL(k_nl_clear, dim3((n * 32u + 255u) / 256u), dim3(256), 0, s, n, rcnt, (uint32_t *)rec, state);
+    hipLaunchKernelGGL(k_nl_knn, dim3(n), dim3(kKnnThreads), lds, s, xy, n, ka, kb, rec, knn_b, dkb2, rcnt, state);
+    hipLaunchKernelGGL(k_nl_counts, per_city, dim3(256), 0, s, rcnt, n, rec, state);
+    hipLaunchKernelGGL(k_nl_commit, per_city, dim3(256), 0, s, xy, n, kept, state);
     out->rec = rec;
     out->dkb2 = dkb2;
     out->knn_b = knn_b;
