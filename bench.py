@@ -682,6 +682,26 @@ def main():
             extras["multistart_two_descents_per_cu"] = {"restarts": R2, "kernel_ms": min(ms2), "candidates_per_s": cands2 / (min(ms2) * 1e-3),
                                                         "vs_one_per_cu": (cands2 / (min(ms2) * 1e-3)) / (cand_per_launch / (k_ms * 1e-3)),
                                                         "note": "tl_two_opt_batch_dev with 2 x the CU count of restarts; first half bit-identical to the timed batch (asserted)"}
+            # The late phase (from the sixth sweep on a row reads per-city neighbour lists instead of walking tiles, the rest of a sweep is
+            # one step: teeline_amd/csrc/two_opt_nl.hip) against the same kernel without it, same batch, same tours.
+            with TA.Context(local, TA.TL_FLAG_2OPT_NO_NL) as cn:
+                ms3 = []
+                for _ in range(2):
+                    with torch.cuda.stream(stream):
+                        cn.check(lib.tl_two_opt_batch_dev(cn.handle, d_xy.data_ptr(), n, None, a.seed, first, R, _capi.TL_MODE_REF_ORDER,
+                                                          d_pos2.data_ptr(), d_cost2.data_ptr(), d_stats2.data_ptr(), C.c_void_p(stream.cuda_stream)))
+                    torch.cuda.synchronize()
+                    ms3.append(cn.last_kernel_ms())
+                assert torch.equal(d_pos2[:R], d_pos) and torch.equal(d_cost2[:R], d_cost), "the tile-only kernel gave other tours"
+            late_clk = (d_stats[:, 13] >> 24).double()
+            extras["late_phase_neighbour_lists"] = {
+                "kernel_ms_without": min(ms3), "kernel_ms_with": k_ms, "speedup": min(ms3) / k_ms,
+                "late_phase_share_of_descent_cycles": {"mean": float((late_clk / d_stats[:, 9].double()).mean().item()),
+                                                       "max": float((late_clk / d_stats[:, 9].double()).max().item())},
+                "late_steps_per_descent_mean": float((d_stats[:, 14] >> 32).double().mean().item()),
+                "note": "TL_FLAG_2OPT_NO_NL: every pruned row walks its tiles in every sweep (the round-3 kernel); default: sweeps >= 6 of a descent "
+                        "decide a row from one 128-byte record pair (16 nearest of a, reverse 24-nearest of b) + the few cities with a long tour edge; "
+                        "lists built once per instance (k_nl_knn, inside kernel_ms of the first call), validated on the device per call; same tours (asserted)"}
             prob = TA.TspProblem(np.arange(n), xy)
             init = TA.synth.restart_perm(n, a.seed, 0)
             sol = TA.two_opt.solve(prob, None, None, [int(v) for v in init], ctx=ctx)
