@@ -5,6 +5,9 @@
 using namespace tl;
 using namespace tlapi;
 
+#ifndef TL_NL_MIN_N
+#define TL_NL_MIN_N 1500u  // smallest instance whose descents build and read the neighbour lists
+#endif
 #ifndef TL_NL_SWEEP_MIN
 #define TL_NL_SWEEP_MIN 6  // first sweep of a descent whose pruned blocks read the neighbour lists (tuning builds override it)
 #endif
@@ -81,7 +84,7 @@ static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uin
         // Neighbour lists of the instance for the late sweeps (two_opt_nl.hip): built once per call, read by every descent of the
         // batch — where the 16-wave float2 form runs, the lists' state fits the LDS beside the tour, and the instance is large
         // enough for the lists (~0.3 ms at n = 10^4) to pay.
-        if (!A.fx_xy && !(c->flags & (TL_FLAG_NO_PRUNE | TL_FLAG_2OPT_NO_NL)) && (n >= 3000u || (c->flags & TL_FLAG_2OPT_NL_ALWAYS)) &&
+        if (!A.fx_xy && !(c->flags & (TL_FLAG_NO_PRUNE | TL_FLAG_2OPT_NO_NL)) && (n >= TL_NL_MIN_N || (c->flags & TL_FLAG_2OPT_NL_ALWAYS)) &&
             two_opt_ref_nl_applies(n, count, c->cus, c->lds_bytes, force_nt)) {
             int rc4;
             const void *had = c->nl.p;

@@ -453,7 +453,11 @@ __device__ __forceinline__ void late_phase(const TwoOptBatchArgs &A, const PT &P
                                            uint32_t &step, uint32_t &status, uint32_t &n_late_steps, TC &tc, int lane, int wave, int tid)
 {
     constexpr int NW = NT / 64;
-    constexpr int kLateRowsPerWave = 64 / NW;  // a chunk of 64 rows over the NW waves
+#ifndef TL_LATE_ROWS
+#define TL_LATE_ROWS 8
+#endif
+    constexpr int kLateRowsPerWave = TL_LATE_ROWS;  // rows a wave takes at a time (a divisor of the 64-row chunk)
+    static_assert(64 % kLateRowsPerWave == 0, "a take lies inside one chunk");
     const uint16_t *__restrict__ rec = A.nl.rec;
     const uint32_t *__restrict__ dkb2 = A.nl.dkb2;
     const bool control = wave == 0;  // wave 0 scans like the others and keeps the accounting beside it
