@@ -252,7 +252,7 @@ __device__ __forceinline__ void flush_pending(Cursor &c, Acct &a, const PT &P, u
 // it asked for another block shape).
 template <bool CONTROL, int NT, int SLOTS, typename PT>
 __device__ __forceinline__ bool step_boundary(Cursor &c, Acct &a, const PT &P, uint16_t *perm, Ctl *ctl, const uint32_t *queues, uint32_t n, uint32_t nrows,
-                                              uint32_t R, int lane, int wave, int tid, uint32_t my_hits, float &bx, float &by, bool &reload)
+                                              uint32_t R, int lane, int wave, int tid, uint32_t my_hits, float &bx, float &by, bool &reload, float *tmsq)
 {
     const uint2 kr = ctl->kr[c.slot];
     const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)kr.x);
@@ -307,6 +307,15 @@ __device__ __forceinline__ bool step_boundary(Cursor &c, Acct &a, const PT &P, u
     } else {
         // pruned mode: one hit, applied at once by every wave (moves are rare here)
         const uint32_t is = key >> 16, js = key & 0xFFFFu;
+        const uint32_t t0 = is >> 6, t1 = js >> 6;
+        // A reversal inside ONE tile (most moves of the sweeps this shape runs in are a dozen positions long) leaves the tile's point
+        // set, hence its box, as it is, and of its tour edges only (i, i+1) and (j, j+1) change: the larger of the two new squares
+        // is folded into the tile's msq (an upper bound is all L0 needs) and no tile is marked stale — no rebuild, no barrier in
+        // front of the next scan.  (Thread 0 alone writes positions i+1 and j, later in its own program order.)
+        if (t0 == t1 && tid == 0) {
+            const float m = fmaxf(sqdist(pt_get(P, is), pt_get(P, js)), sqdist(pt_get(P, is + 1u), pt_get(P, js + 1u)));  // (fmaxf drops a NaN, as build_tile_meta does)
+            if (m > tmsq[t0]) tmsq[t0] = m;
+        }
         reverse_segment<NT>(P, perm, is + 1u, js, tid);  // two_opt.rs:50,69-79  swap_2opt(path, i+1, j)
         TL_SYNC();
         if (CONTROL) {
@@ -326,9 +335,10 @@ __device__ __forceinline__ bool step_boundary(Cursor &c, Acct &a, const PT &P, u
             a.since = 0.0f;
             a.improved = true;
         }
-        const uint32_t t0 = is >> 6, t1 = js >> 6;  // L0 metadata of every tile that saw a changed position or tour-edge
-        c.dirty_lo = t0 < c.dirty_lo ? t0 : c.dirty_lo;
-        c.dirty_hi = t1 > c.dirty_hi ? t1 : c.dirty_hi;
+        if (t0 != t1) {  // L0 metadata of every tile that saw a changed position or tour-edge
+            c.dirty_lo = t0 < c.dirty_lo ? t0 : c.dirty_lo;
+            c.dirty_hi = t1 > c.dirty_hi ? t1 : c.dirty_hi;
+        }
         c.i0 = is;
         c.j0 = js + 1u;
         if (c.j0 > n - 2u) {
@@ -686,6 +696,11 @@ __device__ __forceinline__ void late_phase(const TwoOptBatchArgs &A, const PT &P
             j0 = i0 + 2u;
         } else {
             const uint32_t is = key >> 16, js = key & 0xFFFFu;
+            const uint32_t t0 = is >> 6, t1 = js >> 6;
+            if (t0 == t1 && tid == 0) {  // a reversal inside one tile: its box stands, its msq takes the new edges (step_boundary)
+                const float m = fmaxf(sqdist(pt_get(P, is), pt_get(P, js)), sqdist(pt_get(P, is + 1u), pt_get(P, js + 1u)));
+                if (m > tmsq[t0]) tmsq[t0] = m;
+            }
             reverse_segment<NT>(P, perm, is + 1u, js, tid, L.pos);  // two_opt.rs:50,69-79  swap_2opt(path, i+1, j)
             TL_SYNC();
             if (control) {
@@ -697,9 +712,10 @@ __device__ __forceinline__ void late_phase(const TwoOptBatchArgs &A, const PT &P
                 acct.reversed += (uint64_t)(js - is);
             }
             improved = true;
-            const uint32_t t0 = is >> 6, t1 = js >> 6;  // L0 metadata of every tile that saw a changed position or tour-edge
-            dirty_lo = t0 < dirty_lo ? t0 : dirty_lo;
-            dirty_hi = t1 > dirty_hi ? t1 : dirty_hi;
+            if (t0 != t1) {  // L0 metadata of every tile that saw a changed position or tour-edge
+                dirty_lo = t0 < dirty_lo ? t0 : dirty_lo;
+                dirty_hi = t1 > dirty_hi ? t1 : dirty_hi;
+            }
             fix = true;  // the move's two new edges are entered in the long list in front of the next scan
             fi = is;
             fj = js;
@@ -996,7 +1012,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #endif
             float bx_ = 0.f, by_ = 0.f;
             bool reload_ = false;
-            need_desc = step_boundary<true, NT, kSlots>(c, acct, P, perm, ctl, queues, n, nrows, R, lane, wave, tid, 0u, bx_, by_, reload_);
+            need_desc = step_boundary<true, NT, kSlots>(c, acct, P, perm, ctl, queues, n, nrows, R, lane, wave, tid, 0u, bx_, by_, reload_, tmsq);
             // the block shape the gap estimate asks for; a change is requested for the next boundary
             if (PRUNE && c.i0 < nrows) {
                 const bool want = fmaxf(acct.gap_est, acct.since) > TL_DENSE_ROWS * (float)(n - 2u - c.i0);
@@ -1210,7 +1226,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 t3 = __builtin_amdgcn_s_memtime();  // a pruned step's cycles belong to no dense step
             }
 #endif
-            need_desc = step_boundary<false, NT, kSlots>(c, acct, P, perm, ctl, queues, n, nrows, R, lane, wave, tid, my_hits, bx, by, reload);
+            need_desc = step_boundary<false, NT, kSlots>(c, acct, P, perm, ctl, queues, n, nrows, R, lane, wave, tid, my_hits, bx, by, reload, tmsq);
         }
         if constexpr (NL) {
             if (go_late) late_phase<NT>(A, P, perm, tbox, tmsq, ctl, L, d, n, nrows, ntile, G, c.dirty_lo, c.dirty_hi, acct, sweeps, step, status, n_late_steps, tc, lane, wave, tid);
