@@ -1102,6 +1102,9 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #endif
         Cursor c{0u, 2u, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, false};
         Acct acct{0ull, 0ull, 0ull, 0.0f, 0.0f, false, nullptr, 0u, 0u};  // unused by a worker
+#ifdef TL_PROFILE4
+        uint64_t qp[5] = {0, 0, 0, 0, 0};  // pruned steps of this wave: cycles in the scan, rows, tile passes, steps, wait at B2
+#endif
         bool need_desc = true, reload = true;
         float ax = 0.f, ay = 0.f, bx = 0.f, by = 0.f;
         for (;;) {
@@ -1163,6 +1166,9 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                     TL_SYNC();
                 }
                 // lane-resident row table: lane l holds P[i0+l] and sq(P[i0+l], P[i0+l+1])
+#ifdef TL_PROFILE4
+                const uint64_t tp0 = __builtin_amdgcn_s_memtime();
+#endif
                 const uint32_t i0 = c.i0, j0 = c.j0;
                 const float2 rp = pt_get(P, i0 + (uint32_t)lane);
                 const float2 rq = pt_get(P, i0 + (uint32_t)lane + 1u);
@@ -1178,6 +1184,9 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 }
                 for (int r = wk; r < (int)R; r += NWK) {
                     const uint32_t i = i0 + (uint32_t)r;
+#ifdef TL_PROFILE4
+                    qp[1] += 1;
+#endif
                     if (r >= NWK) {  // a hit in an earlier row makes this one moot
                         const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot);
                         if (kb != kNoKey && (kb >> 16) < i) break;
@@ -1202,6 +1211,14 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                                 t = ((uint32_t)gI << 6) + (uint32_t)(__builtin_ffsll((long long)m) - 1);
                                 m &= m - 1;
                                 tc.ptile += 1u;
+#ifdef TL_PROFILE4
+                                qp[2] += 1;
+#endif
+                                {   // a hit posted in an earlier row makes the rest of this row moot: the step ends when its slowest wave
+                                    // arrives, and a row of the early sweeps has up to a dozen live tiles (round 4: 101.5 -> 96.5 ms)
+                                    const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot);
+                                    if (kb != kNoKey && (kb >> 16) < i) goto rows_done;
+                                }
                                 hm = tile_improving_mask<PRUNE>(P, n, t << 6, jmin, rax, ray, rbx, rby, rsqab, lane, tc);
                                 if (hm) goto row_hit;
                             }
@@ -1213,8 +1230,19 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                     if (lane == 0) lds_min_u32_fenced(keyslot, (i << 16) | ((t << 6) + (uint32_t)(__builtin_ffsll((long long)hm) - 1)));
                     break;  // rows w+NWK, ... are later rows
                 }
+            rows_done:;
+#ifdef TL_PROFILE4
+                qp[0] += __builtin_amdgcn_s_memtime() - tp0;
+                qp[3] += 1;
+#endif
             }
+#ifdef TL_PROFILE4
+            const uint64_t tpb = __builtin_amdgcn_s_memtime();
+#endif
             TL_SYNC();  // B2
+#ifdef TL_PROFILE4
+            if (c.pruned) qp[4] += __builtin_amdgcn_s_memtime() - tpb;
+#endif
             TL_STAMP3(4);
 #ifdef TL_PROFILE3
             if (!c.pruned) {
@@ -1228,6 +1256,11 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #endif
             need_desc = step_boundary<false, NT, kSlots>(c, acct, P, perm, ctl, queues, n, nrows, R, lane, wave, tid, my_hits, bx, by, reload, tmsq);
         }
+#ifdef TL_PROFILE4
+        if (d == 0 && lane == 0 && (wave == 1 || wave == 8))
+            printf("wave %d, pruned steps of the main loop: %lu; scan %lu cycles per step, %lu rows and %lu tile passes per step, B2 wait %lu\n", wave, qp[3], qp[0] / (qp[3] ? qp[3] : 1),
+                   qp[1] * 100 / (qp[3] ? qp[3] : 1), qp[2] * 100 / (qp[3] ? qp[3] : 1), qp[4] / (qp[3] ? qp[3] : 1));
+#endif
         if constexpr (NL) {
             if (go_late) late_phase<NT>(A, P, perm, tbox, tmsq, ctl, L, d, n, nrows, ntile, G, c.dirty_lo, c.dirty_hi, acct, sweeps, step, status, n_late_steps, tc, lane, wave, tid);
         }
