@@ -250,7 +250,7 @@ __device__ __forceinline__ void flush_pending(Cursor &c, Acct &a, const PT &P, u
 // its accounting).  R: rows of the block just scanned.  my_hits: the hit columns this wave chained in the step (lane h = h-th
 // hit), filed in ctl->pend if they are the step's.  Returns true where the control wave's descriptor comes next (sweep ended, or
 // it asked for another block shape).
-template <bool CONTROL, int NT, int SLOTS, typename PT>
+template <bool CONTROL, int NT, int SLOTS, bool FOLD, typename PT>
 __device__ __forceinline__ bool step_boundary(Cursor &c, Acct &a, const PT &P, uint16_t *perm, Ctl *ctl, const uint32_t *queues, uint32_t n, uint32_t nrows,
                                               uint32_t R, int lane, int wave, int tid, uint32_t my_hits, float &bx, float &by, bool &reload, float *tmsq)
 {
@@ -312,7 +312,10 @@ __device__ __forceinline__ bool step_boundary(Cursor &c, Acct &a, const PT &P, u
         // set, hence its box, as it is, and of its tour edges only (i, i+1) and (j, j+1) change: the larger of the two new squares
         // is folded into the tile's msq (an upper bound is all L0 needs) and no tile is marked stale — no rebuild, no barrier in
         // front of the next scan.  (Thread 0 alone writes positions i+1 and j, later in its own program order.)
-        if (t0 == t1 && tid == 0) {
+        // (FOLD: only where the late phase takes the hit-free sweeps — a folded msq is never lowered again, and in a loop that also runs
+        //  those sweeps the weaker bound costs more than the rebuilds: two descents per CU 174 -> 194 ms)
+        const bool fold = FOLD && t0 == t1;
+        if (fold && tid == 0) {
             const float m = fmaxf(sqdist(pt_get(P, is), pt_get(P, js)), sqdist(pt_get(P, is + 1u), pt_get(P, js + 1u)));  // (fmaxf drops a NaN, as build_tile_meta does)
             if (m > tmsq[t0]) tmsq[t0] = m;
         }
@@ -335,7 +338,7 @@ __device__ __forceinline__ bool step_boundary(Cursor &c, Acct &a, const PT &P, u
             a.since = 0.0f;
             a.improved = true;
         }
-        if (t0 != t1) {  // L0 metadata of every tile that saw a changed position or tour-edge
+        if (!fold) {  // L0 metadata of every tile that saw a changed position or tour-edge
             c.dirty_lo = t0 < c.dirty_lo ? t0 : c.dirty_lo;
             c.dirty_hi = t1 > c.dirty_hi ? t1 : c.dirty_hi;
         }
@@ -1012,7 +1015,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #endif
             float bx_ = 0.f, by_ = 0.f;
             bool reload_ = false;
-            need_desc = step_boundary<true, NT, kSlots>(c, acct, P, perm, ctl, queues, n, nrows, R, lane, wave, tid, 0u, bx_, by_, reload_, tmsq);
+            need_desc = step_boundary<true, NT, kSlots, NL>(c, acct, P, perm, ctl, queues, n, nrows, R, lane, wave, tid, 0u, bx_, by_, reload_, tmsq);
             // the block shape the gap estimate asks for; a change is requested for the next boundary
             if (PRUNE && c.i0 < nrows) {
                 const bool want = fmaxf(acct.gap_est, acct.since) > TL_DENSE_ROWS * (float)(n - 2u - c.i0);
@@ -1214,8 +1217,11 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #ifdef TL_PROFILE4
                                 qp[2] += 1;
 #endif
-                                {   // a hit posted in an earlier row makes the rest of this row moot: the step ends when its slowest wave
-                                    // arrives, and a row of the early sweeps has up to a dozen live tiles (round 4: 101.5 -> 96.5 ms)
+                                if constexpr (NL) {
+                                    // a hit posted in an earlier row makes the rest of this row moot: the step ends when its slowest wave
+                                    // arrives, and a row of the early sweeps has up to a dozen live tiles (round 4: 101.5 -> 96.5 ms).
+                                    // Only where the late phase takes the hit-free sweeps: in a loop that also runs those, the extra LDS
+                                    // read per tile costs more than it saves (two descents per CU: 174 -> 201 ms; round 2 measured the same).
                                     const uint32_t kb = (uint32_t)__builtin_amdgcn_readfirstlane((int)*keyslot);
                                     if (kb != kNoKey && (kb >> 16) < i) goto rows_done;
                                 }
@@ -1254,7 +1260,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 t3 = __builtin_amdgcn_s_memtime();  // a pruned step's cycles belong to no dense step
             }
 #endif
-            need_desc = step_boundary<false, NT, kSlots>(c, acct, P, perm, ctl, queues, n, nrows, R, lane, wave, tid, my_hits, bx, by, reload, tmsq);
+            need_desc = step_boundary<false, NT, kSlots, NL>(c, acct, P, perm, ctl, queues, n, nrows, R, lane, wave, tid, my_hits, bx, by, reload, tmsq);
         }
 #ifdef TL_PROFILE4
         if (d == 0 && lane == 0 && (wave == 1 || wave == 8))
