@@ -164,3 +164,28 @@ def test_default_late_phase_equals_the_tile_only_kernel_on_a_batch(ctx):
     (pa, ca, sa), (pb, cb, sb) = res
     assert (pa == pb).all() and (ca == cb).all() and (sa[:, :4] == sb[:, :4]).all()
     assert (sa[:, 14] >> 32).min() > 0 and (sb[:, 14] >> 32).max() == 0  # the default really went through the late phase
+
+
+def test_largest_instance_with_a_late_phase_and_the_first_without(ctx):
+    # the late phase needs 2 more bytes per city (+ 4 KB) beside the tour: n = 12 416 is the last size it fits one CU's LDS at;
+    # one city more runs the tile-only kernel.  NN start (a few thousand moves), against the oracle.
+    import torch
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.current_stream()
+    for n, late in ((12416, True), (12417, False)):
+        xy = O.synth_xy(n, seed=3)
+        rc, nn, _ = O.nearest_neighbor(xy, None, n, 3)
+        d_xy = torch.from_numpy(xy).to(dev)
+        d_init = torch.from_numpy(nn.astype(np.int32)).to(dev)
+        d_pos = torch.empty((1, n), dtype=torch.int32, device=dev)
+        d_cost = torch.empty(1, dtype=torch.float32, device=dev)
+        d_st = torch.zeros((1, 16), dtype=torch.int64, device=dev)
+        ctx.check(ctx.lib.tl_two_opt_batch_dev(ctx.handle, d_xy.data_ptr(), n, C.c_void_p(d_init.data_ptr()), 0, 0, 1, 0, d_pos.data_ptr(), d_cost.data_ptr(), d_st.data_ptr(),
+                                               C.c_void_p(s.cuda_stream)))
+        torch.cuda.synchronize()
+        st = d_st.cpu().numpy()[0]
+        rc, route, cost, ost = O.two_opt(xy, None, n, init=nn)
+        assert d_pos.cpu().numpy()[0].astype(np.uint32).tolist() == route.tolist()
+        assert d_cost.cpu().numpy().view(np.uint32)[0] == np.float32(cost).view(np.uint32)
+        assert (int(st[0]), int(st[1]), int(st[2])) == (ost["sweeps"], ost["moves"], ost["reversed"])
+        assert ((int(st[14]) >> 32) > 0) == late
