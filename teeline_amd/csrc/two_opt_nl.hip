@@ -49,7 +49,9 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
 
 // K-th smallest (1-based) of d[0..n) by a three-digit radix select (11 + 11 + 10 bits).  Returns the value; *quota = how many
 // elements EQUAL to it belong to the K smallest (the others among them are strictly smaller).
-__device__ __forceinline__ uint32_t radix_select(const uint32_t *d, uint32_t n, uint32_t K, uint32_t *hist, uint32_t *misc, int tid, uint32_t *quota)
+// `cap`: elements above it are known not to be among the K smallest and stay out of the histograms (0xFFFFFFFF: none known).
+__device__ __forceinline__ uint32_t radix_select(const uint32_t *d, uint32_t n, uint32_t K, uint32_t *hist, uint32_t *misc, int tid, uint32_t *quota,
+                                                 uint32_t cap = 0xFFFFFFFFu)
 {
     uint32_t prefix = 0, pmask = 0, need = K;
     const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
@@ -60,7 +62,7 @@ __device__ __forceinline__ uint32_t radix_select(const uint32_t *d, uint32_t n, 
         __syncthreads();
         for (uint32_t v = (uint32_t)tid; v < n; v += kKnnThreads) {
             const uint32_t x = d[v];
-            if ((x & pmask) == prefix) atomicAdd(&hist[(x >> sh) & (nb - 1u)], 1u);
+            if (x <= cap && (x & pmask) == prefix) atomicAdd(&hist[(x >> sh) & (nb - 1u)], 1u);
         }
         __syncthreads();
         // thread t owns bins [8t, 8t+8): exclusive scan of the owners' sums, then the owner of the K-th walks its bins
@@ -96,8 +98,8 @@ __device__ __forceinline__ uint32_t radix_select(const uint32_t *d, uint32_t n, 
 __device__ __forceinline__ void emit_list(const uint32_t *d, uint32_t n, uint32_t T, uint32_t quota, uint16_t *out, uint32_t *rcnt, uint16_t *rec, uint32_t u,
                                           uint32_t *misc, int tid)
 {
-    const uint32_t chunk = (n + kKnnThreads - 1) / kKnnThreads;
-    const uint32_t v0 = (uint32_t)tid * chunk, v1 = v0 + chunk < n ? v0 + chunk : n;
+    const uint32_t chunk = ((n + kKnnThreads - 1) / kKnnThreads) | 1u;  // (odd: a thread's run of elements starts in its own LDS bank)
+    const uint32_t v0 = (uint32_t)tid * chunk < n ? (uint32_t)tid * chunk : n, v1 = v0 + chunk < n ? v0 + chunk : n;
     uint32_t less = 0, tie = 0;
     for (uint32_t v = v0; v < v1; ++v) {
         const uint32_t x = d[v];
@@ -170,12 +172,23 @@ __global__ __launch_bounds__(kKnnThreads) void k_nl_knn(const float2 *__restrict
     const int tid = threadIdx.x;
     const uint32_t u = blockIdx.x;
     const float2 pu = xy[u];
-    for (uint32_t v = (uint32_t)tid; v < n; v += kKnnThreads) d[v] = v == u ? 0xFFFFFFFFu : __builtin_bit_cast(uint32_t, sqdist(pu, xy[v]));
+    uint32_t mine = 0xFFFFFFFFu;
+    for (uint32_t v = (uint32_t)tid; v < n; v += kKnnThreads) {
+        const uint32_t x = v == u ? 0xFFFFFFFFu : __builtin_bit_cast(uint32_t, sqdist(pu, xy[v]));
+        d[v] = x;
+        mine = x < mine ? x : mine;
+    }
+    // An upper bound of the KB-th smallest distance, so that the selects below histogram a few dozen elements instead of n (10^4
+    // LDS atomics on a handful of exponent bins were most of this kernel): each thread's smallest element is one of n's, so the
+    // KB-th smallest of the 256 thread minima has at least KB elements at or below it.
+    uint32_t *mins = misc + 16;
+    mins[tid] = mine;
     __syncthreads();
     uint32_t qb, qa;
-    const uint32_t tb = radix_select(d, n, kb, hist, misc, tid, &qb);
+    const uint32_t cap = kb <= (uint32_t)kKnnThreads ? radix_select(mins, kKnnThreads, kb, hist, misc, tid, &qb) : 0xFFFFFFFFu;
+    const uint32_t tb = radix_select(d, n, kb, hist, misc, tid, &qb, cap);
     emit_list(d, n, tb, qb, knn_b + (size_t)u * kb, rcnt, rec, u, misc, tid);
-    const uint32_t ta = radix_select(d, n, ka, hist, misc, tid, &qa);
+    const uint32_t ta = radix_select(d, n, ka, hist, misc, tid, &qa, cap);
     emit_list(d, n, ta, qa, rec + (size_t)u * 64u + (uint32_t)kNlRecA0, nullptr, nullptr, u, misc, tid);
     if (tid == 0) {
         dkb2[u] = tb;
@@ -223,7 +236,7 @@ hipError_t launch_two_opt_nl_build(const float2 *xy, uint32_t n, void *ws, bool 
     uint2 *kept = (uint2 *)p;
     hipError_t e;
     if (fresh && (e = hipMemsetAsync(state, 0, 256, s)) != hipSuccess) return e;  // state[1] = 0: no n matches
-    const size_t lds = ((size_t)((n + 63u) & ~63u) + kHistBins + 16) * 4;
+    const size_t lds = ((size_t)((n + 63u) & ~63u) + kHistBins + 16 + kKnnThreads) * 4;
     e = allow_max_lds(reinterpret_cast<const void *>(k_nl_knn));
     if (e != hipSuccess) return e;
     const dim3 per_city((n + 255u) / 256u);
