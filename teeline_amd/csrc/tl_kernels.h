@@ -57,7 +57,8 @@ struct TwoOptNl {
     const uint32_t *dkb2;    // [n] bits of the KB-th smallest squared distance
     const uint16_t *knn_b;   // [n][kNlKB] the KB nearest cities of each city (the forward form of the reverse lists; diagnostics)
     const uint32_t *rcnt;    // [n] reverse counts (diagnostics)
-    uint32_t sweep_min;      // first sweep of a descent that may run in the late phase (neighbour-list rows)
+    uint32_t sweep_min;      // first sweep of a descent that may run in the late phase (neighbour-list rows) ...
+    uint32_t moves_max;      // ... once a sweep has applied fewer moves than this (in the late phase every move is a whole step)
 };
 size_t two_opt_nl_ws_bytes(uint32_t n);
 hipError_t launch_two_opt_nl_build(const float2 *xy, uint32_t n, void *ws, bool fresh, TwoOptNl *out, hipStream_t s);

@@ -904,6 +904,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         Acct acct{0ull, 0ull, 0ull, 0.0f, 0.0f, false, A.move_log ? A.move_log + (size_t)d * A.log_cap : nullptr, A.log_cap, 0u};
         bool need_desc = true;
         uint32_t n_desc = 0, n_pruned_steps = 0;  // diagnostics (stats words 13, 14)
+        uint64_t sweep_moves0 = 0;                // acct.moves when the current sweep began
 #ifdef TL_PROFILE2
         uint64_t q2[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         uint64_t t_it = __builtin_amdgcn_s_memtime();
@@ -928,8 +929,8 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                     } else if (sweeps >= A.max_sweeps) {
                         status = 1;
                         done = true;
-                    } else if (NL && sweeps + 1u >= A.nl.sweep_min) {
-                        go_late = true;
+                    } else if (NL && sweeps + 1u >= A.nl.sweep_min && acct.moves - sweep_moves0 < (uint64_t)A.nl.moves_max) {
+                        go_late = true;  // (few moves per sweep from here on: the late phase's cheaper rows pay for its dearer moves)
                     } else {
 #ifdef TL_PROFILE4
                         if (d == 0 && lane == 0)
@@ -942,6 +943,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 #endif
                         acct.improved = false;
                         ++sweeps;
+                        sweep_moves0 = acct.moves;
                         c.i0 = 0;
                         c.j0 = 2;
                         if (acct.log) {  // a new sweep begins here (the same row can hold moves of two consecutive sweeps back to back)
