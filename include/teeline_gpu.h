@@ -167,8 +167,9 @@ int tl_selftest_sqrt(tl_ctx *ctx, uint32_t first_bits, uint64_t count, uint64_t 
  * rec [n][64] u16 — per city: [0] high half of the bits of its KA-th smallest squared distance, [2] 1 if its reverse list is
  * incomplete, [4, 4+KA) its KA nearest cities, [20, 20+RB) the cities that count it among their KB nearest (0xFFFF: empty);
  * dkb2 [n] — bits of the KB-th smallest squared distance; knn_b [n][KB] — the KB nearest cities; rcnt [n] — reverse counts.
- * KA, KB, RB come back in *ka, *kb, *rb.  TL_ERR_UNSUPPORTED where the lists do not apply (n <= KB + 1). */
-int tl_two_opt_neighbour_lists(tl_ctx *ctx, const float *xy, uint32_t n, uint16_t *rec, uint32_t *dkb2, uint16_t *knn_b, uint32_t *rcnt,
+ * KA, KB, RB come back in *ka, *kb, *rb.  form 0: the kernel the library runs (a wave per city); 1: its cross-check (a workgroup per
+ * city, radix select) — the same lists.  TL_ERR_UNSUPPORTED where the lists do not apply (n <= KB + 1). */
+int tl_two_opt_neighbour_lists(tl_ctx *ctx, const float *xy, uint32_t n, int form, uint16_t *rec, uint32_t *dkb2, uint16_t *knn_b, uint32_t *rcnt,
                                uint32_t *ka, uint32_t *kb, uint32_t *rb);
 
 /* ---- distance matrix: replaces DistanceMatrix::build (distance_matrix.rs:122-153) ----------- */

@@ -121,7 +121,7 @@ def load():
     L.tl_build_candidates.argtypes = [vp, vp, u32, u32, vp]
     L.tl_nearest_neighbor.argtypes = [vp, vp, vp, u32, u32, vp, f32p]
     L.tl_selftest_sqrt.argtypes = [vp, u32, u64, C.POINTER(u64), C.POINTER(u32)]
-    L.tl_two_opt_neighbour_lists.argtypes = [vp, vp, u32, vp, vp, vp, vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.tl_two_opt_neighbour_lists.argtypes = [vp, vp, u32, i32, vp, vp, vp, vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.tl_or_opt.argtypes = [vp, vp, u32, vp, vp, vp, f32p, C.POINTER(TlStats)]
     L.tl_or_opt_find_best_move.argtypes = [vp, vp, u32, vp, vp, C.POINTER(i32), f32p, C.POINTER(u32), C.POINTER(u32),
                                            C.POINTER(u32), C.POINTER(i32)]

@@ -105,8 +105,8 @@ static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uin
     return TL_OK;
 }
 
-extern "C" int tl_two_opt_neighbour_lists(tl_ctx *c, const float *xy, uint32_t n, uint16_t *rec, uint32_t *dkb2, uint16_t *knn_b, uint32_t *rcnt, uint32_t *ka,
-                                          uint32_t *kb, uint32_t *rb)
+extern "C" int tl_two_opt_neighbour_lists(tl_ctx *c, const float *xy, uint32_t n, int form, uint16_t *rec, uint32_t *dkb2, uint16_t *knn_b, uint32_t *rcnt,
+                                          uint32_t *ka, uint32_t *kb, uint32_t *rb)
 {
     TL_ENTER(c);
     if (!c || !xy || !rec || !dkb2 || !knn_b || !rcnt) return fail(c, TL_ERR_BADARG, "tl_two_opt_neighbour_lists: NULL argument");
@@ -117,7 +117,7 @@ extern "C" int tl_two_opt_neighbour_lists(tl_ctx *c, const float *xy, uint32_t n
     HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     TwoOptNl L{};
     HIPCHK(c, hipMemsetAsync(c->nl.p, 0, 256, c->stream));  // (always a fresh build here)
-    HIPCHK(c, launch_two_opt_nl_build((const float2 *)c->xy.p, n, c->nl.p, true, &L, c->stream));
+    HIPCHK(c, launch_two_opt_nl_build((const float2 *)c->xy.p, n, c->nl.p, true, &L, c->stream, form == 1 ? 1 : 0));
     HIPCHK(c, hipMemcpyAsync(rec, L.rec, (size_t)n * 128, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(dkb2, L.dkb2, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(knn_b, L.knn_b, (size_t)n * kNlKB * 2, hipMemcpyDeviceToHost, c->stream));

@@ -61,7 +61,7 @@ struct TwoOptNl {
     uint32_t moves_max;      // ... once a sweep has applied fewer moves than this (in the late phase every move is a whole step)
 };
 size_t two_opt_nl_ws_bytes(uint32_t n);
-hipError_t launch_two_opt_nl_build(const float2 *xy, uint32_t n, void *ws, bool fresh, TwoOptNl *out, hipStream_t s);
+hipError_t launch_two_opt_nl_build(const float2 *xy, uint32_t n, void *ws, bool fresh, TwoOptNl *out, hipStream_t s, int form = 0);  // form 1: the workgroup-per-city kernel (cross-check)
 
 struct TwoOptBatchArgs {
     const float2 *xy;        // n cities, city order

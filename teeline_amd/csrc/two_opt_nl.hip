@@ -205,6 +205,156 @@ __global__ __launch_bounds__(256) void k_nl_counts(const uint32_t *__restrict__ 
     rec[(size_t)v * 64u + 2u] = rcnt[v] > (uint32_t)kNlRB ? 1u : 0u;
 }
 
+
+// ---- the same lists, one WAVE per city (the form that runs; k_nl_knn above is its cross-check, tl_two_opt_neighbour_lists(form = 1)).
+// No block barrier, no distance array: (1) every lane keeps the smallest distance it meets; the KB-th smallest of the 64 lane minima
+// is an upper bound `cap` of the KB-th smallest of all (each lane's minimum is one of the n - 1 distances); (2) the elements at or
+// below cap — a few dozen — are collected in index order; (3) their ranks by (distance, index) give both lists and both K-th
+// distances.  Where more than kNlBuf elements lie at or below cap (masses of equal distances) the K-th distances come from a
+// bisection on the bit pattern instead (32 counting passes each), and the lists from one more pass each.
+constexpr uint32_t kNlBuf = 256;
+
+__device__ __forceinline__ uint32_t nl_dist_bits(const float2 pu, const float2 *__restrict__ xy, uint32_t u, uint32_t v, uint32_t n)
+{
+    return (v < n && v != u) ? __builtin_bit_cast(uint32_t, sqdist(pu, xy[v < n ? v : 0u])) : 0xFFFFFFFFu;
+}
+
+// K-th smallest distance of city u by bisection on the bits: the smallest T with #{x <= T} >= K; *quota = K - #{x < T}
+__device__ uint32_t nl_bisect(const float2 pu, const float2 *__restrict__ xy, uint32_t u, uint32_t n, uint32_t K, int lane, uint32_t *quota)
+{
+    uint32_t lo = 0u, hi = 0xFFFFFFFEu;  // invariant: count(x <= hi) >= K (n - 1 >= K real elements), count(x <= lo - 1) < K
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        uint32_t c = 0;
+        for (uint32_t base = 0; base < n; base += 64u)
+            c += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(nl_dist_bits(pu, xy, u, base + (uint32_t)lane, n) <= mid));
+        if (c >= K) hi = mid;
+        else lo = mid + 1u;
+    }
+    uint32_t less = 0;
+    for (uint32_t base = 0; base < n; base += 64u)
+        less += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(nl_dist_bits(pu, xy, u, base + (uint32_t)lane, n) < lo));
+    *quota = K - less;
+    return lo;
+}
+
+// the list "x < T, or x == T among the first `quota` such in index order", written in index order (one pass over the cities)
+__device__ void nl_emit_pass(const float2 pu, const float2 *__restrict__ xy, uint32_t u, uint32_t n, uint32_t T, uint32_t quota, uint16_t *__restrict__ out,
+                             uint32_t *__restrict__ rcnt, uint16_t *__restrict__ rec, int lane)
+{
+    uint32_t at = 0, ties = 0;
+    for (uint32_t base = 0; base < n; base += 64u) {
+        const uint32_t v = base + (uint32_t)lane;
+        const uint32_t x = nl_dist_bits(pu, xy, u, v, n);
+        const uint64_t mt = __builtin_amdgcn_ballot_w64(x == T);
+        const uint32_t trank = ties + __builtin_amdgcn_mbcnt_hi((uint32_t)(mt >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mt, 0u));
+        const bool sel = x < T || (x == T && trank < quota);
+        const uint64_t ms = __builtin_amdgcn_ballot_w64(sel);
+        if (sel) {
+            out[at + __builtin_amdgcn_mbcnt_hi((uint32_t)(ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ms, 0u))] = (uint16_t)v;
+            if (rcnt) {
+                const uint32_t slot = atomicAdd(&rcnt[v], 1u);
+                if (slot < (uint32_t)kNlRB) rec[(size_t)v * 64u + (uint32_t)kNlRecB0 + slot] = (uint16_t)u;
+            }
+        }
+        at += (uint32_t)__builtin_popcountll(ms);
+        ties += (uint32_t)__builtin_popcountll(mt);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nl_knn_wave(const float2 *__restrict__ xy, uint32_t n, uint32_t ka, uint32_t kb, uint16_t *__restrict__ rec,
+                                                     uint16_t *__restrict__ knn_b, uint32_t *__restrict__ dkb2, uint32_t *__restrict__ rcnt,
+                                                     const uint32_t *__restrict__ state)
+{
+    if (state[0]) return;
+    __shared__ uint32_t s_bits[4][kNlBuf];
+    __shared__ uint16_t s_idx[4][kNlBuf];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t u = blockIdx.x * 4u + (uint32_t)wave;
+    if (u >= n) return;
+    const float2 pu = xy[u];
+    uint16_t *__restrict__ out_a = rec + (size_t)u * 64u + (uint32_t)kNlRecA0, *__restrict__ out_b = knn_b + (size_t)u * kb;
+    // (1) lane minima, their KB-th smallest
+    uint32_t mine = 0xFFFFFFFFu;
+    for (uint32_t base = 0; base < n; base += 64u) {
+        const uint32_t x = nl_dist_bits(pu, xy, u, base + (uint32_t)lane, n);
+        mine = x < mine ? x : mine;
+    }
+    uint32_t rank = 0;
+    for (int m = 0; m < 64; ++m) {
+        const uint32_t y = (uint32_t)__builtin_amdgcn_readlane((int)mine, m);
+        rank += (y < mine || (y == mine && m < lane)) ? 1u : 0u;
+    }
+    const uint64_t mk = __builtin_amdgcn_ballot_w64(rank == kb - 1u);  // (kb <= 64; exactly one lane)
+    const uint32_t cap = (uint32_t)__builtin_amdgcn_readlane((int)mine, __builtin_ffsll((long long)mk) - 1);
+    // (2) the elements at or below cap, in index order
+    uint32_t cnt = 0;
+    for (uint32_t base = 0; base < n; base += 64u) {
+        const uint32_t v = base + (uint32_t)lane;
+        const uint32_t x = nl_dist_bits(pu, xy, u, v, n);
+        const bool sel = x <= cap && x != 0xFFFFFFFFu;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(sel);
+        const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (sel && pos < kNlBuf) {
+            s_bits[wave][pos] = x;
+            s_idx[wave][pos] = (uint16_t)v;
+        }
+        cnt += (uint32_t)__builtin_popcountll(m);
+    }
+    uint32_t tb, ta;
+    if (cnt <= kNlBuf && cnt >= kb) {
+        // (3) ranks by (distance, position in the buffer = index order); a lane holds entries lane, lane + 64, ...
+        uint32_t mb[kNlBuf / 64], mr[kNlBuf / 64];
+#pragma unroll
+        for (int q = 0; q < (int)(kNlBuf / 64); ++q) {
+            const uint32_t j = (uint32_t)q * 64u + (uint32_t)lane;
+            mb[q] = j < cnt ? s_bits[wave][j] : 0xFFFFFFFFu;
+            mr[q] = 0;
+        }
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const uint32_t b = s_bits[wave][i];  // (one address for the whole wave: a broadcast read)
+#pragma unroll
+            for (int q = 0; q < (int)(kNlBuf / 64); ++q) {
+                const uint32_t j = (uint32_t)q * 64u + (uint32_t)lane;
+                mr[q] += (b < mb[q] || (b == mb[q] && i < j)) ? 1u : 0u;
+            }
+        }
+        uint32_t at_a = 0, at_b = 0;
+        tb = 0;
+        ta = 0;
+#pragma unroll
+        for (int q = 0; q < (int)(kNlBuf / 64); ++q) {
+            const uint32_t j = (uint32_t)q * 64u + (uint32_t)lane;
+            const bool in = j < cnt;
+            const bool sb = in && mr[q] < kb, sa = in && mr[q] < ka;
+            const uint64_t m_b = __builtin_amdgcn_ballot_w64(sb), m_a = __builtin_amdgcn_ballot_w64(sa);
+            const uint32_t v = in ? s_idx[wave][j] : 0u;
+            if (sb) {
+                out_b[at_b + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_b, 0u))] = (uint16_t)v;
+                const uint32_t slot = atomicAdd(&rcnt[v], 1u);
+                if (slot < (uint32_t)kNlRB) rec[(size_t)v * 64u + (uint32_t)kNlRecB0 + slot] = (uint16_t)u;
+            }
+            if (sa) out_a[at_a + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_a >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_a, 0u))] = (uint16_t)v;
+            at_b += (uint32_t)__builtin_popcountll(m_b);
+            at_a += (uint32_t)__builtin_popcountll(m_a);
+            // the K-th distances: the entries of rank kb - 1 and ka - 1
+            const uint64_t kbm = __builtin_amdgcn_ballot_w64(in && mr[q] == kb - 1u), kam = __builtin_amdgcn_ballot_w64(in && mr[q] == ka - 1u);
+            if (kbm) tb = (uint32_t)__builtin_amdgcn_readlane((int)mb[q], __builtin_ffsll((long long)kbm) - 1);
+            if (kam) ta = (uint32_t)__builtin_amdgcn_readlane((int)mb[q], __builtin_ffsll((long long)kam) - 1);
+        }
+    } else {
+        uint32_t qb, qa;
+        tb = nl_bisect(pu, xy, u, n, kb, lane, &qb);
+        nl_emit_pass(pu, xy, u, n, tb, qb, out_b, rcnt, rec, lane);
+        ta = nl_bisect(pu, xy, u, n, ka, lane, &qa);
+        nl_emit_pass(pu, xy, u, n, ta, qa, out_a, nullptr, nullptr, lane);
+    }
+    if (lane == 0) {
+        dkb2[u] = tb;
+        rec[(size_t)u * 64u + 0u] = (uint16_t)(ta >> 16);  // (rounded down: a row is listed only if sq(a, b)'s high half is BELOW it)
+    }
+}
+
 constexpr size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -216,7 +366,7 @@ size_t two_opt_nl_ws_bytes(uint32_t n)
 
 // Lays the lists out in `ws` (two_opt_nl_ws_bytes; `fresh`: the buffer has just been (re)allocated and holds nothing), builds them on
 // `s` unless they are already there for these very coordinates, returns the pointers the descent kernel reads.
-hipError_t launch_two_opt_nl_build(const float2 *xy, uint32_t n, void *ws, bool fresh, TwoOptNl *out, hipStream_t s)
+hipError_t launch_two_opt_nl_build(const float2 *xy, uint32_t n, void *ws, bool fresh, TwoOptNl *out, hipStream_t s, int form)
 {
     static_assert(kNlRecA0 + kNlKA == kNlRecB0 && kNlRecB0 + kNlRB == kNlSurv0 && kNlSurv0 + kNlSurvSlots == 64, "record layout");
     const uint32_t ka = kNlKA, kb = kNlKB;
@@ -243,7 +393,8 @@ hipError_t launch_two_opt_nl_build(const float2 *xy, uint32_t n, void *ws, bool 
     hipLaunchKernelGGL(k_nl_begin, dim3(1), dim3(1), 0, s, n, state);
     hipLaunchKernelGGL(k_nl_check, per_city, dim3(256), 0, s, xy, n, kept, state);
     hipLaunchKernelGGL(k_nl_clear, dim3((n * 32u + 255u) / 256u), dim3(256), 0, s, n, rcnt, (uint32_t *)rec, state);
-    hipLaunchKernelGGL(k_nl_knn, dim3(n), dim3(kKnnThreads), lds, s, xy, n, ka, kb, rec, knn_b, dkb2, rcnt, state);
+    if (form == 1) hipLaunchKernelGGL(k_nl_knn, dim3(n), dim3(kKnnThreads), lds, s, xy, n, ka, kb, rec, knn_b, dkb2, rcnt, state);  // (the cross-check: one workgroup per city)
+    else hipLaunchKernelGGL(k_nl_knn_wave, dim3((n + 3u) / 4u), dim3(256), 0, s, xy, n, ka, kb, rec, knn_b, dkb2, rcnt, state);
     hipLaunchKernelGGL(k_nl_counts, per_city, dim3(256), 0, s, rcnt, n, rec, state);
     hipLaunchKernelGGL(k_nl_commit, per_city, dim3(256), 0, s, xy, n, kept, state);
     out->rec = rec;

@@ -26,7 +26,7 @@ def sq_bits(xy, u):
     return (d[:, 0] + d[:, 1]).astype(np.float32).view(np.uint32).astype(np.int64)
 
 
-def lists(ctx, xy):
+def lists(ctx, xy, form=0):
     n = len(xy)
     ka, kb, rb = C.c_uint32(), C.c_uint32(), C.c_uint32()
     rec = np.empty((n, 64), np.uint16)
@@ -34,15 +34,20 @@ def lists(ctx, xy):
     knn_b = np.empty((n, 24), np.uint16)
     rcnt = np.empty(n, np.uint32)
     p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
-    ctx.check(ctx.lib.tl_two_opt_neighbour_lists(ctx.handle, p(xy), n, p(rec), p(dkb2), p(knn_b), p(rcnt), C.byref(ka), C.byref(kb), C.byref(rb)))
+    ctx.check(ctx.lib.tl_two_opt_neighbour_lists(ctx.handle, p(xy), n, form, p(rec), p(dkb2), p(knn_b), p(rcnt), C.byref(ka), C.byref(kb), C.byref(rb)))
     assert (ka.value, kb.value, rb.value) == (16, 24, 36)
     return rec, dkb2, knn_b, rcnt
 
 
-@pytest.mark.parametrize("kind,n", [("uniform", 3000), ("lattice", 900), ("clusters", 1500), ("duplicates", 400)])
-def test_neighbour_lists_match_numpy(ctx, kind, n):
+@pytest.mark.parametrize("form", [0, 1])
+@pytest.mark.parametrize("kind,n", [("uniform", 3000), ("lattice", 900), ("clusters", 1500), ("duplicates", 400), ("two_points", 700), ("small", 27)])
+def test_neighbour_lists_match_numpy(ctx, kind, n, form):
     rng = np.random.default_rng(5)
-    if kind == "uniform":
+    if kind == "two_points":  # hundreds of cities at one distance: the wave kernel's buffer overflows, its bisection path runs
+        xy = np.array([[0.0, 0.0], [3.0, 4.0]])[rng.integers(0, 2, n)]
+    elif kind == "small":
+        xy = rng.random((n, 2)) * 10
+    elif kind == "uniform":
         xy = rng.random((n, 2)) * 1000
     elif kind == "lattice":  # ties at every distance
         xy = np.stack(np.meshgrid(np.arange(30), np.arange(30)), -1).reshape(-1, 2)[rng.permutation(900)]
@@ -52,7 +57,7 @@ def test_neighbour_lists_match_numpy(ctx, kind, n):
     else:  # many cities at the same point
         xy = rng.integers(0, 6, (n, 2))
     xy = np.ascontiguousarray(xy, dtype=np.float32)
-    rec, dkb2, knn_b, rcnt = lists(ctx, xy)
+    rec, dkb2, knn_b, rcnt = lists(ctx, xy, form)
     want_cnt = np.zeros(n, np.int64)
     for u in range(n):
         d = sq_bits(xy, u)
