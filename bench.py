@@ -700,7 +700,7 @@ def main():
                                                        "max": float((late_clk / d_stats[:, 9].double()).max().item())},
                 "late_steps_per_descent_mean": float((d_stats[:, 14] >> 32).double().mean().item()),
                 "note": "TL_FLAG_2OPT_NO_NL: every pruned row walks its tiles in every sweep (the round-3 kernel); default: the main loop's pruned rows stop at a posted "
-                        "hit before every live tile and a reversal inside one tile folds its new edges into the tile's bound instead of a rebuild; the sweeps after one with fewer than 400 moves (here: from the sixth on) "
+                        "hit before every live tile and a reversal inside one tile folds its new edges into the tile's bound instead of a rebuild; the sweeps after one with fewer than n / 40 moves (here: from the sixth on) "
                         "decide a row from one 128-byte record pair (16 nearest of a, reverse 24-nearest of b) + the few cities with a long tour edge; "
                         "lists built once per instance (k_nl_knn, inside kernel_ms of the first call), validated on the device per call; same tours (asserted)"}
             prob = TA.TspProblem(np.arange(n), xy)

@@ -88,7 +88,7 @@ typedef enum tl_mode {
 #define TL_FLAG_2OPT_NT256 (1u << 15)      /* LDS 2-opt: every descent on 4 waves (default: only when four descents share a CU)  */
 #define TL_FLAG_2OPT_FX (1u << 16)         /* LDS 2-opt: the grid-coordinate form (5 B per point) wherever the instance lies on a decimal grid */
 #define TL_FLAG_2OPT_NO_NL (1u << 18)      /* LDS 2-opt: never read neighbour lists — every pruned row walks its tiles (default: rows of the
-                                              late sweeps (once a sweep has applied fewer than 400 moves) of an instance with n >= 1500 read the lists, csrc/two_opt_nl.hip)               */
+                                              late sweeps (once a sweep has applied fewer than n / 40 moves) of an instance with n >= 400 read the lists, csrc/two_opt_nl.hip)               */
 #define TL_FLAG_2OPT_NL_ALWAYS (1u << 19)  /* LDS 2-opt: neighbour-list rows at every n they fit and from the second sweep on            */
 /* TUNING BUILDS ONLY (libteeline_gpu_tune.so, -DTL_TUNE: `python -m teeline_amd.build --tune`).  Forms that were measured and
  * rejected and stay as cross-checks for development; the product library does not carry them and tl_create
@@ -161,7 +161,7 @@ uint32_t tl_two_opt_lds_max_n(const tl_ctx *ctx);
 int tl_selftest_sqrt(tl_ctx *ctx, uint32_t first_bits, uint64_t count, uint64_t *mismatches, uint32_t *first_bad_bits);
 
 /* ---- diagnostics: the neighbour lists of the LDS 2-opt descent's late sweeps ---------------------------------- */
-/* Once a sweep has applied fewer than 400 moves (random restarts at n = 10^4: from the sixth sweep on), a descent of an instance with n >= 1500 (one descent per CU; TL_FLAG_2OPT_NO_NL: never) decides a
+/* Once a sweep has applied fewer than n / 40 moves (random restarts at n = 10^4: from the sixth sweep on), a descent of an instance with n >= 400 (one descent per CU; TL_FLAG_2OPT_NO_NL: never) decides a
  * row (a, b) from per-city lists instead of walking every tile (csrc/two_opt_nl.hip: improving => c is strictly closer to a than
  * b, or b strictly closer to e than c).  This builds the lists for xy as a call would and copies them out, for tests:
  * rec [n][64] u16 — per city: [0] high half of the bits of its KA-th smallest squared distance, [2] 1 if its reverse list is

@@ -6,13 +6,13 @@ using namespace tl;
 using namespace tlapi;
 
 #ifndef TL_NL_MIN_N
-#define TL_NL_MIN_N 1500u  // smallest instance whose descents build and read the neighbour lists
+#define TL_NL_MIN_N 400u  // smallest instance whose descents build and read the neighbour lists
 #endif
 #ifndef TL_NL_SWEEP_MIN
 #define TL_NL_SWEEP_MIN 3  // first sweep of a descent that may run in the late phase (tuning builds override it) ...
 #endif
-#ifndef TL_NL_MOVES_MAX
-#define TL_NL_MOVES_MAX 400u  // ... once a sweep has applied fewer moves than this (random restarts at n = 10^4: the sixth sweep; NN start: the fourth)
+#ifndef TL_NL_MOVES_DIV
+#define TL_NL_MOVES_DIV 40u  // ... once a sweep has applied fewer than n / 40 moves (n = 10^4: 250 — random restarts: the sixth sweep; NN start: the fourth)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -96,7 +96,7 @@ static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uin
             // (built once per instance: a later call with the same coordinates — compared on the device — finds them in place)
             HIPCHK(c, launch_two_opt_nl_build(d_xy, n, c->nl.p, had != c->nl.p || had_cap != c->nl.cap, &A.nl, s));
             A.nl.sweep_min = (c->flags & TL_FLAG_2OPT_NL_ALWAYS) ? 2u : (uint32_t)TL_NL_SWEEP_MIN;
-            A.nl.moves_max = (c->flags & TL_FLAG_2OPT_NL_ALWAYS) ? 0xFFFFFFFFu : (uint32_t)TL_NL_MOVES_MAX;
+            A.nl.moves_max = (c->flags & TL_FLAG_2OPT_NL_ALWAYS) ? 0xFFFFFFFFu : (n / (uint32_t)TL_NL_MOVES_DIV > 8u ? n / (uint32_t)TL_NL_MOVES_DIV : 8u);
         }
         HIPCHK(c, launch_two_opt_ref_lds(A, count, !(c->flags & TL_FLAG_NO_PRUNE), s, (c->flags & TL_FLAG_COUNT_WORK) != 0, c->cus, c->lds_bytes, force_nt));
     }
