@@ -4,10 +4,10 @@
 // e = p[j+1] (src/tsp/two_opt.rs:35-49).  In f32 that implies  sq(a,c) < sq(a,b)  or  sq(b,e) < sq(c,e)  (the kernel's L1 bound).
 // So the improving candidates of a row all lie in
 //   A = { j : c = p[j] is strictly closer to a than b is }            -> c is among the KA nearest cities of a  whenever sq(a,b) <= the
-//                                                                        KA-th smallest squared distance from a            (knn_a, dka2)
+//                                                                        KA-th smallest squared distance from a     (record words 0, 4..19)
 //   B = { j : b is strictly closer to e = p[j+1] than c = p[j] is }   -> b is among the KB nearest cities of e, i.e. e is in b's REVERSE
 //                                                                        list, whenever sq(c,e) <= the KB-th smallest squared distance
-//                                                                        from e                                            (rl, rknn, dkb2)
+//                                                                        from e                          (record words 2, 20..55; dkb2)
 // (a city strictly closer than the K-th nearest is in every K-nearest set, ties or not; squared distances are the kernel's own
 // sqdist, which is symmetric bit for bit).  Cities e with a tour edge longer than their KB-th distance are kept by the descent in a
 // short "long" list and offered to every row; rows with sq(a,b) beyond a's KA-th distance, or with a b that more than kNlRB cities

@@ -356,15 +356,17 @@ __device__ __forceinline__ bool step_boundary(Cursor &c, Acct &a, const PT &P, u
 
 
 // ------------------------------------------------------------------------------------------------
-// Late phase: the sweeps from TwoOptNl::sweep_min on (two_opt_nl.hip has the argument).
-// By then a sweep applies a few hundred moves at most and nearly every row is decided "no move"; what such a row costs in the
+// Late phase: the sweeps behind the first one (from TwoOptNl::sweep_min - 1 on) that applied fewer than TwoOptNl::moves_max moves
+// (two_opt_nl.hip has the argument).  By then a sweep applies a few hundred moves at most and nearly every row is decided "no move"; what such a row costs in the
 // main loop is L0 over every tile plus L1 over its ~3 live ones (~200 instructions).  Here a row (a, b) reads ONE 128-byte
 // record pair — the KA nearest cities of a (as c), the cities that have b among their KB nearest (as e) — adds the few "long"
 // cities whose disc reaches the block, and runs the same exact cascade once over those <= 64 candidates; rows the lists cannot
 // cover (an (a, b) longer than a's KA-th distance, a b with too long a reverse list) and sweeps with too many long cities walk
 // their tiles as before.  The loop is the main loop's pruned shape only (any block shape gives the reference's moves), without a
-// descriptor: every wave carries the whole cursor — row, column, key slot, dirty tiles, `improved` — and meets the same barriers;
-// wave 0 does not scan: it keeps the accounting, resets the next key slot and enters each move's new edges in the long list.
+// descriptor and without a control wave: every wave carries the whole cursor — row, column, key slot, dirty tiles, `improved` —,
+// scans, and meets the same barriers; a step scans the REST of the sweep (rows taken a few at a time from an LDS counter), so a sweep
+// costs one barrier per move; wave 0 keeps the accounting beside its scan, resets the next key slot and enters each move's new
+// edges in the long list.
 // State of a descent beside the tour: pos (city -> tour position), the long list (cities with a tour edge beyond their KB-th
 // squared distance: x, y, the larger of their two tour edges squared, city) and one scratch row per wave.
 struct NlLds {
