@@ -91,6 +91,8 @@ size_t two_opt_ref_lds_bytes(uint32_t n, uint32_t *n_pad_out, int nt);
 size_t two_opt_ref_nl_lds_bytes(uint32_t n);  // ... with the neighbour-list state (city -> position table, long list) beside the tour
 // would a batch of `count` descents run in the form that reads neighbour lists (16 waves, float2 points, lists + tour fit the LDS)?
 bool two_opt_ref_nl_applies(uint32_t n, uint32_t count, int cus, int lds_budget, int force_nt);
+int two_opt_ref_pick_nt(uint32_t n, uint32_t count, int cus, int lds_budget, int force_nt);   // threads per descent of such a batch
+bool two_opt_ref_nl_form(uint32_t n, uint32_t count, int cus, int lds_budget, int force_nt);  // ... and whether that form reads the lists
 hipError_t launch_two_opt_ref_lds(const TwoOptBatchArgs &A, uint32_t count, bool prune, hipStream_t s, bool count_work, int cus, int lds_budget,
                                   int force_nt);
 // grid-coordinate form (A.fx_xy / A.fx_inv set): would it let two tours share a CU where the float2 form cannot?

@@ -750,7 +750,7 @@ __device__ __forceinline__ void late_phase(const TwoOptBatchArgs &A, const PT &P
 template <int NT, bool PRUNE, bool COUNT, bool FX, bool NL = false>
 __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 {
-    static_assert(!NL || (PRUNE && !FX && NT == 1024), "late phase: the 16-wave float2 form with pruning");
+    static_assert(!NL || (PRUNE && !FX && (NT == 1024 || NT == 512)), "late phase: the 16- and 8-wave float2 forms with pruning");
     constexpr int kSlots = FX ? kFlushSlotsFx : kFlushSlots;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = NT / 64;
@@ -1434,6 +1434,9 @@ static hipError_t launch_nt(const TwoOptBatchArgs &B, uint32_t count, size_t lds
         if (prune && B.nl.rec)  // neighbour lists for the late sweeps (the caller has sized `lds` for their state)
             return count_work ? launch_one<NT, true, true, FX, true>(B, count, lds, s) : launch_one<NT, true, false, FX, true>(B, count, lds, s);
     }
+    if constexpr (NT == 512 && !FX) {  // two descents per CU, each with its late phase (uncounted, like every narrow form)
+        if (prune && B.nl.rec) return launch_one<NT, true, false, FX, true>(B, count, lds, s);
+    }
     if constexpr (NT == TL_TWO_OPT_NT && !FX) {
         if (count_work) return prune ? launch_one<NT, true, true, FX>(B, count, lds, s) : launch_one<NT, false, true, FX>(B, count, lds, s);
     }
@@ -1455,7 +1458,21 @@ hipError_t launch_two_opt_ref_lds(const TwoOptBatchArgs &A, uint32_t count, bool
         if ((size_t)A.n > (size_t)kFlushSlotsFx * 512) return hipErrorInvalidValue;
         return launch_nt<512, true>(B, count, fl, prune, count_work, s);
     }
-    // descents per CU the LDS allows; a flush holds kFlushSlots elements per thread, so a narrow form also needs n <= 15 NT
+    const int nt = two_opt_ref_pick_nt(A.n, count, cus, lds_budget, force_nt);
+    const size_t nl_lds = two_opt_ref_nl_lds_bytes(A.n);
+    // the lists are read by the 16-wave form and — where two tours WITH their late-phase state share a CU — by the 8-wave form
+    const bool nl = prune && B.nl.rec && two_opt_ref_nl_form(A.n, count, cus, lds_budget, force_nt);
+    if (!nl) B.nl.rec = nullptr;
+    if (nt == 256) return launch_nt<256, false>(B, count, lds, prune, count_work, s);
+    if (nt == 512) return launch_nt<512, false>(B, count, nl ? nl_lds : lds, prune, count_work, s);
+    return launch_nt<TL_TWO_OPT_NT, false>(B, count, nl ? nl_lds : lds, prune, count_work, s);
+}
+
+// threads per descent of a batch: 1024 where a descent has a CU to itself; where the batch exceeds the CUs and the LDS holds two or
+// four tours, 512 / 256 (2 / 4 descents per CU); a flush holds kFlushSlots elements per thread, so a narrow form also needs n <= 15 NT
+int two_opt_ref_pick_nt(uint32_t n, uint32_t count, int cus, int lds_budget, int force_nt)
+{
+    const size_t lds = two_opt_ref_lds_bytes(n, nullptr, TL_TWO_OPT_NT);
     const size_t fit = lds ? (size_t)lds_budget / lds : 1;
     int nt = TL_TWO_OPT_NT;
     if (force_nt) {
@@ -1464,11 +1481,21 @@ hipError_t launch_two_opt_ref_lds(const TwoOptBatchArgs &A, uint32_t count, bool
         if (fit >= 4 && count > 2u * (uint32_t)cus) nt = 256;  // (up to two per CU the 8-wave form is the faster one: scripts/per_cu_threshold.py)
         else if (fit >= 2) nt = 512;
     }
-    while (nt < TL_TWO_OPT_NT && (size_t)A.n > (size_t)kFlushSlots * (size_t)nt) nt *= 2;
-    if (nt != 1024 || !prune || two_opt_ref_nl_lds_bytes(A.n) > (size_t)lds_budget) B.nl.rec = nullptr;  // the lists are read by the 16-wave form only
-    if (nt == 256) return launch_nt<256, false>(B, count, lds, prune, count_work, s);
-    if (nt == 512) return launch_nt<512, false>(B, count, lds, prune, count_work, s);
-    return launch_nt<TL_TWO_OPT_NT, false>(B, count, B.nl.rec ? two_opt_ref_nl_lds_bytes(A.n) : lds, prune, count_work, s);
+    while (nt < TL_TWO_OPT_NT && (size_t)n > (size_t)kFlushSlots * (size_t)nt) nt *= 2;
+    return nt;
+}
+
+// does that form read neighbour lists?  16 waves: wherever the late-phase state fits beside the tour; 8 waves: where two such
+// descents still share a CU (a forced 8-wave form: wherever one fits)
+bool two_opt_ref_nl_form(uint32_t n, uint32_t count, int cus, int lds_budget, int force_nt)
+{
+    if (TL_TWO_OPT_NT != 1024 || n <= (uint32_t)kNlKB + 1u || n > 65535u) return false;
+    const size_t nl_lds = two_opt_ref_nl_lds_bytes(n);
+    if (nl_lds > (size_t)lds_budget) return false;
+    const int nt = two_opt_ref_pick_nt(n, count, cus, lds_budget, force_nt);
+    if (nt == 1024) return true;
+    if (nt == 512) return force_nt == 512 || 2 * nl_lds <= (size_t)lds_budget;
+    return false;
 }
 
 size_t two_opt_ref_nl_lds_bytes(uint32_t n)
@@ -1481,13 +1508,7 @@ size_t two_opt_ref_nl_lds_bytes(uint32_t n)
 
 bool two_opt_ref_nl_applies(uint32_t n, uint32_t count, int cus, int lds_budget, int force_nt)
 {
-    if (TL_TWO_OPT_NT != 1024 || (force_nt && force_nt != 1024)) return false;
-    if (n <= (uint32_t)kNlKB + 1u || n > 65535u || two_opt_ref_nl_lds_bytes(n) > (size_t)lds_budget) return false;
-    if (!force_nt && cus > 0 && count > (uint32_t)cus) {  // (the batch would run two or four descents per CU on 8 / 4 waves)
-        const size_t lds = two_opt_ref_lds_bytes(n, nullptr, TL_TWO_OPT_NT);
-        if (lds && (size_t)lds_budget / lds >= 2) return false;
-    }
-    return true;
+    return two_opt_ref_nl_form(n, count, cus, lds_budget, force_nt);
 }
 
 }  // namespace tl
