@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch, teeline_amd as TA
 dev = torch.device("cuda", 0)
 s = torch.cuda.current_stream()
-for n in (1002, 3000, 5000, 5400, 6000):
+for n in (500, 1002, 2000, 3000, 5000, 5400, 6000):
     xy = TA.synth.synth_xy(n)
     d_xy = torch.from_numpy(xy).to(dev)
     for R in (512, 1024):

@@ -750,7 +750,7 @@ __device__ __forceinline__ void late_phase(const TwoOptBatchArgs &A, const PT &P
 template <int NT, bool PRUNE, bool COUNT, bool FX, bool NL = false>
 __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
 {
-    static_assert(!NL || (PRUNE && !FX && (NT == 1024 || NT == 512)), "late phase: the 16- and 8-wave float2 forms with pruning");
+    static_assert(!NL || (PRUNE && !FX), "late phase: the float2 forms with pruning");
     constexpr int kSlots = FX ? kFlushSlotsFx : kFlushSlots;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = NT / 64;
@@ -1434,7 +1434,7 @@ static hipError_t launch_nt(const TwoOptBatchArgs &B, uint32_t count, size_t lds
         if (prune && B.nl.rec)  // neighbour lists for the late sweeps (the caller has sized `lds` for their state)
             return count_work ? launch_one<NT, true, true, FX, true>(B, count, lds, s) : launch_one<NT, true, false, FX, true>(B, count, lds, s);
     }
-    if constexpr (NT == 512 && !FX) {  // two descents per CU, each with its late phase (uncounted, like every narrow form)
+    if constexpr ((NT == 512 || NT == 256) && !FX) {  // two / four descents per CU, each with its late phase (uncounted, like every narrow form)
         if (prune && B.nl.rec) return launch_one<NT, true, false, FX, true>(B, count, lds, s);
     }
     if constexpr (NT == TL_TWO_OPT_NT && !FX) {
@@ -1463,7 +1463,7 @@ hipError_t launch_two_opt_ref_lds(const TwoOptBatchArgs &A, uint32_t count, bool
     // the lists are read by the 16-wave form and — where two tours WITH their late-phase state share a CU — by the 8-wave form
     const bool nl = prune && B.nl.rec && two_opt_ref_nl_form(A.n, count, cus, lds_budget, force_nt);
     if (!nl) B.nl.rec = nullptr;
-    if (nt == 256) return launch_nt<256, false>(B, count, lds, prune, count_work, s);
+    if (nt == 256) return launch_nt<256, false>(B, count, nl ? nl_lds : lds, prune, count_work, s);
     if (nt == 512) return launch_nt<512, false>(B, count, nl ? nl_lds : lds, prune, count_work, s);
     return launch_nt<TL_TWO_OPT_NT, false>(B, count, nl ? nl_lds : lds, prune, count_work, s);
 }
@@ -1485,8 +1485,8 @@ int two_opt_ref_pick_nt(uint32_t n, uint32_t count, int cus, int lds_budget, int
     return nt;
 }
 
-// does that form read neighbour lists?  16 waves: wherever the late-phase state fits beside the tour; 8 waves: where two such
-// descents still share a CU (a forced 8-wave form: wherever one fits)
+// does that form read neighbour lists?  16 waves: wherever the late-phase state fits beside the tour; 8 / 4 waves: where two / four
+// such descents still share a CU (a forced narrow form: wherever one fits)
 bool two_opt_ref_nl_form(uint32_t n, uint32_t count, int cus, int lds_budget, int force_nt)
 {
     if (TL_TWO_OPT_NT != 1024 || n <= (uint32_t)kNlKB + 1u || n > 65535u) return false;
@@ -1495,6 +1495,7 @@ bool two_opt_ref_nl_form(uint32_t n, uint32_t count, int cus, int lds_budget, in
     const int nt = two_opt_ref_pick_nt(n, count, cus, lds_budget, force_nt);
     if (nt == 1024) return true;
     if (nt == 512) return force_nt == 512 || 2 * nl_lds <= (size_t)lds_budget;
+    if (nt == 256) return force_nt == 256 || 4 * nl_lds <= (size_t)lds_budget;
     return false;
 }
 

@@ -9,7 +9,8 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 t0 = time.time(); runs = fails = 0
 with TA.Context(0) as ctx, TA.Context(0, TA.TL_FLAG_NO_PRUNE) as ctx2, TA.Context(0, TA.TL_FLAG_2OPT_NT512) as ctx3, \
         TA.Context(0, TA.TL_FLAG_2OPT_NT256) as ctx4, TA.Context(0, TA.TL_FLAG_2OPT_FX) as ctx5, TA.Context(0, TA.TL_FLAG_2OPT_NL_ALWAYS) as ctx6, \
-        TA.Context(0, TA.TL_FLAG_2OPT_NO_NL) as ctx7, TA.Context(0, TA.TL_FLAG_2OPT_NL_ALWAYS | TA.TL_FLAG_2OPT_NT512) as ctx8:
+        TA.Context(0, TA.TL_FLAG_2OPT_NO_NL) as ctx7, TA.Context(0, TA.TL_FLAG_2OPT_NL_ALWAYS | TA.TL_FLAG_2OPT_NT512) as ctx8, \
+        TA.Context(0, TA.TL_FLAG_2OPT_NL_ALWAYS | TA.TL_FLAG_2OPT_NT256) as ctx9:
     seed = 0
     while time.time() - t0 < budget:
         seed += 1
@@ -48,6 +49,7 @@ with TA.Context(0) as ctx, TA.Context(0, TA.TL_FLAG_NO_PRUNE) as ctx2, TA.Contex
         cases.append(("nl", prob, ctx6))
         if seed % 4 == 0: cases.append(("no_nl", prob, ctx7))
         if seed % 3 == 1: cases.append(("nl_nt512", prob, ctx8))  # the 8-wave form with its late phase (what a batch of two descents per CU runs)
+        if seed % 3 == 2: cases.append(("nl_nt256", prob, ctx9))  # ... and the 4-wave form (four per CU)
         if n <= 1500 and seed % 3 == 0:
             dm = TA.distance_matrix.build(np.arange(n), xy, ctx=ctx)
             cases.append(("matrix", TA.TspProblem(np.arange(n), xy, TA.distance_matrix.DistanceMatrix(n, dm.items, np.arange(n), "explicit")), ctx))
