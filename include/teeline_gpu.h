@@ -161,7 +161,7 @@ uint32_t tl_two_opt_lds_max_n(const tl_ctx *ctx);
 int tl_selftest_sqrt(tl_ctx *ctx, uint32_t first_bits, uint64_t count, uint64_t *mismatches, uint32_t *first_bad_bits);
 
 /* ---- diagnostics: the neighbour lists of the LDS 2-opt descent's late sweeps ---------------------------------- */
-/* Once a sweep has applied fewer than n / 40 moves (random restarts at n = 10^4: from the sixth sweep on), a descent of an instance with n >= 400 (one descent per CU, or two of n <= 5440; TL_FLAG_2OPT_NO_NL: never) decides a
+/* Once a sweep has applied fewer than n / 40 moves (random restarts at n = 10^4: from the sixth sweep on), a descent of an instance with n >= 400 (one descent per CU, or two / four of n <= 5440 / 2176; TL_FLAG_2OPT_NO_NL: never) decides a
  * row (a, b) from per-city lists instead of walking every tile (csrc/two_opt_nl.hip: improving => c is strictly closer to a than
  * b, or b strictly closer to e than c).  This builds the lists for xy as a call would and copies them out, for tests:
  * rec [n][64] u16 — per city: [0] high half of the bits of its KA-th smallest squared distance, [2] 1 if its reverse list is
