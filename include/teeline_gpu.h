@@ -161,7 +161,7 @@ uint32_t tl_two_opt_lds_max_n(const tl_ctx *ctx);
 int tl_selftest_sqrt(tl_ctx *ctx, uint32_t first_bits, uint64_t count, uint64_t *mismatches, uint32_t *first_bad_bits);
 
 /* ---- diagnostics: the neighbour lists of the LDS 2-opt descent's late sweeps ---------------------------------- */
-/* Once a sweep has applied fewer than n / 40 moves (random restarts at n = 10^4: from the sixth sweep on), a descent of an instance with n >= 400 (one descent per CU, or two / four of n <= 5440 / 2176; TL_FLAG_2OPT_NO_NL: never) decides a
+/* Once a sweep has applied fewer than n / 40 moves (random restarts at n = 10^4: from the sixth sweep on), a descent of an instance with n >= 400 (one descent per CU, or two / four of n <= 5568 / 2176; TL_FLAG_2OPT_NO_NL: never) decides a
  * row (a, b) from per-city lists instead of walking every tile (csrc/two_opt_nl.hip: improving => c is strictly closer to a than
  * b, or b strictly closer to e than c).  This builds the lists for xy as a call would and copies them out, for tests:
  * rec [n][64] u16 — per city: [0] high half of the bits of its KA-th smallest squared distance, [2] 1 if its reverse list is
@@ -171,6 +171,12 @@ int tl_selftest_sqrt(tl_ctx *ctx, uint32_t first_bits, uint64_t count, uint64_t 
  * city, radix select) — the same lists.  TL_ERR_UNSUPPORTED where the lists do not apply (n <= KB + 1). */
 int tl_two_opt_neighbour_lists(tl_ctx *ctx, const float *xy, uint32_t n, int form, uint16_t *rec, uint32_t *dkb2, uint16_t *knn_b, uint32_t *rcnt,
                                uint32_t *ka, uint32_t *kb, uint32_t *rb);
+
+/* Which form of the LDS 2-opt descent a batch of `count` descents of n cities runs on a device with `cus` compute units and
+ * `lds_bytes` of LDS per workgroup (tl_device_info), float2 points (the grid-coordinate form is decided per instance, on the device):
+ * *threads per descent (1024 / 512 / 256 = one / two / four descents per CU; 0: n exceeds the LDS-resident limit) and whether that
+ * form has the late phase on neighbour lists.  A host-only query (no context, no device): the library's own selection rule. */
+int tl_two_opt_plan(uint32_t n, uint32_t count, int cus, int lds_bytes, uint32_t flags, int *threads, int *late_phase);
 
 /* ---- distance matrix: replaces DistanceMatrix::build (distance_matrix.rs:122-153) ----------- */
 /* out_host may be NULL (matrix stays on the device for later calls on this context). */

@@ -105,6 +105,19 @@ static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uin
     return TL_OK;
 }
 
+extern "C" int tl_two_opt_plan(uint32_t n, uint32_t count, int cus, int lds_bytes, uint32_t flags, int *threads, int *late_phase)
+{
+    if (!threads || !late_phase || cus <= 0 || lds_bytes <= 0) return TL_ERR_BADARG;
+    *threads = 0;
+    *late_phase = 0;
+    if (n < 3 || n > lds_max_n(lds_bytes)) return TL_OK;
+    const int force_nt = (flags & TL_FLAG_2OPT_NT256) ? 256 : (flags & TL_FLAG_2OPT_NT512) ? 512 : 0;
+    *threads = two_opt_ref_pick_nt(n, count, cus, lds_bytes, force_nt);
+    const bool wanted = !(flags & (TL_FLAG_NO_PRUNE | TL_FLAG_2OPT_NO_NL)) && (n >= TL_NL_MIN_N || (flags & TL_FLAG_2OPT_NL_ALWAYS));
+    *late_phase = wanted && two_opt_ref_nl_form(n, count, cus, lds_bytes, force_nt) ? 1 : 0;
+    return TL_OK;
+}
+
 extern "C" int tl_two_opt_neighbour_lists(tl_ctx *c, const float *xy, uint32_t n, int form, uint16_t *rec, uint32_t *dkb2, uint16_t *knn_b, uint32_t *rcnt,
                                           uint32_t *ka, uint32_t *kb, uint32_t *rb)
 {

@@ -196,3 +196,28 @@ def test_rust_side_compiles():
         assert shutil.which("cargo") is None
         pytest.xfail("no cargo / rustc in this image: integration/teeline-gpu (lib.rs, gpu.rs, the reference patch) has never been compiled")
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_two_opt_plan_is_the_selection_rule(lib):
+    # host-only: which form of the LDS descent a batch runs (threads per descent, late phase on neighbour lists) on an MI355X-sized
+    # device (256 CUs, 160 KB of LDS).  DESIGN.md §8.
+    from teeline_amd import _capi
+
+    def plan(n, count, flags=0):
+        t, l = C.c_int(), C.c_int()
+        assert lib.tl_two_opt_plan(n, count, 256, 163840, flags, C.byref(t), C.byref(l)) == 0
+        return t.value, l.value
+
+    assert plan(10000, 256) == (1024, 1)        # the headline batch: one descent per CU, late phase
+    assert plan(10000, 1) == (1024, 1)
+    assert plan(10000, 256, _capi.TL_FLAG_2OPT_NO_NL) == (1024, 0)
+    assert plan(10000, 256, _capi.TL_FLAG_NO_PRUNE) == (1024, 0)
+    assert plan(12416, 256) == (1024, 1) and plan(12417, 256) == (1024, 0)   # the late phase's state no longer fits beside the tour
+    assert plan(399, 1) == (1024, 0) and plan(400, 1) == (1024, 1)
+    assert plan(26, 1, _capi.TL_FLAG_2OPT_NL_ALWAYS) == (1024, 1) and plan(25, 1, _capi.TL_FLAG_2OPT_NL_ALWAYS) == (1024, 0)
+    assert plan(5000, 512) == (512, 1) and plan(5568, 512) == (512, 1) and plan(5569, 512) == (512, 0)   # two descents per CU
+    assert plan(6000, 512) == (512, 0)
+    assert plan(2000, 1024) == (256, 1) and plan(3000, 1024) == (256, 0)       # four per CU
+    assert plan(10000, 512) == (1024, 0) or plan(10000, 512) == (1024, 1)      # (float2: two tours do not fit; the grid form is decided on the device)
+    assert plan(20000, 1) == (0, 0)                                             # beyond the LDS-resident limit
+    assert plan(4000, 1, _capi.TL_FLAG_2OPT_NT512) == (512, 1)
