@@ -22,7 +22,8 @@ Usage: python bench.py --gpus N --steps K --warmup W
   --single-process: no RCCL, ONE process drives N devices through tl_two_opt_multistart_devices (the path a Rust caller
         has); cross-check of the RCCL number.
   --dry-launch: rehearsal of the launch + collective plumbing on CPU (gloo, a stub step, no GPU, no oracle): NOT a measurement.
-Prints ONE JSON line on rank 0.
+Rank 0 prints the long material first (`EXTRAS {...}` lines, also written whole to ./bench_extras.json) and then, as the LAST
+stdout line, ONE compact JSON object of at most 4096 bytes (asserted) — the line the driver parses.
 """
 import argparse
 import ctypes as C
@@ -94,7 +95,9 @@ def self_launch(a):
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')]
     for ln in proc.stdout.splitlines():
-        if not ln.startswith('{"metric"'):
+        if ln.startswith("EXTRAS "):
+            print(ln)                       # the long material stays on stdout, ahead of the result line
+        elif not ln.startswith('{"metric"'):
             print(ln, file=sys.stderr)
     if proc.returncode != 0:
         for ln in lines:
@@ -344,11 +347,108 @@ def drop_in_end_to_end(TA, with_cpu):
 
 METRIC = "2-opt candidate swaps evaluated/sec + final tour cost, TSPLIB EUC_2D n=10000"
 STRONG_TOTAL = 256  # BASELINE.json configs[3]: "256 random restarts sharded 1/2/4/8 GPUs"
-SCALING_NOTE = ("two readings of configs[3] in one line: `value` / weak_per_gpu = R restarts PER GPU (one descent per CU on every GPU; work grows "
-                "with N: weak scaling, the headline) and strong_256_total = 256 restarts IN ALL dealt over the ranks as configs[3] words it.  "
-                "The strong reading is flat by design: a descent is sequential and occupies one CU, a batch takes as long as its slowest "
-                "descent (~107 ms at n = 10^4) whether a GPU runs 256 of them or 32, so N GPUs finish 256 restarts in the time of one — "
-                "strong-scaling efficiency ~1/N; more GPUs buy more restarts per unit time (weak), not a shorter batch (DESIGN.md §6)")
+XCU_ROUND_US = (1.4, 2.1)  # profiles/r02_xcu_sync_probe.json: one cross-CU agreement round (flag in L2 / device-scope atomic), measured
+SCALING_NOTE = ("value / weak_per_gpu = R restarts PER GPU (one descent per CU; weak scaling, the headline); strong_256_total = 256 restarts IN ALL "
+                "dealt over the ranks (configs[3] as worded).  The strong reading is flat by design: a descent is sequential and holds one CU, a batch "
+                "lasts as long as its slowest descent whether a GPU runs 256 or 32, so efficiency ~1/N.  Spreading ONE descent over CUs does not pay: "
+                "a cross-CU round costs 1.4-2.1 us (profiles/r02_xcu_sync_probe.json), about one whole 2.2 us step (DESIGN.md §6)")
+
+LINE_LIMIT = 4096  # the driver stopped parsing the line when it grew to 22 KB; the LAST stdout line stays below this
+SIDECAR = "bench_extras.json"
+
+
+def _round_floats(o, sig=7):
+    """floats to `sig` significant digits (the line is a report, not a checkpoint); containers walked."""
+    if isinstance(o, float):
+        return float(f"{o:.{sig}g}") if o == o and abs(o) != float("inf") else None
+    if isinstance(o, dict):
+        return {k: _round_floats(v, sig) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_round_floats(v, sig) for v in o]
+    return o
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(full):
+    """The ONE line the driver parses: the contract's keys, `roofline` and `cpu_baseline` in short form, the like-for-like rates and
+    the parity record.  Everything else (extras, per-level counters, notes) lives in the sidecar / the EXTRAS lines.  Asserted
+    <= LINE_LIMIT bytes by emit()."""
+    out = _pick(full, ("metric", "value", "unit", "n_gpus", "ranks_seen", "devices_driven", "steps", "warmup", "ms_per_step", "ms_per_step_per_rank", "launcher",
+                       "higher_is_better", "dry_launch", "scaling", "vs_baseline", "dtype", "data"))
+    cfg = full.get("config") or {}
+    out["config"] = _pick(cfg, ("workload", "n", "restarts_per_gpu", "restarts_total", "mode", "restart_seed", "launcher"))
+    if len(out["config"].get("workload", "")) > 260:
+        out["config"]["workload"] = out["config"]["workload"][:257] + "..."
+    out.update(_pick(full, ("final_tour_cost", "best_restart", "stub_units_all_ranks")))
+    r = full.get("roofline")
+    if isinstance(r, dict):
+        rr = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms_avg", "launches", "simds", "clock_mhz_live",
+                       "source", "work_matches_profile", "binding_pipe", "simd_issue_frac_valu_plus_salu"))
+        if isinstance(r.get("salu_issue"), dict):
+            rr["salu_issue"] = _pick(r["salu_issue"], ("frac",))
+        pmc = r.get("pmc") or {}
+        if pmc.get("SQ_WAVE_CYCLES") and pmc.get("SQ_WAIT_ANY") is not None:
+            rr["wait_any_frac"] = float(pmc["SQ_WAIT_ANY"]) / float(pmc["SQ_WAVE_CYCLES"])
+        if isinstance(r.get("algorithmic_hbm_view"), dict):
+            rr["algorithmic_hbm_GBps_at_8B_per_candidate"] = r["algorithmic_hbm_view"].get("GBps")
+        out["roofline"] = rr
+    else:
+        out["roofline"] = r
+    c = full.get("cpu_baseline")
+    if isinstance(c, dict):
+        cc = _pick(c, ("value", "unit", "cores", "kind", "sample", "per_core"))
+        if len(cc.get("sample", "")) > 240:
+            cc["sample"] = cc["sample"][:237] + "..."
+        if isinstance(c.get("ref_faithful_1core"), dict):
+            cc["ref_faithful_1core"] = _pick(c["ref_faithful_1core"], ("value",))
+        out["cpu_baseline"] = cc
+    else:
+        out["cpu_baseline"] = c
+    for k in ("value_l1_evaluated", "value_every_candidate_exact", "value_with_two_descents_per_cu"):
+        if isinstance(full.get(k), dict):
+            out[k] = _pick(full[k], ("value", "restarts_per_gpu"))
+    for k, v in full.items():
+        if k == "weak_per_gpu" or (k.startswith("strong_") and k.endswith("_total")):
+            out[k] = _pick(v, ("ms_per_step", "value", "restarts_per_rank", "final_tour_cost", "best_restart", "stub_units_all_ranks", "cross_cu_round_us")) if isinstance(v, dict) else v
+    out.update(_pick(full, ("scaling_note", "candidates_per_step_per_gpu", "descents_not_converged", "device", "parity_checked_restarts", "parity_mismatches")))
+    if isinstance(out.get("parity_mismatches"), list) and len(out["parity_mismatches"]) > 2:
+        out["parity_mismatches"] = out["parity_mismatches"][:2] + [f"... {len(full['parity_mismatches'])} in all: see {SIDECAR}"]
+    ex = full.get("extras")
+    if isinstance(ex, dict):
+        out["extras_file"] = SIDECAR
+        out["extras_keys"] = sorted(ex.keys())
+        if "error" in ex:
+            out["extras_error"] = str(ex["error"])[:200]
+    return _round_floats(out)
+
+
+def emit(full, stream=None):
+    """Print the result: first the long material — one `EXTRAS {...}` line per extra (and one for the headline's long objects), also
+    written whole to ./bench_extras.json (and gpurun_out/ where that exists) — then, LAST, the compact line, asserted <= LINE_LIMIT."""
+    stream = stream or sys.stdout
+    line = json.dumps(compact_line(full), separators=(",", ":"))
+    if len(line.encode()) > LINE_LIMIT:
+        raise SystemExit(f"bench.py: the result line is {len(line.encode())} bytes (> {LINE_LIMIT}): move material to the sidecar")
+    side = _round_floats(full, 9)
+    for d in (os.getcwd(), os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d) and os.access(d, os.W_OK):
+                with open(os.path.join(d, SIDECAR), "w") as fh:
+                    json.dump(side, fh, indent=1)
+        except OSError:
+            pass
+    ex = side.get("extras") if isinstance(side.get("extras"), dict) else {}
+    for k, v in ex.items():
+        print("EXTRAS " + json.dumps({k: v}, separators=(",", ":")), file=stream)
+    head = {k: side[k] for k in ("roofline", "cpu_baseline", "candidates_touched", "config") if k in side}
+    if head:
+        print("EXTRAS " + json.dumps({"headline_detail": head}, separators=(",", ":")), file=stream)
+    print(line, file=stream)
+    stream.flush()
+    return line
 
 
 def gather_rank_ms(ms_local, device, dist):
@@ -407,7 +507,7 @@ def dry_launch(a, rank, world):
     if not ok:
         raise SystemExit("bench.py --dry-launch: the shared tour is not the winner's")
     if rank == 0:
-        print(json.dumps({"metric": METRIC, "value": None, "unit": "candidates/s", "n_gpus": world, "ranks_seen": seen,
+        emit({"metric": METRIC, "value": None, "unit": "candidates/s", "n_gpus": world, "ranks_seen": seen,
                           "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt_max / max(a.steps, 1) * 1e3,
                           "ms_per_step_per_rank": per_rank, "higher_is_better": True, "dry_launch": True,
                           "scaling": "strong" if a.restarts_total > 0 else "weak", "vs_baseline": None, "dtype": "f32",
@@ -415,8 +515,8 @@ def dry_launch(a, rank, world):
                           "stub_units_all_ranks": total, "best_restart": restart, "launcher": "torch.distributed.run" if world > 1 else "none",
                           "weak_per_gpu": {"ms_per_step": dt_max / max(a.steps, 1) * 1e3, "value": None, "restarts_per_rank": R},
                           f"strong_{strong_total}_total": {"ms_per_step": s_dt_max / max(a.steps, 1) * 1e3, "value": None, "restarts_per_rank": sR,
-                                                           "stub_units_all_ranks": s_total},
-                          "scaling_note": SCALING_NOTE}))
+                                                           "stub_units_all_ranks": s_total, "cross_cu_round_us": list(XCU_ROUND_US)},
+                          "scaling_note": SCALING_NOTE})
 
 
 def single_process(a):
@@ -446,7 +546,7 @@ def single_process(a):
         kms.append(sol.stats["kernel_ms"])
     dt = time.perf_counter() - t0
     info = ctxs[0].device_info()
-    print(json.dumps({
+    emit({
         "metric": METRIC, "value": cands / dt, "unit": "candidates/s", "n_gpus": a.gpus, "ranks_seen": 1, "devices_driven": a.gpus,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -456,7 +556,7 @@ def single_process(a):
         "final_tour_cost": float(sol.total), "best_restart": sol.stats["best_restart"],
         "slowest_shard_kernel_ms": float(np.mean(kms)), "device": info,
         "note": "host-buffer entry: the rate includes the per-call PCIe traffic (coordinates up; costs, counters and the winner's tour down)",
-        "roofline": None, "cpu_baseline": None}))
+        "roofline": None, "cpu_baseline": None})
     for c in ctxs:
         c.close()
 
@@ -611,6 +711,7 @@ def main():
     else:
         strong_obj = {"ms_per_step": dt_max / a.steps * 1e3, "value": total / dt_max, "restarts_per_rank": R}
 
+    strong_obj["cross_cu_round_us"] = list(XCU_ROUND_US)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -932,9 +1033,9 @@ def main():
         out["parity_checked_restarts"] = sum(1 for k in range(len(res)) if first <= k < first + R)
         out["parity_mismatches"] = bad
         if bad:
-            print(json.dumps(out))
+            emit(out)
             raise SystemExit(f"bench.py: GPU restarts differ from the oracle: {bad[:4]}")
-    print(json.dumps(out))
+    emit(out)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -270,8 +270,9 @@ int tl_lk_trace(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed
 /* tl_lk_live (ABI v5) — the same messages WHILE the search runs: `progress` is called on the calling thread, between two polls of
  * the device-side search (every 64 rounds: a few milliseconds at n = 13 509), once per best tour the ILS settles on, in order,
  * with the tour (n positions, valid during the call only) and its best_dist — what teeline-qt's channel shows of a multi-second
- * run (teeline-qt/src/solver_engine.rs:412-434).  The callback must not call into the same context (TL_ERR_BUSY does not apply:
- * it is the owning thread) and should return quickly — the GPU idles while it runs.  With TL_FLAG_LK_ONE_WORKGROUP: one call, the
+ * run (teeline-qt/src/solver_engine.rs:412-434).  A call into the SAME context from inside the callback is refused with
+ * TL_ERR_BUSY (the running search owns the context's stream and workspace; other contexts are free to use); the callback should
+ * return quickly — the GPU idles while it runs.  With TL_FLAG_LK_ONE_WORKGROUP: one call, the
  * final tour.  (The 2-opt / 3-opt / Or-opt descents are single launches of milliseconds: their messages are replayed, above.) */
 typedef void (*tl_lk_progress_fn)(void *user, const uint32_t *best_pos, uint32_t n, float best_dist);
 int tl_lk_live(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed, const uint32_t *init_pos, const tl_lk_opts *opts,
@@ -306,7 +307,10 @@ int tl_two_opt_multistart(tl_ctx *ctx, const float *xy, uint32_t n, uint64_t see
  * proposed tl_multistart_two_opt(..., n_gpus, ...)): ctxs holds one context per device, each from tl_create(device, ...).
  * Restarts [first, first+count) are dealt in contiguous blocks (the first count % n_ctxs contexts take one more), all
  * shards run concurrently, the winner is the minimum packed key over the shards — results do not depend on n_ctxs.
- * Errors are reported on ctxs[0].  stats->kernel_ms is the slowest shard's device time. */
+ * Errors are reported on ctxs[0].  stats->kernel_ms is the slowest shard's device time.
+ * tl_multistart_shard: that deal as a host-only query (no context) — block `part` of `parts`; the ranks of a multi-process job
+ * (bench.py, teeline_amd/host/multistart.py shard_total) use the same map. */
+int tl_multistart_shard(uint32_t first, uint32_t count, int parts, int part, uint32_t *shard_first, uint32_t *shard_count);
 int tl_two_opt_multistart_devices(tl_ctx *const *ctxs, int n_ctxs, const float *xy, uint32_t n, uint64_t seed,
                                   uint32_t first, uint32_t count, int mode, uint32_t *out_best_pos, float *out_best_cost,
                                   uint32_t *out_best_restart, float *out_costs, tl_stats *stats);
@@ -329,6 +333,9 @@ int tl_two_opt_population(tl_ctx *ctx, const float *xy, uint32_t n, const float 
  * into L3, shader clocks, 100 MHz ticks, reserved...}.  stream: the hipStream_t to enqueue on,
  * or NULL for the context's own stream — which is NON-BLOCKING, i.e. not ordered with the legacy default stream: a
  * caller that passes NULL must wait on tl_last_kernel_ms() (or a device synchronise) before touching the outputs.
+ * Several asynchronous calls on one context may use different streams: the context's shared device workspace (the instance's
+ * neighbour lists, grid coordinates) is handed from one kernel sequence to the next through an event, so a call on stream B waits
+ * on the device for the previous call's descents on stream A before it rebuilds them (no host synchronisation).
  * Asynchronous: returns after enqueueing — except that a batch with more descents than the device has CUs at 7 100 < n <= 10 240
  * first asks the device whether the coordinates lie on a decimal grid (then two descents share a CU): one 4-byte read-back,
  * i.e. a synchronisation of `stream`, before the descents are enqueued. */

@@ -56,9 +56,11 @@ if sq:
         for k in sorted(sq):
             fh.write(f"{k},{sq[k]:.0f},{(sq[k] / wc if wc else 0):.4f}\n")
 bench = os.path.join(G, "bench.json")
-line = None
+line = full = None
 if os.path.exists(bench):
-    line = json.loads(open(bench).read().strip().splitlines()[-1])
+    line = json.loads(open(bench).read().strip().splitlines()[-1])   # the compact result line (<= 4096 bytes, the LAST stdout line)
+    side = os.path.join(G, "bench_extras.json")                       # the whole record bench.py wrote beside it
+    full = json.load(open(side)) if os.path.exists(side) else line
 if fetch is not None and write is not None:
     tpath = os.path.join(P, f"{rnd}_hbm_traffic.json")
     t = json.load(open(tpath)) if os.path.exists(tpath) else {}
@@ -68,11 +70,12 @@ if fetch is not None and write is not None:
     json.dump(t, open(tpath, "w"), indent=1)
     if line:
         line["roofline"]["traffic"] = t["traffic_bytes_per_launch"]
-if sq and line and "candidates_touched" in line:
+        full["roofline"]["traffic"] = t["traffic_bytes_per_launch"]
+if sq and line and "candidates_touched" in full:
     # what bench.py's roofline reads: the VALU instruction count of ONE launch of the deterministic workload, with the
     # in-kernel work counters of the same workload as its fingerprint
     v = {"n": line["config"]["n"], "restarts": line["config"]["restarts_per_gpu"], "seed": line["config"]["restart_seed"],
-         "work": {k: line["candidates_touched"][k] for k in ("l0_tile_bounds", "l1_candidates", "l2_candidates", "l3_candidates")},
+         "work": {k: full["candidates_touched"][k] for k in ("l0_tile_bounds", "l1_candidates", "l2_candidates", "l3_candidates")},
          "source": "rocprofv3 --pmc SQ_* --kernel-trace (two passes) on `bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras`, "
                    "k_two_opt_ref_lds, summed over the dispatch (scripts/profile_round.sh, scripts/harvest_profiles.py)",
          "kernel_ms_bench": line["roofline"]["kernel_ms_avg"], "clock_mhz_bench": line["roofline"]["clock_mhz_live"]}
@@ -82,5 +85,7 @@ if sq and line and "candidates_touched" in line:
         v["hbm_traffic_bytes_per_launch"] = json.load(open(tpath)).get("traffic_bytes_per_launch")
     json.dump(v, open(os.path.join(P, f"{rnd}_valu_roofline.json"), "w"), indent=1)
 if line:
-    open(os.path.join(P, f"{rnd}_bench.json"), "w").write(json.dumps(line) + "\n")
+    open(os.path.join(P, f"{rnd}_bench.json"), "w").write(json.dumps(line, separators=(",", ":")) + "\n")
+    if full is not line:
+        json.dump(full, open(os.path.join(P, f"{rnd}_bench_extras.json"), "w"), indent=1)
 print("harvested", rnd, "fetch", fetch, "write", write, "sq counters", len(sq))

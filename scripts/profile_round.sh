@@ -12,7 +12,7 @@ step() { echo "[profile_round] $(date +%T) $1"; }
   if [ "$2" != "skip-tests" ]; then
     step "pytest -m gpu" && timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; rc=$?; echo "pytest rc=$rc" >> $OUT/pytest_gpu.log; tail -3 $OUT/pytest_gpu.log; [ $rc -eq 0 ]
   fi
-} && step "bench" && timeout -k 10 300 python bench.py --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err && tail -c 600 $OUT/bench.json && cd /tmp && export TMPDIR=/tmp \
+} && step "bench" && timeout -k 10 300 python bench.py --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err && cp bench_extras.json $OUT/bench_extras.json && tail -n 1 $OUT/bench.json | wc -c && tail -n 1 $OUT/bench.json && cd /tmp && export TMPDIR=/tmp \
 && step "kernel stats" && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-work-count > $OUT/stats.log 2>&1 \
 && step "pmc fetch" && timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $BENCH_PMC > $OUT/pmc_fetch.log 2>&1 \
 && step "pmc write" && timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $BENCH_PMC > $OUT/pmc_write.log 2>&1 \

@@ -40,7 +40,7 @@ SYMBOLS = [
     "tl_two_opt_batch_dev", "tl_last_kernel_ms", "tl_dm_build_dev", "tl_build_candidates", "tl_nearest_neighbor",
     "tl_or_opt", "tl_or_opt_find_best_move", "tl_selftest_sqrt", "tl_two_opt_population", "tl_dm_is_euc2d",
     "tl_two_opt_multistart_devices", "tl_two_opt_trace", "tl_three_opt_trace", "tl_lk_trace", "tl_or_opt_trace",
-    "tl_lk_live", "tl_two_opt_neighbour_lists", "tl_two_opt_plan",
+    "tl_lk_live", "tl_two_opt_neighbour_lists", "tl_two_opt_plan", "tl_multistart_shard",
 ]
 
 
@@ -122,6 +122,7 @@ def load():
     L.tl_nearest_neighbor.argtypes = [vp, vp, vp, u32, u32, vp, f32p]
     L.tl_selftest_sqrt.argtypes = [vp, u32, u64, C.POINTER(u64), C.POINTER(u32)]
     L.tl_two_opt_plan.argtypes = [u32, u32, i32, i32, u32, C.POINTER(i32), C.POINTER(i32)]
+    L.tl_multistart_shard.argtypes = [u32, u32, i32, i32, C.POINTER(u32), C.POINTER(u32)]
     L.tl_two_opt_neighbour_lists.argtypes = [vp, vp, u32, i32, vp, vp, vp, vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.tl_or_opt.argtypes = [vp, vp, u32, vp, vp, vp, f32p, C.POINTER(TlStats)]
     L.tl_or_opt_find_best_move.argtypes = [vp, vp, u32, vp, vp, C.POINTER(i32), f32p, C.POINTER(u32), C.POINTER(u32),

@@ -69,6 +69,8 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
     try:
         bad = verify_ds_min_waits(LIB_OUT + ".tmp")
     except (RuntimeError, OSError, subprocess.CalledProcessError) as exc:  # no disassembler on this box: the check is skipped, loudly
+        if os.environ.get("TL_BUILD_STRICT"):  # CI: an unverified library is not installed
+            raise RuntimeError(f"TL_BUILD_STRICT: the ds_min_u32 wait check could not run ({exc})") from exc
         print(f"teeline_amd.build: ds_min_u32 wait check skipped ({exc})", file=sys.stderr)
         bad = []
     if bad:
@@ -138,7 +140,7 @@ def _check_ds_min_paths(text, re):
             while k < len(ins) and k not in seen:
                 seen.add(k)
                 _a, mn, ops, tgt, _k = ins[k]
-                if mn == "s_waitcnt" and ("lgkmcnt(0)" in ops or ops.strip().startswith("0")):
+                if mn == "s_waitcnt" and _waitcnt_drains_lgkm(ops):
                     break  # drained on this path
                 if mn == "s_barrier":
                     ok = False
@@ -163,6 +165,22 @@ def _check_ds_min_paths(text, re):
         if not ok:
             bad.append((kern, hex(a0)))
     return bad
+
+
+def _waitcnt_drains_lgkm(ops):
+    """True if this s_waitcnt operand text waits for lgkmcnt == 0.  Symbolic form: `lgkmcnt(0)` by name.  A raw immediate (how the
+    disassembler prints encodings it does not decompose): gfx9 SOPP simm16 carries lgkmcnt in bits [11:8] — vmcnt is [3:0]+[15:14],
+    expcnt [6:4] — so `0x0f70` (lgkmcnt 15) is NOT a drain although its text starts with a zero."""
+    t = ops.strip()
+    if "lgkmcnt(" in t:
+        return "lgkmcnt(0)" in t
+    if "cnt(" in t:            # symbolic, other counters only: lgkmcnt is not waited on
+        return False
+    try:
+        imm = int(t.split()[0].rstrip(","), 0)
+    except (ValueError, IndexError):
+        return False
+    return ((imm >> 8) & 0xF) == 0
 
 
 JITTER_LIB = os.path.join(HERE, "libteeline_gpu_jitter.so")

@@ -30,6 +30,7 @@ int ensure(tl_ctx *c, DevBuf &b, size_t bytes)
     if (bytes <= b.cap) return TL_OK;
     if (b.p) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->ws_pending) HIPCHK(c, hipEventSynchronize(c->ev_ws));  // an asynchronous batch on a caller's stream may still read it
         HIPCHK(c, hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
@@ -37,6 +38,21 @@ int ensure(tl_ctx *c, DevBuf &b, size_t bytes)
     size_t cap = bytes + bytes / 8 + 256;
     HIPCHK(c, hipMalloc(&b.p, cap));
     b.cap = cap;
+    return TL_OK;
+}
+
+
+int ws_order(tl_ctx *c, hipStream_t s)
+{
+    if (c->ws_pending && c->ws_stream != s) HIPCHK(c, hipStreamWaitEvent(s, c->ev_ws, 0));
+    return TL_OK;
+}
+
+int ws_mark(tl_ctx *c, hipStream_t s)
+{
+    HIPCHK(c, hipEventRecord(c->ev_ws, s));
+    c->ws_stream = s;
+    c->ws_pending = true;
     return TL_OK;
 }
 
@@ -111,7 +127,8 @@ extern "C" int tl_create(int device, uint32_t flags, tl_ctx **out)
     }
     c->arch = prop.gcnArchName;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_ws, hipEventDisableTiming)) != hipSuccess) {
         int rc = fail(nullptr, TL_ERR_HIP, "tl_create: %s", hipGetErrorString(e));
         delete c;
         return rc;
@@ -125,10 +142,12 @@ extern "C" void tl_destroy(tl_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->ws_pending) (void)hipEventSynchronize(c->ev_ws);
     for (DevBuf *b : {&c->xy, &c->dm, &c->init, &c->out_pos, &c->out_cost, &c->out_stats, &c->misc, &c->work, &c->dmfull, &c->kd, &c->fx, &c->nl})
         if (b->p) (void)hipFree(b->p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_ws) (void)hipEventDestroy(c->ev_ws);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -33,6 +33,14 @@ struct tl_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
+    // The context's device workspace shared by asynchronous calls (neighbour lists `nl`, grid coordinates `fx`) belongs to the LAST
+    // kernel sequence enqueued with it.  tl_two_opt_batch_dev returns before that sequence has run and takes the caller's stream, so a
+    // later call on ANOTHER stream (or on the context's own) must be ordered behind it before it rebuilds that workspace:
+    // ev_ws is recorded behind every such sequence on ws_stream; ws_order() makes a different stream wait on it.
+    hipEvent_t ev_ws = nullptr;
+    hipStream_t ws_stream = nullptr;
+    bool ws_pending = false;
+    bool in_callback = false;  // a tl_lk_live callback of this context is running: any entry into this context from inside it is refused
     int cus = 0, lds_bytes = 0;
     std::string arch;
     std::string err;
@@ -56,6 +64,10 @@ struct CtxUse {
         if (!c) return;
         const std::thread::id me = std::this_thread::get_id();
         if (c->owner.load(std::memory_order_acquire) == me) {
+            if (c->in_callback) {  // re-entry from inside a live-progress callback: the running search owns stream and workspace
+                ok = false;
+                return;
+            }
             ++c->depth;
             return;
         }
@@ -93,6 +105,8 @@ int fail(tl_ctx *c, int code, const char *fmt, ...);            // sets the cont
 int ensure(tl_ctx *c, DevBuf &b, size_t bytes);                // grow-only device buffer
 bool is_permutation(const uint32_t *p, uint32_t n);            // validate_tour, src/tsp/mod.rs:1620-1634
 uint32_t lds_max_n(int lds_bytes);                             // largest n of the LDS-resident 2-opt descent
+int ws_order(tl_ctx *c, hipStream_t s);                        // before touching nl / fx on stream s: wait for their last user on another stream
+int ws_mark(tl_ctx *c, hipStream_t s);                         // behind a kernel sequence that reads nl / fx on stream s
 // A tune-only create flag: always clear in the product build (tl_create refuses them), so the branches it selects fold away.
 #ifdef TL_TUNE
 inline uint32_t tune_flags(const tl_ctx *c) { return c->flags; }

@@ -343,7 +343,9 @@ static int lk_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed
                     if (e == hipSuccess) e = hipMemcpyAsync(&bd, G.snap_dist + at, 4, hipMemcpyDeviceToHost, c->stream);
                     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
                     if (e != hipSuccess) break;
+                    c->in_callback = true;   // an entry into THIS context from inside the callback gets TL_ERR_BUSY (CtxUse): the search owns it
                     live(live_user, live_tour.data(), n, bd);
+                    c->in_callback = false;
                 }
                 if (e != hipSuccess) {
                     rc_loop = fail(c, TL_ERR_HIP, "tl_lk_live: %s", hipGetErrorString(e));

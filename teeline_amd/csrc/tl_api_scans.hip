@@ -143,6 +143,7 @@ static int three_opt_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm
     const ScanRunState hs0{0u, 0u, 0u, dev_log_cap};
     ScanRunState hs = hs0;
     HIPCHK(c, hipMemcpyAsync(S.A.run, &hs0, sizeof(hs0), hipMemcpyHostToDevice, c->stream));
+    c->ev_valid = false;  // (an early return below must not leave this ev0 paired with an older sequence's ev1: ADVICE r04)
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     const uint64_t cap = 64ull * n + 1024;  // safety cap, far above any observed pass count
     for (;;) {
@@ -302,6 +303,7 @@ static int or_opt_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_pa
     const ScanRunState hs0{0u, 0u, 0u, dev_log_cap};
     ScanRunState hs = hs0;
     HIPCHK(c, hipMemcpyAsync(A.run, &hs0, sizeof(hs0), hipMemcpyHostToDevice, c->stream));
+    c->ev_valid = false;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     const uint64_t cap = 64ull * n + 1024;
     for (;;) {  // or_opt.rs:45 while let Some(best) = find_best_move(..)

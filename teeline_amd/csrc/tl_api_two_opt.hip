@@ -50,6 +50,10 @@ static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uin
         return fail(c, TL_ERR_UNSUPPORTED, "two_opt (on-the-fly form): n=%u exceeds the LDS-resident limit %u", n, lds_max_n(c->lds_bytes));
     }
     c->ev_valid = false;
+    {   // nl / fx / dmfull may still be read by an asynchronous batch this context enqueued on another stream
+        int rco;
+        if ((rco = ws_order(c, s))) return rco;
+    }
     HIPCHK(c, hipEventRecord(c->ev0, s));
     if (d_dm) {
         // the packed triangle (reference layout) is expanded to a full row-major matrix once per call: a row scan then
@@ -102,7 +106,7 @@ static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uin
     }
     HIPCHK(c, hipEventRecord(c->ev1, s));
     c->ev_valid = true;
-    return TL_OK;
+    return ws_mark(c, s);
 }
 
 extern "C" int tl_two_opt_plan(uint32_t n, uint32_t count, int cus, int lds_bytes, uint32_t flags, int *threads, int *late_phase)
@@ -126,7 +130,7 @@ extern "C" int tl_two_opt_neighbour_lists(tl_ctx *c, const float *xy, uint32_t n
     if (n <= (uint32_t)kNlKB + 1u || n > 65535u) return fail(c, TL_ERR_UNSUPPORTED, "tl_two_opt_neighbour_lists: n=%u outside (%d, 65535]", n, kNlKB + 1);
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
-    if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->nl, two_opt_nl_ws_bytes(n)))) return rc;
+    if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->nl, two_opt_nl_ws_bytes(n))) || (rc = ws_order(c, c->stream))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     TwoOptNl L{};
     HIPCHK(c, hipMemsetAsync(c->nl.p, 0, 256, c->stream));  // (always a fresh build here)
@@ -415,6 +419,18 @@ extern "C" int tl_two_opt_multistart(tl_ctx *c, const float *xy, uint32_t n, uin
                                          out_costs, stats);
 }
 
+// The deal of restarts [first, first + count) over `parts` devices / ranks: contiguous blocks, the first count % parts take one more.
+// Host-only; tl_two_opt_multistart_devices deals with it, and a multi-process job's ranks (teeline_amd/host/multistart.py shard_total)
+// use the same map, so that a run's result does not depend on how it was spread.
+extern "C" int tl_multistart_shard(uint32_t first, uint32_t count, int parts, int part, uint32_t *shard_first, uint32_t *shard_count)
+{
+    if (!shard_first || !shard_count || parts <= 0 || part < 0 || part >= parts) return TL_ERR_BADARG;
+    const uint32_t base = count / (uint32_t)parts, extra = count % (uint32_t)parts;
+    *shard_first = first + (uint32_t)part * base + ((uint32_t)part < extra ? (uint32_t)part : extra);
+    *shard_count = base + ((uint32_t)part < extra ? 1u : 0u);
+    return TL_OK;
+}
+
 // North-star config 4 from ONE host process (what the Rust caller has: the reference is single-process): the restarts
 // [first, first + count) are dealt in contiguous blocks to the caller's contexts — one per device, created once with
 // tl_create(device, ...) — every shard is enqueued before any is waited for, and the winner is the minimum of at most
@@ -440,12 +456,7 @@ extern "C" int tl_two_opt_multistart_devices(tl_ctx *const *ctxs, int n_ctxs, co
         uint32_t first, count;
     };
     std::vector<Shard> shard((size_t)n_ctxs);
-    const uint32_t base = count / (uint32_t)n_ctxs, extra = count % (uint32_t)n_ctxs;
-    uint32_t at = first;
-    for (int d = 0; d < n_ctxs; ++d) {
-        shard[d] = {at, base + ((uint32_t)d < extra ? 1u : 0u)};
-        at += shard[d].count;
-    }
+    for (int d = 0; d < n_ctxs; ++d) (void)tl_multistart_shard(first, count, n_ctxs, d, &shard[d].first, &shard[d].count);
     int rc;
     for (int d = 0; d < n_ctxs; ++d)
         if (shard[d].count && (rc = multistart_begin(ctxs[d], xy, n, seed, shard[d].first, shard[d].count, mode))) {

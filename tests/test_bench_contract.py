@@ -39,6 +39,49 @@ def test_committed_bench_line_follows_the_contract():
     assert line["parity_checked_restarts"] >= 1 and line["parity_mismatches"] == []
 
 
+def test_result_line_stays_within_the_size_the_driver_parses():
+    # the round-4 line was 22 112 bytes and BENCH_r04.json.parsed came back null.  The LAST stdout line is now a
+    # compact object (bench.compact_line) of at most 4096 bytes; the long material goes to EXTRAS lines + bench_extras.json.
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.LINE_LIMIT == 4096
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json"))):
+        line = json.load(open(path))
+        short = json.dumps(bench.compact_line(line), separators=(",", ":"))
+        assert len(short.encode()) <= bench.LINE_LIMIT, (path, len(short))
+        back = json.loads(short)
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                    "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert key in back, (path, key)
+        assert "extras" not in back
+        rnd = int(os.path.basename(path)[1:3])
+        if rnd >= 5:  # from round 5 on the committed line IS the compact line
+            assert os.path.getsize(path) <= bench.LINE_LIMIT + 1, path
+            assert os.path.exists(path.replace("_bench.json", "_bench_extras.json")), "the sidecar of the committed line"
+
+
+def test_emit_prints_the_compact_line_last_and_refuses_an_oversized_one(tmp_path, monkeypatch):
+    import io
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.chdir(tmp_path)
+    full = {"metric": "m", "value": 1.0, "unit": "u", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1.0, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": "w" * 1000},
+            "roofline": {"bound": "valu_issue", "achieved": 1.0, "peak": 2.0, "unit": "x", "frac": 0.5, "traffic": None, "formula": "f" * 5000},
+            "cpu_baseline": {"value": 1.0, "unit": "u", "cores": 1, "kind": "port", "sample": "s" * 3000},
+            "extras": {"a": {"note": "n" * 20000}, "b": {"x": 1}}}
+    buf = io.StringIO()
+    last = bench.emit(full, stream=buf)
+    lines = buf.getvalue().splitlines()
+    assert lines[-1] == last and lines[-1].startswith('{"metric"') and len(lines[-1].encode()) <= bench.LINE_LIMIT
+    assert [ln[:10] for ln in lines[:-1]] == ["EXTRAS {\"a", "EXTRAS {\"b", "EXTRAS {\"h"]
+    side = json.load(open(tmp_path / bench.SIDECAR))
+    assert side["extras"]["a"]["note"] == "n" * 20000 and json.loads(last)["extras_keys"] == ["a", "b"]
+    full["scaling_note"] = "z" * 5000
+    with pytest.raises(SystemExit):
+        bench.emit(full, stream=io.StringIO())
+
+
 def test_roofline_is_rederivable_from_the_committed_counters():
     bench, pmc = latest("r*_bench.json"), latest("r*_valu_roofline.json")
     if bench is None or pmc is None:
@@ -72,6 +115,7 @@ def test_bare_gpus_2_starts_two_ranks_itself():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1
+    assert out.stdout.splitlines()[-1] == lines[0] and len(lines[0].encode()) <= 4096     # the result line is the LAST line, and short
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and len(line["ms_per_step_per_rank"]) == 2
     assert line["dry_launch"] is True and line["value"] is None          # a rehearsal never carries a number
@@ -84,7 +128,8 @@ def test_bare_gpus_2_starts_two_ranks_itself():
     st = line["strong_256_total"]
     assert st["restarts_per_rank"] == 128 and st["ms_per_step"] > 0 and st["stub_units_all_ranks"] == 256 * 2  # 2 steps
     assert st["value"] is None and line["weak_per_gpu"]["value"] is None
-    assert "flat by design" in line["scaling_note"]
+    assert "flat by design" in line["scaling_note"] and "r02_xcu_sync_probe" in line["scaling_note"]
+    assert st["cross_cu_round_us"] == [1.4, 2.1]
 
 
 def test_rank_count_mismatch_is_an_error_not_a_one_gpu_run():

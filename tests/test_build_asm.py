@@ -37,6 +37,19 @@ def test_checker_follows_both_sides_of_a_branch():
     assert B._check_ds_min_paths(_BAD, re) == [("k_bad", "0x1000")]  # the taken side skips the wait
 
 
+def test_a_raw_waitcnt_immediate_is_decoded_not_prefix_matched():
+    # `s_waitcnt 0x0f70` (lgkmcnt field [11:8] = 15) starts with a zero but drains nothing
+    import re
+    assert B._waitcnt_drains_lgkm("lgkmcnt(0)") and B._waitcnt_drains_lgkm("vmcnt(0) lgkmcnt(0)")
+    assert not B._waitcnt_drains_lgkm("vmcnt(0)") and not B._waitcnt_drains_lgkm("lgkmcnt(1)")
+    assert B._waitcnt_drains_lgkm("0") and B._waitcnt_drains_lgkm("0x0070") and B._waitcnt_drains_lgkm("0xc07f")
+    assert not B._waitcnt_drains_lgkm("0x0f70") and not B._waitcnt_drains_lgkm("0x0170") and not B._waitcnt_drains_lgkm("garbage")
+    raw_bad = _GOOD.replace("s_waitcnt lgkmcnt(0)     ", "s_waitcnt 0x0f70         ").replace("s_waitcnt vmcnt(0) lgkmcnt(0)", "s_waitcnt vmcnt(0)           ")
+    assert B._check_ds_min_paths(raw_bad, re) == [("k_good", "0x1004")]
+    raw_ok = _GOOD.replace("s_waitcnt lgkmcnt(0)     ", "s_waitcnt 0xc07f         ")
+    assert B._check_ds_min_paths(raw_ok, re) == []
+
+
 @pytest.mark.parametrize("lib", ["LIB", "JITTER_LIB", "TUNE_LIB"])
 def test_every_ds_min_is_drained_before_the_next_barrier(lib):
     path = getattr(B, lib)

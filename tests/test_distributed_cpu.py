@@ -100,6 +100,66 @@ def test_two_rank_strong_shard_map():
     assert res[0][6] == res[1][6] == (res[0][7] + res[1][7])[want]
 
 
+def _shard_worker(rank, world, port, outq):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    from teeline_amd.host import multistart as ms
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rows = [ms.shard_total(rank, world, total) for total in (256, 255, 10, 7, 1)]
+        t = torch.tensor(rows, dtype=torch.int64)
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        if rank == 0:
+            outq.put([g.tolist() for g in got])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+def test_library_shard_map_is_the_ranks_shard_map(world):
+    # tl_two_opt_multistart_devices (ONE process, n_ctxs devices) deals restarts with tl_multistart_shard —
+    # contiguous blocks, the first count % n take one more; the ranks of a multi-process job use multistart.shard_total.  The two
+    # maps must be the same map, or a run's winner would depend on how it was spread: compared here for world 1..8, the ranks'
+    # side gathered over a real gloo process group of that size (world 1: no group).
+    import ctypes as C
+    from teeline_amd import _capi, build
+    from teeline_amd.host import multistart as ms
+    build.build()
+    lib = _capi.load()
+    totals = (256, 255, 10, 7, 1)
+
+    def lib_map(total, first=0):
+        out = []
+        for d in range(world):
+            f, c = C.c_uint32(), C.c_uint32()
+            assert lib.tl_multistart_shard(first, total, world, d, C.byref(f), C.byref(c)) == 0
+            out.append([f.value, c.value])
+        return out
+
+    if world == 1:
+        ranks = [[list(ms.shard_total(0, 1, t)) for t in totals]]
+    else:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q)) for r in range(world)]
+        [p.start() for p in procs]
+        ranks = q.get(timeout=180)
+        [p.join(timeout=60) for p in procs]
+        assert all(p.exitcode == 0 for p in procs)
+    for k, total in enumerate(totals):
+        assert [ranks[r][k] for r in range(world)] == lib_map(total), (world, total)
+    # a shifted first restart shifts every block; bad arguments are refused
+    assert lib_map(10, first=100) == [[100 + f, c] for f, c in lib_map(10)]
+    f, c = C.c_uint32(), C.c_uint32()
+    assert lib.tl_multistart_shard(0, 10, 0, 0, C.byref(f), C.byref(c)) == _capi.TL_ERR_BADARG
+    assert lib.tl_multistart_shard(0, 10, 4, 4, C.byref(f), C.byref(c)) == _capi.TL_ERR_BADARG
+
+
 def test_key_packing_matches_c_abi_definition():
     from teeline_amd.host import multistart as ms
     costs = torch.tensor([3.5, 1.25, 1.25, 77647.55469], dtype=torch.float32)
