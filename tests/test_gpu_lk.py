@@ -365,6 +365,36 @@ def test_progress_messages_arrive_while_the_search_runs(ctx):
     assert stamps[-1] - stamps[0] > 0.1 * run, (stamps[0] - t0, stamps[-1] - t0, run)  # ... and the others come spread over the run
 
 
+def test_live_callback_cannot_re_enter_its_own_context(ctx):
+    # the callback runs on the owning thread, so the owner guard used to let it back in — onto the stream and workspace of
+    # the running search.  Now every entry into THIS context from inside the callback is TL_ERR_BUSY; another context is free; and the
+    # search's result is untouched.
+    import teeline_amd as TA
+    n = 400
+    xy = O.synth_xy(n, seed=31)
+    seen = []
+    out = np.empty(n, dtype=np.uint32)
+    cost, st = C.c_float(), _capi.TlStats()
+    with TA.Context(0) as other:
+        @_capi.LK_PROGRESS_FN
+        def cb(user, best_pos, nn, best_dist):
+            ms = C.c_double()
+            rc_same = ctx.lib.tl_last_kernel_ms(ctx.handle, C.byref(ms))
+            tmp = np.empty(n, dtype=np.uint32)
+            c2 = C.c_float()
+            rc_same2 = ctx.lib.tl_nearest_neighbor(ctx.handle, xy.ctypes.data_as(C.c_void_p), None, n, 3, tmp.ctypes.data_as(C.c_void_p), C.byref(c2))
+            rc_other = other.lib.tl_nearest_neighbor(other.handle, xy.ctypes.data_as(C.c_void_p), None, n, 3, tmp.ctypes.data_as(C.c_void_p), C.byref(c2))
+            seen.append((rc_same, rc_same2, rc_other))
+        o = _capi.TlLkOpts(40, 10, 5, 5)
+        ctx.check(ctx.lib.tl_lk_live(ctx.handle, xy.ctypes.data_as(C.c_void_p), n, None, None, C.byref(o), 9, out.ctypes.data_as(C.c_void_p), C.byref(cost),
+                                     C.byref(st), cb, None))
+    assert seen and all(s == (_capi.TL_ERR_BUSY, _capi.TL_ERR_BUSY, 0) for s in seen), seen[:4]
+    rc, oroute, ocost, ost = O.lin_kernighan_trace(xy, epochs=40, platoo_epochs=10, seed=9)[:4]
+    assert out.tolist() == oroute.tolist() and np.float32(cost.value).tobytes() == np.float32(ocost).tobytes()
+    ms = C.c_double()
+    assert ctx.lib.tl_last_kernel_ms(ctx.handle, C.byref(ms)) == 0          # ... and the context is usable again afterwards
+
+
 def test_no_progress_messages_below_four_cities(ctx):
     # lin_kernighan.rs:57-59 returns before its first send_progress
     import teeline_amd as TA

@@ -29,9 +29,9 @@ def test_the_stress_library_is_the_jitter_build():
 
 
 @pytest.mark.parametrize("script,seconds,min_runs", [
-    ("fuzz_campaign.py", 40, 20),         # LDS 2-opt (pruned, NO_PRUNE, 8- and 4-wave forms) and the matrix form
-    ("fuzz_campaign_lk.py", 30, 20),      # LK, kd-tree candidate lists, NN seed
-    ("fuzz_campaign_oropt.py", 20, 10),   # Or-opt and 3-opt scans / solves
+    ("fuzz_campaign.py", 15, 8),          # LDS 2-opt (pruned, NO_PRUNE, 8- and 4-wave forms) and the matrix form
+    ("fuzz_campaign_lk.py", 12, 6),       # LK, kd-tree candidate lists, NN seed
+    ("fuzz_campaign_oropt.py", 8, 4),     # Or-opt and 3-opt scans / solves
 ])
 def test_results_do_not_depend_on_wave_timing(script, seconds, min_runs):
     env = dict(os.environ, TEELINE_GPU_LIB=JITTER_LIB)

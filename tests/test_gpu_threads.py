@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROBE = os.path.join(ROOT, "tests", "probes", "thread_campaign.py")
 
 
-@pytest.mark.parametrize("lib,seconds", [("libteeline_gpu.so", 20), ("libteeline_gpu_jitter.so", 20)])
+@pytest.mark.parametrize("lib,seconds", [("libteeline_gpu.so", 10), ("libteeline_gpu_jitter.so", 10)])
 def test_eight_threads_own_contexts_mixed_solvers(lib, seconds):
     path = os.path.join(ROOT, "teeline_amd", lib)
     assert os.path.exists(path), "built by __graft_entry__.build()"

@@ -194,3 +194,40 @@ def test_largest_instance_with_a_late_phase_and_the_first_without(ctx):
         assert d_cost.cpu().numpy().view(np.uint32)[0] == np.float32(cost).view(np.uint32)
         assert (int(st[0]), int(st[1]), int(st[2])) == (ost["sweeps"], ost["moves"], ost["reversed"])
         assert ((int(st[14]) >> 32) > 0) == late
+
+
+def test_async_batches_on_two_streams_of_one_context_hand_the_lists_over(ctx):
+    """the neighbour lists live in ONE per-context buffer, tl_two_opt_batch_dev is asynchronous and takes the caller's
+    stream.  Two instances, alternately, on two streams of ONE context, nothing synchronised in between: every call rebuilds the lists
+    for its coordinates while the previous call's descents may still be reading them — unless the library orders the rebuild behind
+    them on the device (ev_ws).  Every descent of every call must equal the oracle's."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n, R, rounds = 3000, 6, 4
+    inst = [O.synth_xy(n, seed=21), O.synth_xy(n, seed=22)]
+    d_xy = [torch.from_numpy(x).to(dev) for x in inst]
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    torch.cuda.synchronize()
+    outs = []
+    for k in range(rounds):
+        for w in (0, 1):
+            d_pos = torch.empty((R, n), dtype=torch.int32, device=dev)
+            d_cost = torch.empty(R, dtype=torch.float32, device=dev)
+            d_st = torch.zeros((R, 16), dtype=torch.int64, device=dev)
+            with torch.cuda.stream(streams[w]):
+                ctx.check(ctx.lib.tl_two_opt_batch_dev(ctx.handle, d_xy[w].data_ptr(), n, None, 777, 10 * k, R, 0, d_pos.data_ptr(), d_cost.data_ptr(),
+                                                       d_st.data_ptr(), C.c_void_p(streams[w].cuda_stream)))
+            outs.append((w, k, d_pos, d_cost, d_st))
+    torch.cuda.synchronize()
+    want = {}
+    for w, k, d_pos, d_cost, d_st in outs:
+        pos, cost, st = d_pos.cpu().numpy(), d_cost.cpu().numpy(), d_st.cpu().numpy()
+        assert (st[:, 14] >> 32).min() > 0, "the descents should have gone through the late phase (the lists were read)"
+        for r in range(R):
+            key = (w, 10 * k + r)
+            if key not in want:
+                rc, route, c, ost = O.two_opt(inst[w], None, n, init=O.restart_perm(n, 777, 10 * k + r))
+                want[key] = (route.tolist(), np.float32(c).tobytes(), ost["sweeps"], ost["moves"])
+            route, cbytes, sw, mv = want[key]
+            assert pos[r].astype(np.uint32).tolist() == route, (w, k, r)
+            assert np.float32(cost[r]).tobytes() == cbytes and (int(st[r, 0]), int(st[r, 1])) == (sw, mv), (w, k, r)
