@@ -27,6 +27,9 @@ TL_FLAG_2OPT_NT512, TL_FLAG_2OPT_NT256 = 1 << 14, 1 << 15  # LDS 2-opt: force th
 TL_FLAG_2OPT_FX = 1 << 16  # LDS 2-opt: grid-coordinate form of the tour (two tours of n = 10^4 per CU) wherever it is exact
 TL_FLAG_2OPT_NO_NL, TL_FLAG_2OPT_NL_ALWAYS = 1 << 18, 1 << 19  # LDS 2-opt: neighbour-list rows of the late sweeps off / wherever they fit
 TL_FLAG_LK_SCAN_PERSIST = 1 << 17  # tl_lk (tuning build): the fused scan as a persistent grid striding over the window's pairs
+TL_FLAG_LK_CHIP_WIDE = 1 << 20  # tl_lk: chip-wide scans at every n
+TL_FLAG_LK_ILS_LDS = 1 << 21    # tl_lk: the single-workgroup LDS form (k_lk_ils) at every n it fits
+TL_FLAG_LK_NO_SPECULATION = 1 << 22  # tl_lk, LDS form: epochs one after the other (default: a batch of consecutive epochs at once)
 TL_FLAG_LK_SMALL = 1 << 9  # tl_lk: the LDS-resident single-workgroup form wherever it fits
 TL_FLAG_COUNT_WORK = 1 << 8  # the LDS 2-opt kernel also counts the work of its cascade (stats words 5..8); ~8 % slower
 TL_DM_PACKED_LOWER, TL_DM_FULL = 0, 1

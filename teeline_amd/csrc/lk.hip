@@ -124,7 +124,8 @@ struct Arcs {
 // Tour positions of the chain's cities, all loads independent (one L2 latency).  Every arc boundary of the arc model is the
 // position of a chain city, so the validity walk and the application need no further pos[] / tour[] look-ups: the city
 // at a boundary position is found among these (index_at), its added-edge partner by index (partner_index).
-__device__ __forceinline__ void chain_positions(const uint32_t (&chain)[kLkMaxChain], uint32_t clen, const uint32_t *pos,
+template <typename PosT>
+__device__ __forceinline__ void chain_positions(const uint32_t (&chain)[kLkMaxChain], uint32_t clen, const PosT *pos,
                                                 uint32_t (&cpos)[kLkMaxChain])
 {
 #pragma unroll
@@ -194,11 +195,10 @@ __device__ __forceinline__ uint32_t arc_start_from_end(const Arcs &A, uint32_t p
     return best + 1u == n ? 0u : best + 1u;
 }
 // chain_is_valid_tour (lin_kernighan.rs:181-250): one Hamiltonian cycle <=> the arc walk sees all k arcs
-__device__ bool chain_valid(const uint32_t (&chain)[kLkMaxChain], uint32_t clen, const uint32_t *tour, const uint32_t *pos, uint32_t n)
+// (cpos: the chain's tour positions — chain_positions — which the caller may want to keep for lk_build_segments)
+__device__ bool chain_valid_at(const uint32_t (&cpos)[kLkMaxChain], uint32_t clen, uint32_t n)
 {
     if (clen < 4) return false;
-    uint32_t cpos[kLkMaxChain];
-    chain_positions(chain, clen, pos, cpos);
     Arcs A;
     arcs_build(cpos, clen, n, A);
     uint32_t ti = 0, arcs = 0;  // chain cities are distinct: back at index 0 <=> back at chain[0]
@@ -212,6 +212,14 @@ __device__ bool chain_valid(const uint32_t (&chain)[kLkMaxChain], uint32_t clen,
         ti = partner_index(tj, clen);
     } while (ti != 0u);
     return arcs == A.k;
+}
+__device__ bool chain_valid(const uint32_t (&chain)[kLkMaxChain], uint32_t clen, const uint32_t *tour, const uint32_t *pos, uint32_t n)
+{
+    (void)tour;
+    if (clen < 4) return false;
+    uint32_t cpos[kLkMaxChain];
+    chain_positions(chain, clen, pos, cpos);
+    return chain_valid_at(cpos, clen, n);
 }
 
 struct LkSeg {
@@ -1272,6 +1280,740 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
         S->key = 0xFFFFFFFFu;
         S->window = kLkWindowFirst < 2u * n ? kLkWindowFirst : 2u * n;  // a fresh pass: hits start at the front
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// k_lk_ils — the whole ILS of a SMALL instance (round 5): ONE persistent workgroup, every array the search
+// touches in this CU's LDS as 16-bit city ids (coordinates, candidate lists, tour, scratch tour, rank, successor, predecessor,
+// scan order, best tour: n (22 + 2k) bytes), no kernel boundary per round — at berlin52's size a round of the chip-wide form is
+// 23.6 us of launch latency around a scan of 52 x 2 x 3 candidates.
+//
+// What made the round-2 single-workgroup form (k_lk_solve<NT, true>) slow was one LANE walking a pair's whole depth-first search
+// (up to k + k^2 + ... + k^depth nodes, three dependent look-ups each).  Here find_lk_move (:345-389) runs LEVEL BY LEVEL over a
+// chunk of consecutive (t1, orientation) pairs: a lane is (live node, candidate q) — one branch of find_lk_chain's loop (:290-337)
+// — and files the child it creates, after the child's own closing test (:280-283), in the next level's queue.  A node's place in
+// the reference's depth-first order is its PATH (q0, q1, ...): as a key of `bits` per level, digit q + 1, most significant first,
+// zeros behind a node that closes — so a closing node sorts before its own descendants and after everything under an earlier
+// sibling, exactly as the recursion meets them.  The pair's first chain is the minimum key that closed (ds_min_u64 per pair), and
+// nodes behind an already posted key are not expanded.  Exactness of dropping the `break` at g1 <= EPS (:292-295): see lk_subsearch.
+// Then, as in the reference (:373-381): only that first chain of a pair is checked for a single cycle; the lowest pair with a
+// valid one wins; its lane builds the move's segment table; the workgroup copies the arcs.  Chunks grow geometrically from the
+// front (hits of a running pass sit near the front), a queue overflow halves the chunk and repeats it (the plan guarantees that a
+// chunk of one pair fits: k^(max_depth-1) <= queue capacity).
+//
+// The ILS state machine (first pass, kick, accept / plateau: :61-97) runs in the same workgroup; a launch is a SLICE of at most
+// LkArgs::ils_slice scans — the state lives in LkState + the global tour / best / city_ids between slices — so that the host can
+// drain progress snapshots (tl_lk_live) and a run of minutes is no single launch.
+namespace {
+__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l)  // l: wave-uniform
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)l));
+}
+constexpr int kIlsNT = 1024;
+#ifndef TL_ILS_SMALL_N
+#define TL_ILS_SMALL_N 200u
+#endif
+constexpr uint32_t kIlsSmallN = TL_ILS_SMALL_N;  // up to here k_lk_ils runs on 4 waves
+constexpr uint32_t kIlsHdr = 4u;  // record words in front of the chain: key lo, key hi, gain, pair (chunk-local)
+
+__host__ __device__ __forceinline__ uint32_t ils_bits(uint32_t k)
+{
+    uint32_t b = 1u;
+    while ((1u << b) < k + 1u) ++b;
+    return b;
+}
+__host__ __device__ __forceinline__ size_t ils_up16(size_t v) { return (v + 15u) & ~(size_t)15u; }
+// LDS image: xy | cand | dcand (the candidates' distances) | dnext (every city's tour edge to its successor) | 7 x u16[n] |
+// pairmin u64[kIlsNT] | two queues of qcap records of (kIlsHdr + max_depth) words
+__host__ __device__ __forceinline__ size_t ils_fixed_bytes(uint32_t n, uint32_t k)
+{
+    return ils_up16((size_t)n * 8) + ils_up16((size_t)n * k * 2) + ils_up16((size_t)n * k * 4) + ils_up16((size_t)n * 4) + 7u * ils_up16((size_t)n * 2) +
+           (size_t)kIlsNT * 8;
+}
+// the kernel's static __shared__: per-wave segment tables + words
+constexpr size_t kIlsStatic = (size_t)(kIlsNT / 64) * kLkMaxSeg * 16 + 1024;
+
+}  // namespace
+
+// the form applies iff this returns a queue capacity (records per level) > 0
+uint32_t lk_ils_qcap(uint32_t n, uint32_t k, uint32_t max_depth, size_t lds_budget)
+{
+    if (n < 4 || n > 65535u || k == 0 || max_depth == 0 || max_depth > (uint32_t)kLkMaxDepth) return 0u;
+    if (ils_bits(k) * max_depth > 64u) return 0u;
+    const size_t fixed = ils_fixed_bytes(n, k) + kIlsStatic;
+    if (fixed >= lds_budget) return 0u;
+    const size_t rec = (size_t)(kIlsHdr + max_depth) * 4;
+    size_t qcap = (lds_budget - fixed) / (2 * rec);
+    // a chunk of ONE pair must fit: its widest queued level holds k^(max_depth-1) nodes; the queues also serve as the n floats of
+    // the ordered cost sum
+    uint64_t need = 1;
+    for (uint32_t d = 1; d < max_depth; ++d) {
+        need *= k;
+        if (need > qcap) return 0u;
+    }
+    // no more than the search uses: a level of a chunk of <= 1024 pairs rarely holds more than a few hundred nodes (an overflow
+    // only halves the chunk), and a small image lets two epochs share a CU
+    size_t cap = need > 512 ? need : 512;
+    if ((size_t)n * 4 > 2 * cap * rec) cap = ((size_t)n * 4 + 2 * rec - 1) / (2 * rec);
+    if (cap > 2048) cap = 2048;
+    if (qcap > cap) qcap = cap;
+    if (qcap < 64 || 2 * qcap * rec < (size_t)n * 4) return 0u;
+    return (uint32_t)qcap;
+}
+
+size_t lk_ils_lds_bytes(uint32_t n, uint32_t k, uint32_t max_depth, uint32_t qcap)
+{
+    return ils_fixed_bytes(n, k) + 2 * (size_t)qcap * (kIlsHdr + max_depth) * 4 + kIlsStatic;
+}
+
+namespace {
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_lk_ils(LkArgs G)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ils_smem[];
+    __shared__ uint32_t s_cnt[3];
+    __shared__ uint32_t s_nsegw[NT / 64], s_clenw[NT / 64], s_widx[NT / 64], s_wcnt[NT / 64];
+    __shared__ unsigned long long s_wmask[NT / 64];
+    __shared__ LkSeg s_segw[NT / 64][kLkMaxSeg];  // per wave: the segment table of its first valid chain
+    __shared__ float s_bd;
+    const uint32_t tid = threadIdx.x, n = G.n, k = G.k, D = G.max_depth, qcap = G.ils_qcap;
+    const uint32_t bits = ils_bits(k), RW = kIlsHdr + D;
+    LkState *S = G.state;
+    // ---- LDS image
+    unsigned char *sp = ils_smem;
+    float2 *xy = reinterpret_cast<float2 *>(sp);
+    sp += ils_up16((size_t)n * 8);
+    uint16_t *cand = reinterpret_cast<uint16_t *>(sp);
+    sp += ils_up16((size_t)n * k * 2);
+    float *const dcand = reinterpret_cast<float *>(sp);  // d(t, cand[t][q]): the g1 term of a branch costs no square root
+    sp += ils_up16((size_t)n * k * 4);
+    float *const dnext = reinterpret_cast<float *>(sp);  // d(c, next[c]) of the current tour: the g2 term (t_break = next[t_next]) and g0
+    sp += ils_up16((size_t)n * 4);
+    const size_t a16 = ils_up16((size_t)n * 2);
+    uint16_t *tour = reinterpret_cast<uint16_t *>(sp), *alt = reinterpret_cast<uint16_t *>(sp + a16);
+    uint16_t *const pos = reinterpret_cast<uint16_t *>(sp + 2 * a16), *const next = reinterpret_cast<uint16_t *>(sp + 3 * a16),
+                    *const prev = reinterpret_cast<uint16_t *>(sp + 4 * a16), *const ids = reinterpret_cast<uint16_t *>(sp + 5 * a16),
+                    *const best = reinterpret_cast<uint16_t *>(sp + 6 * a16);
+    sp += 7 * a16;
+    unsigned long long *pairmin = reinterpret_cast<unsigned long long *>(sp);
+    sp += (size_t)kIlsNT * 8;
+    uint32_t *const fq0 = reinterpret_cast<uint32_t *>(sp);
+    uint32_t *const fq1 = fq0 + (size_t)qcap * RW;
+    float *fsum = reinterpret_cast<float *>(fq0);  // the ordered cost sum's edge lengths (the queues are idle then)
+
+    // mode 0: the whole ILS in this one workgroup, slice by slice.  mode 1: the first lk_pass only (:61-70), then the state goes back.
+    // mode 2: ONE EPOCH per workgroup — workgroup j of the launch kicks the current best tour with the draws of epoch S->epoch + j,
+    // runs that epoch's lk_pass and files the tour it ends on, its length and its counters in slot j; k_lk_ils_commit then takes the
+    // epochs in order up to the first one that is accepted (the later ones started from a best tour that is no longer the best).
+    const uint32_t mode = G.ils_mode, slot = blockIdx.x;
+    if (mode == 2u && (S->finished != 0u || S->epoch + slot >= G.epochs)) return;
+    const bool fresh = mode != 2u && S->applied == 0u;
+    for (uint32_t r = tid; r < n; r += NT) {
+        xy[r] = G.xy[r];
+        const uint32_t c = G.tour[r];
+        tour[r] = (uint16_t)c;
+        ids[r] = (uint16_t)(fresh ? c : G.city_ids[r]);    // :466 city_ids = tour at a pass's start
+        best[r] = (uint16_t)(fresh ? c : G.best[r]);
+    }
+    if (mode == 2u && G.ils_dcand) {  // (written by the first-pass launch)
+        for (uint32_t e = tid; e < n * k; e += NT) {
+            cand[e] = (uint16_t)G.cand[e];
+            dcand[e] = G.ils_dcand[e];
+        }
+    } else {
+        for (uint32_t e = tid; e < n * k; e += NT) {
+            const uint32_t c = G.cand[e];
+            cand[e] = (uint16_t)c;
+            const float dd = dist(G.xy[e / k], G.xy[c]);
+            dcand[e] = dd;
+            if (G.ils_dcand) G.ils_dcand[e] = dd;
+        }
+    }
+    uint32_t stage = S->stage, epoch = S->epoch, platoo = S->platoo, snaps = S->snaps;
+    float best_dist = S->best_dist;
+    uint64_t draws = S->draws, scans = S->scans, searches = S->searches, moves = S->moves, exchanged = S->exchanged;
+    TL_SYNC();
+
+    auto rebuild = [&]() {  // make_pos + flat_to_next_prev (:110-145)
+        for (uint32_t r = tid; r < n; r += NT) {
+            const uint32_t c = tour[r];
+            pos[c] = (uint16_t)r;
+            const uint32_t cn = tour[r + 1u == n ? 0u : r + 1u];
+            next[c] = (uint16_t)cn;
+            prev[c] = tour[r == 0u ? n - 1u : r - 1u];
+            dnext[c] = dist(xy[c], xy[cn]);
+        }
+        TL_SYNC();
+    };
+
+    // tour_distance (:118-122): sequential f32 sum from 0 in tour order, the closing edge last.  Only ever asked of the current tour
+    // (behind a rebuild): its edge lengths are dnext.
+    auto tour_distance = [&](const uint16_t *t) -> float {
+        for (uint32_t r = tid; r < n; r += NT) fsum[r] = dnext[t[r]];
+        TL_SYNC();
+        if (tid == 0) {
+            float total = 0.0f;
+            uint32_t q = 0;
+            const float4 *f4 = reinterpret_cast<const float4 *>(fsum);
+            for (; q + 4 <= n; q += 4) {
+                const float4 v = f4[q >> 2];
+                total += v.x;
+                total += v.y;
+                total += v.z;
+                total += v.w;
+            }
+            for (; q < n; ++q) total += fsum[q];
+            s_bd = total;
+        }
+        TL_SYNC();
+        const float r = s_bd;
+        TL_SYNC();
+        return r;
+    };
+
+    auto snapshot = [&](const uint16_t *t, float d) {  // :71,90 send_progress(best_tour, best_dist)
+        if (G.snap) {
+            if (G.snap_ring || snaps < G.snap_cap) {
+                const uint32_t at = G.snap_ring ? snaps % G.snap_cap : snaps;
+                for (uint32_t r = tid; r < n; r += NT) G.snap[(size_t)at * n + r] = t[r];
+                if (tid == 0) G.snap_dist[at] = d;
+            }
+        }
+        ++snaps;
+    };
+
+    // one branch of find_lk_chain's loop (:290-337) for the node (cw[0..d], key, gain) of pair `pl` at depth d: candidate q of its
+    // open end; the child closes (:280-283: posted), is queued for the next level, or dies
+    auto expand = [&](const uint32_t (&cw)[kLkMaxDepth + 1], const uint32_t d, const uint64_t key, const float gain, const uint32_t pl, const uint32_t q,
+                      uint32_t *fnext, const uint32_t nxt) {
+        const uint32_t t1 = cw[0] & 0xFFFFu;
+        uint32_t t_open = 0;
+#pragma unroll
+        for (int t = 0; t < kLkMaxDepth + 1; ++t) t_open = (uint32_t)t == d ? cw[t] >> 16 : t_open;
+        const uint32_t t_next = cand[t_open * k + q];
+        const float g1 = gain - dcand[t_open * k + q];
+        const uint32_t n_open = next[t_open];
+        if (g1 <= kLkEps) return;                                   // :292-295
+        const uint32_t t_break = next[t_next];
+        if (n_open == t_next || t_break == t_open) return;          // is_tour_edge
+        bool used = false;                                          // used[t_next] || used[t_break]
+#pragma unroll
+        for (int t = 0; t < kLkMaxDepth + 1; ++t) {
+            if ((uint32_t)t <= d) {
+                const uint32_t lo = cw[t] & 0xFFFFu, hi = cw[t] >> 16;
+                used |= lo == t_next || hi == t_next || lo == t_break || hi == t_break;
+            }
+        }
+        if (used) return;
+        const float2 p_break = xy[t_break];
+        const float g2 = g1 + dnext[t_next];
+        const uint64_t ck = key | ((uint64_t)(q + 1u) << (64u - bits * (d + 1u)));
+        if (g2 - dist(p_break, xy[t1]) > kLkEps) {                  // find_lk_chain(depth = d + 1) closes: :280-283
+            atomicMin(&pairmin[pl], (unsigned long long)ck);
+            return;
+        }
+        if (d + 1u >= D) return;                                    // :286-288
+        const uint32_t slot = atomicAdd(&s_cnt[nxt], 1u);
+        if (slot >= qcap) return;  // overflow: the count itself (> qcap) says so to everybody behind the level's barrier
+        uint32_t *rec = fnext + (size_t)slot * RW;
+        rec[0] = (uint32_t)ck;
+        rec[1] = (uint32_t)(ck >> 32);
+        rec[2] = __float_as_uint(g2);
+        rec[3] = pl;
+#pragma unroll
+        for (int t = 0; t < kLkMaxDepth + 1; ++t)
+            if ((uint32_t)t <= d) rec[kIlsHdr + t] = cw[t];
+        rec[kIlsHdr + d + 1u] = t_next | (t_break << 16);
+    };
+
+    // find_lk_move (:345-389): true with the move's segment table in s_seg / s_nseg, its pair in s_bestpair, its length in s_clen
+#ifdef TL_PROFILE_ILS
+    uint64_t iq[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // cycles: chunk init, level 0, deeper levels, validation, segment table, apply + rebuild, pass end, levels run
+    uint64_t it = __builtin_amdgcn_s_memtime();
+#define TL_ISTAMP(k) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); iq[k] += t_ - it; it = t_; } while (0)
+#else
+#define TL_ISTAMP(k) do { } while (0)
+#endif
+    // task w of a level -> (node w / k, candidate w % k) without an integer division: k <= 16, w < 2^16
+    const uint32_t kdiv = (1u << 20) / k + 1u;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    // find_lk_move (:345-389): true with the move's segment table in s_segw[s_win] / s_nsegw, its pair in s_bestpair, its length in s_clenw
+    uint32_t chunk0 = 128u < (uint32_t)NT ? 128u : (uint32_t)NT;
+    uint32_t hit_pair = 0u, hit_wave = 0u;  // the scan's answer: the pair, and the wave whose segment table is the move's
+    auto scan = [&]() -> bool {
+        uint32_t base = 0, chunk = chunk0;
+        while (base < 2u * n) {
+            const uint32_t CH = chunk < 2u * n - base ? chunk : 2u * n - base;
+            for (uint32_t p = tid; p < CH; p += NT) pairmin[p] = ~0ull;
+            if (tid == 0) {
+                s_cnt[0] = 0u;
+                s_cnt[1] = 0u;
+            }
+            TL_SYNC();
+            TL_ISTAMP(0);
+            // level 0: the pairs themselves
+            for (uint32_t w = tid; w < CH * k; w += NT) {
+                const uint32_t pl = (w * kdiv) >> 20, q = w - pl * k, idx = base + pl;
+                const uint32_t t1 = ids[idx >> 1];
+                const uint32_t t2 = (idx & 1u) ? prev[t1] : next[t1];  // :359 [next[t1], prev[t1]]
+                uint32_t cw[kLkMaxDepth + 1];
+#pragma unroll
+                for (int t = 0; t < kLkMaxDepth + 1; ++t) cw[t] = 0u;
+                cw[0] = t1 | (t2 << 16);
+                const float g0 = (idx & 1u) ? dnext[t2] : dnext[t1];
+                expand(cw, 0u, 0ull, g0, pl, q, fq0, 0u);
+            }
+            if (tid == 0) s_cnt[2] = 0u;  // the queue counters rotate (level L files into s_cnt[L % 3], resets s_cnt[(L + 2) % 3]): one barrier per level
+            TL_SYNC();
+            TL_ISTAMP(1);
+            uint32_t d = 1;
+            bool over = false;
+            for (;;) {
+                const uint32_t cslot = (d - 1u) % 3u, nslot = d % 3u;
+                // (read behind the barrier that closed the level which filed into this slot: stable, the same for every thread — a
+                //  separate overflow flag written by the level in progress would not be)
+                const uint32_t cntp = s_cnt[cslot];
+                over = cntp > qcap;
+                if (over || cntp == 0u || d >= D) break;
+                const uint32_t *fcur = ((d - 1u) & 1u) ? fq1 : fq0;
+                uint32_t *fnext = ((d - 1u) & 1u) ? fq0 : fq1;
+                for (uint32_t w = tid; w < cntp * k; w += NT) {
+                    const uint32_t j = (w * kdiv) >> 20, q = w - j * k;
+                    const uint32_t *rec = fcur + (size_t)j * RW;
+                    const uint64_t key = (uint64_t)rec[0] | ((uint64_t)rec[1] << 32);
+                    const uint32_t pl = rec[3];
+                    if (key > pairmin[pl]) continue;  // behind the pair's first chain in depth-first order: the recursion never gets here
+                    uint32_t cw[kLkMaxDepth + 1];
+#pragma unroll
+                    for (int t = 0; t < kLkMaxDepth + 1; ++t) cw[t] = (uint32_t)t <= d ? rec[kIlsHdr + t] : 0u;
+                    expand(cw, d, key, __uint_as_float(rec[2]), pl, q, fnext, nslot);
+                }
+                if (tid == 0) s_cnt[(d + 1u) % 3u] = 0u;
+                TL_SYNC();
+                ++d;
+#ifdef TL_PROFILE_ILS
+                iq[7] += 1;
+#endif
+            }
+            TL_ISTAMP(2);
+            if (over) {  // a queue overflowed: the same pairs again in a smaller chunk (one pair always fits)
+                chunk = CH > 1u ? CH / 2u : 1u;
+                TL_SYNC();
+                continue;
+            }
+            // The pairs' first chains (:373-381), lowest pair first: the chunk's pairs that hold a chain are numbered in pair order (a
+            // ballot per wave, the waves' counts through LDS) and taken NW at a time, one WAVE per chain — lane e holds chain city e.
+            // The chain is walked again from its key; removed edge m = (c[2m], c[2m+1]) sits behind position lo[m]; the arcs between the
+            // removed edges are numbered by rank of lo; every chain city is the START or the END of an arc; the added edges (partner)
+            // lead from arc to arc: one cycle <=> the walk from c[0] meets all k arcs (chain_is_valid_tour :181-250, what chain_valid_at
+            // does per lane).  A valid chain's segment table (apply_lk_chain :397-450: the arcs in walk order from tour[0]) comes out of
+            // the same tables.  The first batch with a valid chain holds the scan's answer: its lowest valid pair.
+            constexpr uint32_t NW = (uint32_t)NT / 64u;
+            {
+                const bool has = tid < CH && pairmin[tid < CH ? tid : 0u] != ~0ull;
+                const uint64_t bm = __builtin_amdgcn_ballot_w64(has);
+                if (lane == 0u) {
+                    s_wmask[wave] = bm;
+                    s_wcnt[wave] = (uint32_t)__builtin_popcountll(bm);
+                }
+            }
+            TL_SYNC();
+            uint32_t tot = 0u;
+            for (uint32_t w = 0; w < NW; ++w) tot += s_wcnt[w];
+            uint32_t found_pair = 0xFFFFFFFFu, found_wave = 0u;
+            for (uint32_t b0 = 0; b0 < tot && found_pair == 0xFFFFFFFFu; b0 += NW) {
+                const uint32_t r = b0 + wave;  // this wave's chain: the r-th pair with one
+                uint32_t myidx = 0xFFFFFFFFu;
+                if (r < tot) {
+                    uint32_t ws = 0u, rr = r;
+                    while (rr >= s_wcnt[ws]) {
+                        rr -= s_wcnt[ws];
+                        ++ws;
+                    }
+                    uint64_t mm = s_wmask[ws];
+                    for (uint32_t q = 0; q < rr; ++q) mm &= mm - 1ull;
+                    const uint32_t pl = (ws << 6) + (uint32_t)__builtin_ffsll((long long)mm) - 1u, idx = base + pl;
+                    const uint64_t key = pairmin[pl];
+                    const uint32_t t1 = ids[idx >> 1];
+                    uint32_t t_open = (idx & 1u) ? prev[t1] : next[t1];
+                    uint32_t ce = lane == 0u ? t1 : t_open;  // lane e: chain city e
+                    uint32_t clen = 2u;
+                    for (uint32_t lv = 0; lv < D; ++lv) {
+                        const uint32_t dg = (uint32_t)((key >> (64u - bits * (lv + 1u))) & ((1ull << bits) - 1ull));
+                        if (dg == 0u) break;
+                        const uint32_t t_next = cand[t_open * k + (dg - 1u)];
+                        const uint32_t t_break = next[t_next];
+                        ce = lane == clen ? t_next : (lane == clen + 1u ? t_break : ce);
+                        t_open = t_break;
+                        clen += 2u;
+                    }
+                    const uint32_t kk = clen >> 1;
+                    const uint32_t P = pos[lane < clen ? ce : t1];
+                    const uint32_t pu = (uint32_t)__shfl((int)P, (int)((2u * lane) & 63u)), pv = (uint32_t)__shfl((int)P, (int)((2u * lane + 1u) & 63u));
+                    const uint32_t lo = ((pu + 1u == pv) || (pu == n - 1u && pv == 0u)) ? pu : pv;  // lanes < kk: removed edge m sits behind position lo
+                    uint32_t rank = 0u;
+                    for (uint32_t j = 0; j < kk; ++j) rank += readlane_u32(lo, j) < lo ? 1u : 0u;
+                    const uint32_t lo_e = (uint32_t)__shfl((int)lo, (int)(lane >> 1)), rk_e = (uint32_t)__shfl((int)rank, (int)(lane >> 1));
+                    const bool is_end = P == lo_e;  // the END of arc rank, else the START of the arc behind it
+                    const uint32_t arc = is_end ? rk_e : (rk_e + 1u == kk ? 0u : rk_e + 1u);
+                    uint32_t mate = 0u;  // the chain city at the other end of my arc
+                    for (uint32_t j = 0; j < clen; ++j) mate = (readlane_u32(arc, j) == arc && j != lane) ? j : mate;
+                    auto partner = [&](uint32_t t) -> uint32_t { return t == 0u ? clen - 1u : (t == clen - 1u ? 0u : ((t & 1u) ? t + 1u : t - 1u)); };
+                    uint32_t ti = 0u, arcs = 0u;
+                    bool ok = clen >= 4u;
+                    if (ok) {
+                        do {
+                            const uint32_t tj = readlane_u32(mate, ti);
+                            if (++arcs > kk) {
+                                ok = false;
+                                break;
+                            }
+                            ti = partner(tj);
+                        } while (ti != 0u);
+                        ok = ok && arcs == kk;
+                    }
+                    if (ok) {
+                        // ---- valid: the segment table (lk_build_segments), by the same walk from tour position 0
+                        const bool first_removed = __builtin_amdgcn_ballot_w64(lane < kk && lo == 0u) != 0ull;
+                        int dir = first_removed ? -1 : +1;
+                        // the first run stays inside arc 0: forward to its END, or (position 0 is its END) backward to its START
+                        const uint64_t mb = __builtin_amdgcn_ballot_w64(lane < clen && arc == 0u && is_end == (dir > 0));
+                        uint32_t eb = (uint32_t)__builtin_ffsll((long long)mb) - 1u;
+                        uint32_t pp = 0u, emitted = 0u, nseg = 0u;
+                        LkSeg *seg = s_segw[wave];
+                        for (;;) {
+                            const uint32_t endp = readlane_u32(P, eb);
+                            uint32_t len = dir > 0 ? (endp >= pp ? endp - pp + 1u : endp + n - pp + 1u) : (pp >= endp ? pp - endp + 1u : pp + n - endp + 1u);
+                            if (len > n - emitted) len = n - emitted;
+                            if (lane == 0u) {
+                                seg[nseg].src = pp;
+                                seg[nseg].len = len;
+                                seg[nseg].dst = emitted;
+                                seg[nseg].dir = dir;
+                            }
+                            ++nseg;
+                            emitted += len;
+                            if (emitted >= n || nseg >= kLkMaxSeg) break;
+                            const uint32_t e = partner(eb);
+                            pp = readlane_u32(P, e);
+                            dir = readlane_u32(is_end ? 1u : 0u, e) ? -1 : +1;
+                            eb = readlane_u32(mate, e);
+                        }
+                        if (lane == 0u) {
+                            s_nsegw[wave] = nseg;
+                            s_clenw[wave] = clen;
+                        }
+                        myidx = idx;
+                    }
+                }
+                if (lane == 0u) s_widx[wave] = myidx;
+                TL_SYNC();
+                for (uint32_t w = 0; w < NW; ++w) {
+                    const uint32_t v = s_widx[w];
+                    if (v < found_pair) {
+                        found_pair = v;
+                        found_wave = w;
+                    }
+                }
+                TL_SYNC();  // (s_widx is written again by the next batch)
+            }
+            TL_ISTAMP(3);
+            if (found_pair != 0xFFFFFFFFu) {
+                hit_pair = found_pair;
+                hit_wave = found_wave;
+                chunk0 = found_pair + 64u < 128u ? 128u : found_pair + 64u;  // the next hit is most often near this one
+                chunk0 = chunk0 > (uint32_t)NT ? (uint32_t)NT : chunk0;
+                TL_ISTAMP(4);
+                return true;
+            }
+            base += CH;
+            chunk = CH * 2u < (uint32_t)NT ? CH * 2u : (uint32_t)NT;
+        }
+        chunk0 = 128u < (uint32_t)NT ? 128u : (uint32_t)NT;
+        return false;
+    };
+
+
+    // apply_lk_chain (:397-450) of the scan's move: the old tour's arcs copied in walk order from tour[0]
+    auto apply_move = [&]() {
+        const uint32_t win = hit_wave, nseg = s_nsegw[win];
+        const LkSeg *s_seg = s_segw[win];
+        for (uint32_t r = tid; r < n; r += NT) {
+            uint32_t sidx = 0;
+            while (sidx + 1u < nseg && r >= s_seg[sidx + 1u].dst) ++sidx;
+            const LkSeg sg = s_seg[sidx];
+            const uint32_t t = r - sg.dst;
+            uint32_t spos = sg.dir > 0 ? sg.src + t : sg.src + n - t;
+            if (spos >= n) spos -= n;
+            alt[r] = tour[spos];
+        }
+        searches += (uint64_t)hit_pair + 1u;
+        ++moves;
+        exchanged += (uint64_t)(s_clenw[win] / 2u);
+        TL_SYNC();
+        uint16_t *const tsw = tour;
+        tour = alt;
+        alt = tsw;
+        rebuild();
+    };
+    // double_bridge (:485-499) of the best tour with the draws of epoch e, then a fresh pass: city_ids = tour (:466)
+    auto kick_from_best = [&](uint64_t dr) {
+        if (n < 8u) {
+            for (uint32_t r = tid; r < n; r += NT) tour[r] = best[r];
+        } else {
+            const uint32_t qn = n / 4u;
+            const uint32_t r1 = (uint32_t)(splitmix64_at(G.seed, dr) % qn), r2 = (uint32_t)(splitmix64_at(G.seed, dr + 1) % qn),
+                           r3 = (uint32_t)(splitmix64_at(G.seed, dr + 2) % qn);
+            const uint32_t p1 = 1u + r1, p2 = p1 + 1u + r2, p3 = p2 + 1u + r3;
+            for (uint32_t w = tid; w < n; w += NT) {
+                uint32_t src;
+                if (w < p1) src = w;
+                else if (w < p1 + (p3 - p2)) src = p2 + (w - p1);
+                else if (w < p3) src = p1 + (w - p1 - (p3 - p2));
+                else src = w;
+                tour[w] = best[src];
+            }
+        }
+        TL_SYNC();
+        for (uint32_t r = tid; r < n; r += NT) ids[r] = tour[r];
+        rebuild();
+    };
+
+    if (mode == 2u) {
+        // ---- one epoch (:75-96 up to the comparison): kick, lk_pass, tour_distance; the verdict is k_lk_ils_commit's
+        // A speculative epoch has a budget of scans.  The reference's lk_pass can cycle — a chain's gain is a sum of rounded f32
+        // terms, and on instances with many equal distances a few moves of "gain" 1e-5 lead back to the same tour (a280: the kick of
+        // epoch 170 from the best tour of epoch 10, found by this very kernel; the oracle does not return from it either).  The
+        // sequential loop never meets such an epoch when an earlier one is accepted first, so a speculative one must not hang
+        // the launch: out of budget it files "unfinished" and the verdict stops in front of it; only an epoch that is really next
+        // (slot 0) is run again with a larger budget (S->window counts the doublings).
+        const uint32_t e = S->epoch + slot;
+        const uint32_t lvl = S->window < 6u ? S->window : 6u;
+        const uint64_t ep_budget = (uint64_t)G.ils_slice << (3u * lvl);
+        scans = searches = moves = exchanged = 0ull;
+        kick_from_best(3ull * e);
+        bool unfinished = false;
+        for (;;) {
+            if (scans >= ep_budget) {
+                unfinished = true;
+                break;
+            }
+            const bool found = scan();
+            ++scans;
+            if (!found) break;
+            apply_move();
+        }
+        searches += 2ull * n;
+        const float dcur = tour_distance(tour);
+        for (uint32_t r = tid; r < n; r += NT) G.ils_ep_tour[(size_t)slot * n + r] = tour[r];
+        if (tid == 0) {
+            G.ils_ep_dist[slot] = dcur;
+            uint64_t *cn = G.ils_ep_cnt + (size_t)slot * 4;
+            cn[0] = unfinished ? ~0ull : scans;
+            cn[1] = searches;
+            cn[2] = moves;
+            cn[3] = exchanged;
+        }
+        return;
+    }
+
+    // ---- lin_kernighan::solve (:35-100), from wherever the previous slice stopped
+    rebuild();
+    uint32_t budget = G.ils_slice;
+    bool fin = S->finished != 0u;
+    uint64_t pass_scans = 0;
+    bool cycling = false;
+    while (!fin && budget != 0u) {
+        --budget;
+        const bool found = scan();
+        ++scans;
+        if (found) {
+            apply_move();
+            TL_ISTAMP(5);
+            if (++pass_scans > (1ull << 31)) {  // (per launch: a pass of 2^31 moves is a cycle — see the epochs' budget)
+                cycling = true;
+                break;
+            }
+            continue;
+        }
+        pass_scans = 0;
+        searches += 2ull * n;
+        // ---- this lk_pass is over (:472-473)
+        bool kick;
+        if (stage == 0u) {                          // the initial pass (:61-70)
+            for (uint32_t r = tid; r < n; r += NT) best[r] = tour[r];
+            TL_SYNC();
+            best_dist = tour_distance(best);
+            stage = 1u;
+            epoch = 0u;
+            platoo = 0u;
+            snapshot(tour, best_dist);
+            kick = G.epochs > 0u;
+            if (mode == 1u) {  // the epochs are the speculative launches' (mode 2)
+                fin = !kick;
+                break;
+            }
+        } else {                                    // an epoch's pass (:85-96)
+            const float dcur = tour_distance(tour);
+            bool stop = false;
+            if (dcur < best_dist) {
+                for (uint32_t r = tid; r < n; r += NT) best[r] = tour[r];
+                snapshot(tour, dcur);
+                best_dist = dcur;
+                platoo = 0u;
+            } else if (++platoo >= G.platoo_epochs) {
+                stop = true;
+            }
+            ++epoch;
+            kick = !stop && epoch < G.epochs;
+        }
+        TL_SYNC();
+        if (!kick) {
+            fin = true;
+            break;
+        }
+        kick_from_best(draws);
+        if (n >= 8u) draws += 3;
+        TL_ISTAMP(6);
+        // a full ring of undelivered snapshots ends the slice: the host drains it and starts the next one
+        if (G.snap && G.snap_ring && snaps - G.snap_delivered >= G.snap_cap) break;
+    }
+#ifdef TL_PROFILE_ILS
+    if (tid == 0)
+        printf("k_lk_ils n=%u: scans %lu; cycles per scan: chunk init %lu, level 0 %lu, deeper levels %lu (%lu levels per 100 scans), validation %lu, segment table %lu, apply + rebuild %lu, pass end %lu\n",
+               n, (unsigned long)(scans - S->scans), (unsigned long)(iq[0] / (scans - S->scans + 1)), (unsigned long)(iq[1] / (scans - S->scans + 1)), (unsigned long)(iq[2] / (scans - S->scans + 1)),
+               (unsigned long)(iq[7] * 100 / (scans - S->scans + 1)), (unsigned long)(iq[3] / (scans - S->scans + 1)), (unsigned long)(iq[4] / (scans - S->scans + 1)),
+               (unsigned long)(iq[5] / (scans - S->scans + 1)), (unsigned long)(iq[6] / (scans - S->scans + 1)));
+#endif
+    // ---- the state goes back to HBM (the next slice, or the result)
+    TL_SYNC();
+    for (uint32_t r = tid; r < n; r += NT) {
+        G.tour[r] = tour[r];
+        G.city_ids[r] = ids[r];
+        G.best[r] = best[r];
+    }
+    if (tid == 0) {
+        S->applied = 1u;
+        S->finished = fin ? 1u : (cycling ? 2u : 0u);
+        S->stage = stage;
+        S->epoch = epoch;
+        S->platoo = platoo;
+        S->best_dist = best_dist;
+        S->draws = draws;
+        S->scans = scans;
+        S->searches = searches;
+        S->moves = moves;
+        S->exchanged = exchanged;
+        S->snaps = snaps;
+    }
+}
+
+}  // namespace
+
+namespace {
+// The verdict over a batch of speculative epochs (k_lk_ils mode 2), in epoch order, exactly as the sequential loop gives it
+// (lin_kernighan.rs:75-97): an epoch's counters count; shorter than the best -> it becomes the best (PathUpdate), the plateau
+// count restarts, and the batch ends here — the later epochs of the batch were kicked from a tour that is no longer the best and
+// are run again; not shorter -> the plateau count grows and may end the search.
+__global__ __launch_bounds__(256) void k_lk_ils_commit(LkArgs G)
+{
+    __shared__ uint32_t s_acc;
+    __shared__ float s_d;
+    LkState *S = G.state;
+    if (S->finished) return;
+    const uint32_t tid = threadIdx.x, n = G.n;
+    const uint32_t left = G.epochs - S->epoch, P = G.ils_P < left ? G.ils_P : left;
+    if (tid == 0) {
+        uint32_t epoch = S->epoch, platoo = S->platoo, acc = 0xFFFFFFFFu;
+        float best_dist = S->best_dist;
+        uint64_t scans = S->scans, searches = S->searches, moves = S->moves, exchanged = S->exchanged;
+        bool fin = false;
+        uint32_t window = S->window;
+        for (uint32_t j = 0; j < P; ++j) {
+            const uint64_t *cn = G.ils_ep_cnt + (size_t)j * 4;
+            if (cn[0] == ~0ull) {  // out of its scan budget: the verdict stops in front of it; if it is the next epoch it runs again, longer
+                if (j == 0u) {
+                    ++window;
+                    if (window > 6u) S->key = 0xDEAD0001u;  // 8192 << 18 scans in one lk_pass: it does not terminate (nor does the reference's)
+                }
+                break;
+            }
+            if (j == 0u) window = 0u;
+            scans += cn[0];
+            searches += cn[1];
+            moves += cn[2];
+            exchanged += cn[3];
+            const float d = G.ils_ep_dist[j];
+            bool stop = false;
+            if (d < best_dist) {      // :86
+                best_dist = d;
+                platoo = 0u;
+                acc = j;
+            } else if (++platoo >= G.platoo_epochs) {  // :92-95
+                stop = true;
+            }
+            ++epoch;
+            fin = stop || epoch >= G.epochs;
+            if (fin || acc != 0xFFFFFFFFu) break;
+        }
+        S->epoch = epoch;
+        S->platoo = platoo;
+        S->best_dist = best_dist;
+        S->draws = n >= 8u ? 3ull * epoch : 0ull;
+        S->scans = scans;
+        S->searches = searches;
+        S->moves = moves;
+        S->exchanged = exchanged;
+        S->finished = fin ? 1u : (S->key == 0xDEAD0001u ? 2u : 0u);
+        S->window = window;
+        s_acc = acc;
+        s_d = best_dist;
+#ifdef TL_DEBUG_ILS
+        printf("commit: P %u -> epoch %u platoo %u acc %u best %.5f scans %lu fin %d\n", P, epoch, platoo, acc, (double)best_dist, (unsigned long)scans, (int)fin);
+#endif
+    }
+    TL_SYNC();
+    const uint32_t acc = s_acc;
+    if (acc == 0xFFFFFFFFu) return;
+    const uint32_t *src = G.ils_ep_tour + (size_t)acc * n;
+    const uint32_t sidx = S->snaps;
+    const bool keep = G.snap && (G.snap_ring || sidx < G.snap_cap);
+    const uint32_t at = G.snap_ring ? sidx % (G.snap_cap ? G.snap_cap : 1u) : sidx;
+    for (uint32_t r = tid; r < n; r += 256u) {
+        const uint32_t c = src[r];
+        G.best[r] = c;
+        if (keep) G.snap[(size_t)at * n + r] = c;  // :90 send_progress(best_tour, best_dist)
+    }
+    TL_SYNC();
+    if (tid == 0) {
+        if (keep) G.snap_dist[at] = s_d;
+        S->snaps = sidx + 1u;
+    }
+}
+}  // namespace
+
+hipError_t launch_lk_ils_commit(const LkArgs &G, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_lk_ils_commit, dim3(1), dim3(256), 0, s, G);
+    return hipGetLastError();
+}
+
+hipError_t launch_lk_ils(const LkArgs &G, hipStream_t s)
+{
+    const size_t lds = ils_fixed_bytes(G.n, G.k) + 2 * (size_t)G.ils_qcap * (kIlsHdr + G.max_depth) * 4;
+    auto go = [&](auto kern, int nt) -> hipError_t {
+        hipError_t e = allow_max_lds(reinterpret_cast<const void *>(kern));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(G.ils_mode == 2u ? G.ils_P : 1u), dim3(nt), lds, s, G);
+        return hipGetLastError();
+    };
+    // a level of a small instance is a few hundred lanes: four waves meet at a barrier faster than sixteen
+    const uint32_t nt = G.ils_threads ? G.ils_threads : (G.n <= kIlsSmallN ? 256u : 1024u);
+    if (nt == 256u) return go(k_lk_ils<256>, 256);
+    if (nt == 512u) return go(k_lk_ils<512>, 512);
+    return go(k_lk_ils<kIlsNT>, kIlsNT);
 }
 
 // after a move: tour = alt, rank / successor / predecessor of every city — spread over the chip

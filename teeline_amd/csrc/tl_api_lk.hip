@@ -7,6 +7,13 @@ using namespace tlapi;
 
 // lin_kernighan cut-over (measured, NOTEBOOK.md §4.6): the LDS-resident single workgroup never wins -> 0
 static constexpr uint32_t kLkSmallMaxN = 0, kLkSmallWave64MaxN = 0, kLkSmall256MaxN = 0;
+#ifndef TL_LK_ILS_MAX_N
+#define TL_LK_ILS_MAX_N 2000u  // largest n the LDS-resident ILS (k_lk_ils) takes by default
+#endif
+static constexpr uint32_t kLkIlsMaxN = TL_LK_ILS_MAX_N;
+static constexpr uint32_t kLkIlsSlice = 8192u;  // scans per launch of k_lk_ils (tens of milliseconds)
+static constexpr uint32_t kLkIlsEpochScans = 512u;  // scans a speculative epoch may take before it files "unfinished" (x 8 per retry as the next epoch)
+static constexpr int kLkIlsBatches = 16;         // batches of speculative epochs per poll of the state (at most one progress message per batch: the ring holds 64)
 
 static bool max_depth_ge2_split(uint32_t) { return true; }
 
@@ -192,7 +199,14 @@ static int lk_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed
     const uint32_t variant_flags = TL_FLAG_LK_ONE_WORKGROUP | TL_FLAG_LK_NO_SPLIT | TL_FLAG_LK_SPLIT2 | TL_FLAG_LK_NO_SUBCHAINS | TL_FLAG_LK_SEPARATE_PICK | TL_FLAG_LK_NO_GRAPH | TL_FLAG_LK_SEPARATE_STEP | TL_FLAG_LK_SCAN_PERSIST;
     const bool lk_small = ((tf & TL_FLAG_LK_SMALL) || (!((c->flags | tf) & variant_flags) && n <= small_max_n)) &&
                           lk_small_lds_bytes(n, k_small) + 4096 <= (size_t)c->lds_bytes;
-    const bool multi_cu = !(c->flags & TL_FLAG_LK_ONE_WORKGROUP) && !lk_small;
+    // Small instances (round 5): the whole ILS as ONE persistent workgroup with every array in LDS and a level-synchronous search
+    // (k_lk_ils, lk.hip) — no kernel boundary per round.  Wherever its state and its level queues fit one CU's LDS, up to the size
+    // from which the chip-wide scans are faster (kLkIlsMaxN, measured: scripts/timing_lk_ils.py); TL_FLAG_LK_ILS_LDS: wherever it
+    // fits; TL_FLAG_LK_CHIP_WIDE: never.
+    const uint32_t ils_qcap = deep ? tl_lk_deep::lk_ils_qcap(n, k_small, o.max_depth, (size_t)c->lds_bytes) : lk_ils_qcap(n, k_small, o.max_depth, (size_t)c->lds_bytes);
+    const bool lk_ils = ils_qcap != 0u && !lk_small && !((c->flags | tf) & (variant_flags | TL_FLAG_LK_CHIP_WIDE)) &&
+                        (n <= kLkIlsMaxN || (c->flags & TL_FLAG_LK_ILS_LDS));
+    const bool multi_cu = !(c->flags & TL_FLAG_LK_ONE_WORKGROUP) && !lk_small && !lk_ils;
     const size_t slot_words = deep ? tl_lk_deep::lk_chain_slot_words() : lk_chain_slot_words();
     const size_t sub_bytes = (deep ? tl_lk_deep::lk_sub_slot_words() : lk_sub_slot_words()) * 4;  // 64 at depth <= 6
     const size_t o_pairmin = o_chains + (multi_cu ? up((size_t)2 * n * slot_words * 4) : 0);
@@ -208,11 +222,17 @@ static int lk_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed
                             !(tf & (TL_FLAG_LK_SEPARATE_PICK | TL_FLAG_LK_NO_SUBCHAINS));
     const bool keep_sub = split_scan && !fused_pick && sub_b <= ((size_t)4 << 30) && !(tf & TL_FLAG_LK_NO_SUBCHAINS);
     const size_t o_sub = o_pairmin + (split_scan ? up((size_t)2 * n * 4) : 0);
-    const size_t total = o_sub + (keep_sub ? up(sub_b) : 0);
+    // k_lk_ils with speculative epochs: the candidates' distances and, per epoch of a batch, its final tour, length and counters
+    const bool ils_spec = lk_ils && !(c->flags & TL_FLAG_LK_NO_SPECULATION);
+    const size_t ils_lds = lk_ils ? (deep ? tl_lk_deep::lk_ils_lds_bytes(n, k_small, o.max_depth, ils_qcap) : lk_ils_lds_bytes(n, k_small, o.max_depth, ils_qcap)) : 0;
+    const uint32_t ils_P = ils_spec ? (uint32_t)c->cus * (2 * ils_lds <= (size_t)c->lds_bytes ? 2u : 1u) : 0u;  // two epochs per CU where their images fit
+    const size_t o_ils_dc = o_sub + (keep_sub ? up(sub_b) : 0), o_ils_tour = o_ils_dc + (ils_spec ? up((size_t)n * k_small * 4) : 0),
+                 o_ils_dist = o_ils_tour + up((size_t)ils_P * n * 4), o_ils_cnt = o_ils_dist + up((size_t)ils_P * 4);
+    const size_t total = o_ils_cnt + up((size_t)ils_P * 32);
     // every mode / size check and every allocation comes before the first event record and the first enqueue: a rejected call
     // leaves the previous kernel sequence's event pair intact and nothing in flight
     // (the single-workgroup forms keep no snapshots on the device: a trace of theirs is the final best tour alone, below)
-    const bool snap_dev = snap_pos && multi_cu;
+    const bool snap_dev = snap_pos && (multi_cu || lk_ils);
     if (!init_pos && dm_packed && (size_t)n + 1024 > (size_t)c->lds_bytes)
         return fail(c, TL_ERR_UNSUPPORTED, "nearest_neighbor: n=%u exceeds the LDS-resident visited flags", n);
     if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->work, total)) || (rc = ensure(c, c->out_cost, 4))) return rc;
@@ -284,7 +304,93 @@ static int lk_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed
     uint32_t delivered = 0;  // live: snapshots handed to the callback so far
     if (split_scan) HIPCHK(c, hipMemsetAsync(G.pairmin, 0xFF, (size_t)2 * n * 4, c->stream));
     uint64_t cnt[4] = {0, 0, 0, 0};
-    if (!multi_cu) {
+    if (lk_ils) {
+        // slices of kLkIlsSlice scans: between two of them the host reads the state words (finished, counters, snapshots so far) and,
+        // with a progress callback, hands the new best tours on — the reference's send_progress (lin_kernighan.rs:71,90) while it runs
+        G.ils_qcap = ils_qcap;
+        G.ils_slice = kLkIlsSlice;
+        if (ils_spec) {
+            G.ils_P = ils_P;
+            G.ils_dcand = (float *)(w + o_ils_dc);
+            G.ils_ep_tour = (uint32_t *)(w + o_ils_tour);
+            G.ils_ep_dist = (float *)(w + o_ils_dist);
+            G.ils_ep_cnt = (uint64_t *)(w + o_ils_cnt);
+        }
+        HIPCHK(c, hipMemsetAsync(G.state, 0, sizeof(LkState), c->stream));
+        LkState hs{};
+        int rc_loop = TL_OK;
+        // Phase 1 (sequential by nature): the first lk_pass — or, without speculation, the whole ILS — in ONE workgroup, slice by slice.
+        // Phase 2: the epochs.  A kick starts from the best tour and the RNG draws of its epoch number alone, so the epochs
+        // e, e + 1, ... are independent of each other as long as none of them is accepted: ils_P workgroups run ils_P consecutive
+        // epochs at once, k_lk_ils_commit takes them in order up to the first accepted one.  Same tours, counters and messages as
+        // the sequential loop (lin_kernighan.rs:75-97); what is thrown away is work on otherwise idle CUs.
+        auto drain = [&]() -> hipError_t {
+            hipError_t e = hipSuccess;
+            for (; live && delivered < hs.snaps; ++delivered) {
+                const uint32_t at = delivered % snap_cap;
+                float bd = 0.0f;
+                e = hipMemcpyAsync(live_tour.data(), G.snap + (size_t)at * n, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(&bd, G.snap_dist + at, 4, hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                if (e != hipSuccess) break;
+                c->in_callback = true;
+                live(live_user, live_tour.data(), n, bd);
+                c->in_callback = false;
+            }
+            return e;
+        };
+        auto ils_launch = [&]() { return deep ? tl_lk_deep::launch_lk_ils(G, c->stream) : launch_lk_ils(G, c->stream); };
+        auto ils_commit = [&]() { return deep ? tl_lk_deep::launch_lk_ils_commit(G, c->stream) : launch_lk_ils_commit(G, c->stream); };
+        G.ils_mode = ils_spec ? 1u : 0u;
+        for (;;) {
+            G.snap_delivered = delivered;
+            hipError_t e = ils_launch();
+            if (e == hipSuccess) e = hipMemcpyAsync(&hs, G.state, sizeof(hs), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e == hipSuccess) e = drain();
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                rc_loop = fail(c, TL_ERR_HIP, "tl_lk: %s", hipGetErrorString(e));
+                break;
+            }
+            if (hs.finished || (ils_spec && hs.stage == 1u)) break;
+        }
+        if (rc_loop == TL_OK && ils_spec && !hs.finished) {
+            G.ils_mode = 2u;
+            G.ils_slice = kLkIlsEpochScans;  // (mode 2: an epoch's scan budget)
+            for (;;) {
+                hipError_t e = hipSuccess;
+                for (int b = 0; b < kLkIlsBatches && e == hipSuccess; ++b) {  // (both kernels are no-ops once `finished` is set)
+                    e = ils_launch();
+                    if (e == hipSuccess) e = ils_commit();
+                }
+                if (e == hipSuccess) e = hipMemcpyAsync(&hs, G.state, sizeof(hs), hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                if (e == hipSuccess) e = drain();
+                if (e != hipSuccess) {
+                    (void)hipGetLastError();
+                    rc_loop = fail(c, TL_ERR_HIP, "tl_lk: %s", hipGetErrorString(e));
+                    break;
+                }
+                if (hs.finished) break;
+            }
+        }
+        if (rc_loop != TL_OK) return rc_loop;
+        if (hs.finished == 2u)
+            return fail(c, TL_ERR_NO_CONVERGE, "tl_lk: an lk_pass does not terminate (the reference's loop cycles on this input: chains of rounded f32 gain that lead back to the same tour)");
+        cnt[0] = hs.scans;
+        cnt[1] = hs.searches;
+        cnt[2] = hs.moves;
+        cnt[3] = hs.exchanged;
+        if (snap_pos && !live) {
+            if (snap_len) *snap_len = hs.snaps;
+            const uint32_t have = hs.snaps < snap_cap ? hs.snaps : snap_cap;
+            if (have) {
+                HIPCHK(c, hipMemcpyAsync(snap_pos, G.snap, (size_t)have * n * 4, hipMemcpyDeviceToHost, c->stream));
+                if (snap_dist) HIPCHK(c, hipMemcpyAsync(snap_dist, G.snap_dist, (size_t)have * 4, hipMemcpyDeviceToHost, c->stream));
+            }
+        }
+    } else if (!multi_cu) {
         HIPCHK(c, deep ? tl_lk_deep::launch_lk_solve(G, c->stream, lk_small, small_nt) : launch_lk_solve(G, c->stream, lk_small, small_nt));
     } else {
         HIPCHK(c, deep ? tl_lk_deep::launch_lk_begin(G, c->stream) : launch_lk_begin(G, c->stream));
@@ -376,11 +482,11 @@ static int lk_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed
     c->ev_valid = true;
     float cost = 0.f;
     HIPCHK(c, hipMemcpyAsync(out_pos, G.best, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    if (!multi_cu) HIPCHK(c, hipMemcpyAsync(cnt, G.counters, 32, hipMemcpyDeviceToHost, c->stream));
+    if (!multi_cu && !lk_ils) HIPCHK(c, hipMemcpyAsync(cnt, G.counters, 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(&cost, c->out_cost.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (out_cost) *out_cost = cost;
-    if (snap_pos && !multi_cu) {
+    if (snap_pos && !multi_cu && !lk_ils) {
         // TL_FLAG_LK_ONE_WORKGROUP: the reference's last PathUpdate only — the final best tour with its best_dist, the Euclidean
         // tour_distance of lin_kernighan.rs:118-122 (edges in tour order, the closing edge last; f32, as KDPoint::distance)
         float bd = 0.0f;

@@ -241,6 +241,16 @@ struct LkArgs {
     uint32_t snap_cap;
     uint32_t snap_ring;      // snap is a ring of snap_cap slots (tl_lk_live) instead of a list of the first snap_cap
     uint32_t persist_blocks; // fused three-level scan: workgroups of the persistent grid (k_lk_scan_persist); 0 = one workgroup per pair
+    // k_lk_ils (the LDS-resident single-workgroup ILS of a small instance): records per level queue (lk_ils_qcap), scans per launch,
+    // and how many snapshots of the ring the host has taken so far (a slice ends when the ring is full of undelivered ones)
+    uint32_t ils_qcap, ils_slice, snap_delivered;
+    uint32_t ils_threads;    // 0: by n (256 up to n = 200, else 1024); tuning: 256 / 512 / 1024
+    // speculative epochs (k_lk_ils mode 2 + k_lk_ils_commit): ils_P workgroups = ils_P consecutive epochs kicked from the same best tour
+    uint32_t ils_mode, ils_P;
+    float *ils_dcand;        // [n][k] the candidates' distances (written by the first-pass launch, read by the epoch launches)
+    uint32_t *ils_ep_tour;   // [ils_P][n] the tour each epoch ends on
+    float *ils_ep_dist;      // [ils_P] its tour_distance
+    uint64_t *ils_ep_cnt;    // [ils_P][4] scans, searches, moves, exchanged edges of the epoch
 };
 // form: 0 = default (16 lanes per city up to n = 32 K, 4 beyond), 4 = four lanes per city, 1 = one lane per city
 hipError_t launch_knn(const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, hipStream_t s, int form = 0);
@@ -251,6 +261,10 @@ hipError_t launch_lk_solve(const LkArgs &G, hipStream_t s, bool small = false, i
 size_t lk_small_lds_bytes(uint32_t n, uint32_t k);
 hipError_t launch_lk_begin(const LkArgs &G, hipStream_t s);
 hipError_t launch_lk_round(const LkArgs &G, hipStream_t s, uint32_t round);
+uint32_t lk_ils_qcap(uint32_t n, uint32_t k, uint32_t max_depth, size_t lds_budget);  // > 0: k_lk_ils applies (records per level queue)
+size_t lk_ils_lds_bytes(uint32_t n, uint32_t k, uint32_t max_depth, uint32_t qcap);   // LDS of one k_lk_ils workgroup
+hipError_t launch_lk_ils(const LkArgs &G, hipStream_t s);                             // mode 0 / 1: one slice of G.ils_slice scans; mode 2: ils_P epochs
+hipError_t launch_lk_ils_commit(const LkArgs &G, hipStream_t s);                      // the verdict over a batch of epochs
 size_t lk_chain_slot_words();
 size_t lk_sub_slot_words();
 uint32_t lk_max_depth();  // the build's compile-time recursion bound (6)
@@ -262,6 +276,10 @@ hipError_t launch_lk_solve(const tl::LkArgs &G, hipStream_t s, bool small = fals
 size_t lk_small_lds_bytes(uint32_t n, uint32_t k);
 hipError_t launch_lk_begin(const tl::LkArgs &G, hipStream_t s);
 hipError_t launch_lk_round(const tl::LkArgs &G, hipStream_t s, uint32_t round);
+uint32_t lk_ils_qcap(uint32_t n, uint32_t k, uint32_t max_depth, size_t lds_budget);
+size_t lk_ils_lds_bytes(uint32_t n, uint32_t k, uint32_t max_depth, uint32_t qcap);
+hipError_t launch_lk_ils(const tl::LkArgs &G, hipStream_t s);
+hipError_t launch_lk_ils_commit(const tl::LkArgs &G, hipStream_t s);
 size_t lk_chain_slot_words();
 size_t lk_sub_slot_words();
 uint32_t lk_max_depth();
