@@ -90,8 +90,9 @@ typedef enum tl_mode {
 #define TL_FLAG_2OPT_NO_NL (1u << 18)      /* LDS 2-opt: never read neighbour lists — every pruned row walks its tiles (default: rows of the
                                               late sweeps (once a sweep has applied fewer than n / 40 moves) of an instance with n >= 400 read the lists, csrc/two_opt_nl.hip)               */
 #define TL_FLAG_2OPT_NL_ALWAYS (1u << 19)  /* LDS 2-opt: neighbour-list rows at every n they fit and from the second sweep on            */
-#define TL_FLAG_LK_CHIP_WIDE (1u << 20)    /* tl_lk: chip-wide scans at every n (default: an instance whose search state fits one CU's LDS, up to
-                                              n = 2000, runs its whole ILS as ONE persistent workgroup: k_lk_ils, csrc/lk.hip)                  */
+#define TL_FLAG_LK_CHIP_WIDE (1u << 20)    /* tl_lk: chip-wide scans at every n (default: an instance whose search state fits one CU's LDS runs its
+                                              lk_pass in ONE workgroup with all state in LDS, k_lk_ils in csrc/lk.hip — up to n = 700, up to
+                                              n = 2000 with epochs and platoo_epochs >= 64)                                                      */
 #define TL_FLAG_LK_ILS_LDS (1u << 21)      /* tl_lk: that single-workgroup LDS form at every n it fits                                          */
 #define TL_FLAG_LK_NO_SPECULATION (1u << 22) /* tl_lk, LDS form: the epochs one after the other in one workgroup (default: one workgroup per epoch,
                                               as many consecutive epochs at once as the chip holds, taken in order up to the first accepted one) */

@@ -36,6 +36,10 @@ using namespace tl;  // (a no-op for the default namespace)
 namespace {
 
 constexpr float kLkEps = 1e-6f;  // lin_kernighan.rs:252
+// moves after which an lk_pass is taken to be cycling (the reference's loop does not end on such an input: lin_kernighan.rs:468-478
+// goes on while find_lk_move returns a chain, and a chain's "gain" is a sum of rounded f32 terms).  A pass from a random tour takes
+// about n moves.
+__host__ __device__ __forceinline__ uint64_t lk_pass_cap(uint32_t n) { return 64ull * n + 4096ull; }
 constexpr int kLkNT = 1024;
 #ifndef TL_LK_WINDOW_MARGIN
 #define TL_LK_WINDOW_MARGIN 2048
@@ -1155,6 +1159,7 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
                 S->searches += (uint64_t)key + 1u;
                 S->moves += 1;
                 S->exchanged += clen / 2u;
+                if (++S->pass_moves > lk_pass_cap(n)) S->finished = 2u;  // a cycling lk_pass (see lk_pass_cap): the host reports it
                 S->key2[G.parity ^ 1u] = 0xFFFFFFFFu;  // the next scan's key
                 const uint32_t w = key + kLkWindowMargin;
                 S->window = w < 2u * n ? w : 2u * n;
@@ -1188,6 +1193,7 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
             S->searches += (uint64_t)key + 1u;
             S->moves += 1;
             S->exchanged += clen / 2u;
+            if (++S->pass_moves > lk_pass_cap(n)) S->finished = 2u;
             S->key = 0xFFFFFFFFu;
             // find_lk_move restarts at pair 0 after every move (:468-478) and keeps the LOWEST pair with a valid chain, so a
             // scan of a prefix that contains a hit is a complete scan.  The pairs before this hit had no valid chain a moment
@@ -1213,6 +1219,7 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
     if (tid == 0) {
         S->scans += 1;
         S->searches += 2ull * n;
+        S->pass_moves = 0u;
     }
     bool kick = false;
     if (S->stage == 0) {                       // initial pass done (:61-70)
@@ -1791,7 +1798,8 @@ __global__ __launch_bounds__(NT) void k_lk_ils(LkArgs G)
         // (slot 0) is run again with a larger budget (S->window counts the doublings).
         const uint32_t e = S->epoch + slot;
         const uint32_t lvl = S->window < 6u ? S->window : 6u;
-        const uint64_t ep_budget = (uint64_t)G.ils_slice << (3u * lvl);
+        const uint64_t cap = lk_pass_cap(n);
+        const uint64_t ep_budget = ((uint64_t)G.ils_slice << (3u * lvl)) < cap ? ((uint64_t)G.ils_slice << (3u * lvl)) : cap;
         scans = searches = moves = exchanged = 0ull;
         kick_from_best(3ull * e);
         bool unfinished = false;
@@ -1823,7 +1831,7 @@ __global__ __launch_bounds__(NT) void k_lk_ils(LkArgs G)
     rebuild();
     uint32_t budget = G.ils_slice;
     bool fin = S->finished != 0u;
-    uint64_t pass_scans = 0;
+    uint64_t pass_scans = S->pass_moves;  // (a pass may span slices)
     bool cycling = false;
     while (!fin && budget != 0u) {
         --budget;
@@ -1832,7 +1840,7 @@ __global__ __launch_bounds__(NT) void k_lk_ils(LkArgs G)
         if (found) {
             apply_move();
             TL_ISTAMP(5);
-            if (++pass_scans > (1ull << 31)) {  // (per launch: a pass of 2^31 moves is a cycle — see the epochs' budget)
+            if (++pass_scans > lk_pass_cap(n)) {  // a pass longer than this is a cycle — see the epochs' budget
                 cycling = true;
                 break;
             }
@@ -1896,6 +1904,7 @@ __global__ __launch_bounds__(NT) void k_lk_ils(LkArgs G)
     }
     if (tid == 0) {
         S->applied = 1u;
+        S->pass_moves = (uint32_t)pass_scans;
         S->finished = fin ? 1u : (cycling ? 2u : 0u);
         S->stage = stage;
         S->epoch = epoch;
@@ -1934,9 +1943,10 @@ __global__ __launch_bounds__(256) void k_lk_ils_commit(LkArgs G)
         for (uint32_t j = 0; j < P; ++j) {
             const uint64_t *cn = G.ils_ep_cnt + (size_t)j * 4;
             if (cn[0] == ~0ull) {  // out of its scan budget: the verdict stops in front of it; if it is the next epoch it runs again, longer
-                if (j == 0u) {
+                if (j == 0u) {  // the next epoch: again with 8 x the budget — or, if that was lk_pass_cap already, it does not terminate
+                    const uint32_t lvl = window < 6u ? window : 6u;
+                    if (((uint64_t)G.ils_slice << (3u * lvl)) >= lk_pass_cap(n)) S->key = 0xDEAD0001u;
                     ++window;
-                    if (window > 6u) S->key = 0xDEAD0001u;  // 8192 << 18 scans in one lk_pass: it does not terminate (nor does the reference's)
                 }
                 break;
             }
@@ -2057,6 +2067,7 @@ __global__ __launch_bounds__(kLkNT) void k_lk_begin(LkArgs G)
         S->scans = S->searches = S->moves = S->exchanged = 0;
         S->window = kLkWindowFirst < 2u * n ? kLkWindowFirst : 2u * n;
         S->applied = 0u;
+        S->pass_moves = 0u;
     }
 }
 

@@ -8,9 +8,10 @@ using namespace tlapi;
 // lin_kernighan cut-over (measured, NOTEBOOK.md §4.6): the LDS-resident single workgroup never wins -> 0
 static constexpr uint32_t kLkSmallMaxN = 0, kLkSmallWave64MaxN = 0, kLkSmall256MaxN = 0;
 #ifndef TL_LK_ILS_MAX_N
-#define TL_LK_ILS_MAX_N 2000u  // largest n the LDS-resident ILS (k_lk_ils) takes by default
+#define TL_LK_ILS_MAX_N 700u  // largest n the LDS-resident ILS (k_lk_ils) takes by default ...
 #endif
 static constexpr uint32_t kLkIlsMaxN = TL_LK_ILS_MAX_N;
+static constexpr uint32_t kLkIlsMaxNLongPlateau = 2000u;  // ... and with a plateau of >= 64 epochs (the speculative epochs fill the chip)
 static constexpr uint32_t kLkIlsSlice = 8192u;  // scans per launch of k_lk_ils (tens of milliseconds)
 static constexpr uint32_t kLkIlsEpochScans = 512u;  // scans a speculative epoch may take before it files "unfinished" (x 8 per retry as the next epoch)
 static constexpr int kLkIlsBatches = 16;         // batches of speculative epochs per poll of the state (at most one progress message per batch: the ring holds 64)
@@ -204,8 +205,12 @@ static int lk_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed
     // from which the chip-wide scans are faster (kLkIlsMaxN, measured: scripts/timing_lk_ils.py); TL_FLAG_LK_ILS_LDS: wherever it
     // fits; TL_FLAG_LK_CHIP_WIDE: never.
     const uint32_t ils_qcap = deep ? tl_lk_deep::lk_ils_qcap(n, k_small, o.max_depth, (size_t)c->lds_bytes) : lk_ils_qcap(n, k_small, o.max_depth, (size_t)c->lds_bytes);
+    // (the cut-over: one workgroup's scan loses to the chip-wide one from n ~ 800 — scripts/timing_lk_ils.py: n = 400 6.6 against 14.2 ms,
+    //  n = 1000 27.5 against 21.1 with the library's default 100 epochs / plateau 10 — unless the plateau is long enough for the
+    //  speculative epochs to fill the chip: the CLI's 10 000 / 500 runs 256-512 epochs at once)
+    const bool ils_size = n <= kLkIlsMaxN || (n <= kLkIlsMaxNLongPlateau && o.platoo_epochs >= 64u && o.epochs >= 64u);
     const bool lk_ils = ils_qcap != 0u && !lk_small && !((c->flags | tf) & (variant_flags | TL_FLAG_LK_CHIP_WIDE)) &&
-                        (n <= kLkIlsMaxN || (c->flags & TL_FLAG_LK_ILS_LDS));
+                        (ils_size || (c->flags & TL_FLAG_LK_ILS_LDS));
     const bool multi_cu = !(c->flags & TL_FLAG_LK_ONE_WORKGROUP) && !lk_small && !lk_ils;
     const size_t slot_words = deep ? tl_lk_deep::lk_chain_slot_words() : lk_chain_slot_words();
     const size_t sub_bytes = (deep ? tl_lk_deep::lk_sub_slot_words() : lk_sub_slot_words()) * 4;  // 64 at depth <= 6
@@ -463,6 +468,8 @@ static int lk_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed
         if (gexec) (void)hipGraphExecDestroy(gexec);
         if (graph) (void)hipGraphDestroy(graph);
         if (rc_loop != TL_OK) return rc_loop;
+        if (hs.finished == 2u)
+            return fail(c, TL_ERR_NO_CONVERGE, "tl_lk: an lk_pass does not terminate (the reference's loop cycles on this input: chains of rounded f32 gain that lead back to the same tour)");
         cnt[0] = hs.scans;
         cnt[1] = hs.searches;
         cnt[2] = hs.moves;

@@ -210,6 +210,7 @@ struct LkState {             // device-side state machine of the multi-CU LK var
     uint32_t key2[2];        // chip-wide step: the scan's key, double-buffered by round parity
     uint32_t flip, flip_next;  // chip-wide step: which tour buffer is current (0: tour, 1: alt); handed over by the next scan
     uint32_t snaps;          // best tours recorded so far (LkArgs::snap; counted on beyond snap_cap)
+    uint32_t pass_moves;     // moves of the lk_pass in progress (finished = 2 beyond lk_pass_cap: the pass is cycling)
 };
 struct LkArgs {
     const float2 *xy;
