@@ -1003,6 +1003,46 @@ def main():
                 wc = time.perf_counter() - t0c
                 extras["lin_kernighan_n13509_20_epochs"]["cpu_baseline"] = {"value": st_lk["moves"] / wc, "unit": "moves/s", "cores": 1, "kind": "port",
                     "sample": f"one ILS epoch at n = {n13}: double-bridge kick of the GPU run's final tour, then the oracle's lk_pass to the next local optimum ({st_lk['moves']} moves, {st_lk['sweeps']} find_lk_move scans) on one core; wall {wc:.1f} s"}
+            # LK on the instances the reference publishes wall times for (bench/baseline-solvers.tsv:17-31, docs/benchmarks.md:47), with the CLI's
+            # defaults (mod.rs:596-613,1321-1325: epochs 10 000, platoo 500, n_nearest 3, depth 5): the LDS form with speculative epochs
+            # (default at these sizes) beside the chip-wide scans, the oracle on one core and the reference's own published range
+            pub = {}
+            published_s = {"berlin52": [0.10, 0.22], "a280": [1.1, 3.1], "att532": [14.0, 37.0]}
+            for nm in ("berlin52", "a280", "att532"):
+                f = os.path.join(ROOT, "tests", "golden", "tsplib", nm + ".tsp")
+                xyp = np.ascontiguousarray(TA.tsplib.read_from_file(f).xy, dtype=np.float32)
+                pp = TA.TspProblem(np.arange(len(xyp)), xyp)
+                lo = TA.LKOptions(TA.HeuristicOptions(epochs=10000, platoo_epochs=500, n_nearest=3), 5)
+                row = {"n": int(len(xyp)), "reference_published_wall_s": published_s[nm]}
+                for label, flags in (("lds_speculative_epochs", 0), ("chip_wide_scans", TA.TL_FLAG_LK_CHIP_WIDE)):
+                    with TA.Context(local, flags) as cl:
+                        best = None
+                        for _ in range(2):
+                            t0l = time.perf_counter()
+                            sl = TA.lin_kernighan.solve(pp, lo, ctx=cl, seed=1)
+                            wl = (time.perf_counter() - t0l) * 1e3
+                            if best is None or sl.stats["kernel_ms"] < best[0]:
+                                best = (sl.stats["kernel_ms"], wl, sl)
+                    k_ms_l, w_ms_l, sl = best
+                    row[label] = {"kernel_ms": k_ms_l, "wall_ms": w_ms_l, "rounds": sl.stats["sweeps"], "moves": sl.stats["moves"],
+                                  "us_per_round": k_ms_l * 1e3 / max(sl.stats["sweeps"], 1), "cost": float(sl.total)}
+                    row.setdefault("_route", list(sl.route()))
+                    assert list(sl.route()) == row["_route"], f"LK {nm}: the two forms differ"
+                if not a.no_cpu_baseline:
+                    import _oracle as O
+                    t0c = time.perf_counter()
+                    _rc, orr, oc, ost, _sn = O.lin_kernighan_trace(xyp, epochs=10000, platoo_epochs=500, n_nearest=3, max_depth=5, seed=1, cap=2048)
+                    wo = (time.perf_counter() - t0c) * 1e3
+                    assert orr.tolist() == row["_route"] and ost["sweeps"] == row["lds_speculative_epochs"]["rounds"], f"LK {nm}: GPU != oracle"
+                    row["cpu_baseline"] = {"value": wo, "unit": "ms", "cores": 1, "kind": "port",
+                                           "sample": "the whole run (same options, same seeded kicks) by the oracle on one core: same tour and round count (asserted)"}
+                    row["speedup_vs_one_core"] = wo / row["lds_speculative_epochs"]["wall_ms"]
+                del row["_route"]
+                pub[nm] = row
+            extras["lk_published_instances"] = dict(pub, note="tl_lk with the CLI's defaults incl. NN seed and candidate lists; kernel_ms = device time, wall_ms = the call; "
+                                                              "lds_speculative_epochs: k_lk_ils, one workgroup per epoch, a batch of consecutive epochs at once, taken in order up to the "
+                                                              "first accepted one (same tours, counters and messages as the sequential loop); reference_published_wall_s: the reference's "
+                                                              "own CLI on its laptop (bench/baseline-solvers.tsv:17-31)")
         except Exception as exc:
             extras["error"] = repr(exc)
         if not a.no_end_to_end:

@@ -369,7 +369,9 @@ def test_live_callback_cannot_re_enter_its_own_context(ctx):
     # the callback runs on the owning thread, so the owner guard used to let it back in — onto the stream and workspace of
     # the running search.  Now every entry into THIS context from inside the callback is TL_ERR_BUSY; another context is free; and the
     # search's result is untouched.
+    import ctypes as C
     import teeline_amd as TA
+    from teeline_amd import _capi
     n = 400
     xy = O.synth_xy(n, seed=31)
     seen = []
