@@ -514,6 +514,10 @@ __device__ __forceinline__ void late_phase(const TwoOptBatchArgs &A, const PT &P
         }
         // ---- in front of the scan, by every wave alike: stale tile boxes (each wave its share), the city -> position table and the
         // long list (rebuilt at a sweep's start, brought up to date after a move), one barrier (a rebuild: two)
+        if (!nl_ok) {  // once per sweep every tile's bound afresh: a move inside one tile only ever RAISES that tile's msq (fold), so without
+            dirty_lo = 0u;  // this the L0 bound of the rows that still walk tiles would loosen for the rest of the descent
+            dirty_hi = ntile - 1u;
+        }
         const bool dirty = dirty_lo <= dirty_hi;
         if (tid == 0) ctl->late_cur = i0;
         {
@@ -924,7 +928,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
         for (;;) {
             if (need_desc) {
                 ++n_desc;
-                bool done = false;
+                bool done = false, new_sweep = false;
                 if (c.i0 >= nrows) {  // sweep finished (two_opt.rs:26-28)
                     if (!acct.improved) {
                         done = true;
@@ -948,6 +952,11 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                         sweep_moves0 = acct.moves;
                         c.i0 = 0;
                         c.j0 = 2;
+                        if (NL) {  // folded tile bounds (step_boundary) are rebuilt with the next stale ones; the workers do the same (bit 3)
+                            c.dirty_lo = 0u;
+                            c.dirty_hi = ntile - 1u;
+                            new_sweep = true;
+                        }
                         if (acct.log) {  // a new sweep begins here (the same row can hold moves of two consecutive sweeps back to back)
                             if (lane == 0 && acct.log_n < acct.log_cap) acct.log[acct.log_n] = 0xFFFFFFFFu;
                             acct.log_n += 1u;
@@ -957,7 +966,7 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 // block shape: dense (moves every few rows: one row, every tile) or pruned (up to kRMax rows, L0)
                 c.pruned = PRUNE && !done && fmaxf(acct.gap_est, acct.since) > TL_DENSE_ROWS * (float)(n - 2u - c.i0);
                 if (lane == 0) {
-                    *reinterpret_cast<uint2 *>(ctl->desc) = make_uint2((done ? OP_EXIT : go_late ? OP_LATE : OP_GO) | (c.pruned ? 4u : 0u), c.i0 | (c.j0 << 16));
+                    *reinterpret_cast<uint2 *>(ctl->desc) = make_uint2((done ? OP_EXIT : go_late ? OP_LATE : OP_GO) | (c.pruned ? 4u : 0u) | (new_sweep ? 8u : 0u), c.i0 | (c.j0 << 16));
                     if (NL) ctl->desc[2] = sweeps;
                 }
                 TL_SYNC();  // B0
@@ -1129,6 +1138,10 @@ __global__ __launch_bounds__(NT, 4) void k_two_opt_ref_lds(TwoOptBatchArgs A)
                 c.i0 = w1 & 0xFFFFu;
                 c.j0 = w1 >> 16;
                 reload = true;
+                if (NL && (w0 & 8u)) {  // a sweep begins: folded tile bounds (step_boundary) are rebuilt with the next stale ones
+                    c.dirty_lo = 0u;
+                    c.dirty_hi = ntile - 1u;
+                }
             }
             uint32_t *keyslot = &ctl->kr[c.slot].x;
             uint32_t my_hits = 0;
