@@ -94,6 +94,9 @@ typedef enum tl_mode {
                                               lk_pass in ONE workgroup with all state in LDS, k_lk_ils in csrc/lk.hip — up to n = 700, up to
                                               n = 2000 with epochs and platoo_epochs >= 64)                                                      */
 #define TL_FLAG_LK_ILS_LDS (1u << 21)      /* tl_lk: that single-workgroup LDS form at every n it fits                                          */
+#define TL_FLAG_LK_CLASSIC_VIEW (1u << 23)  /* tl_lk, chip-wide scans at n >= 1500: the chain search reads cand -> xy -> next -> xy (default: the
+                                              packed view — candidates with their distances, successor records with the successor's point and the
+                                              tour edge's length: two dependent look-ups and one square root per branch instead of four and three) */
 #define TL_FLAG_LK_NO_SPECULATION (1u << 22) /* tl_lk, LDS form: the epochs one after the other in one workgroup (default: one workgroup per epoch,
                                               as many consecutive epochs at once as the chip holds, taken in order up to the first accepted one) */
 /* TUNING BUILDS ONLY (libteeline_gpu_tune.so, -DTL_TUNE: `python -m teeline_amd.build --tune`).  Forms that were measured and

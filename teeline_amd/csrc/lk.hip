@@ -59,6 +59,58 @@ struct LkViewT {
 };
 using LkView = LkViewT<uint32_t>;
 
+// The packed view (round 5): what a branch of the chain search needs of a candidate and of a tour successor sits
+// NEXT TO the index it follows from — candd[t][q] = (candidate id, d(t, candidate)), nx[c] = (next[c], x, y of next[c], d(c, next[c])) —
+// so that a branch costs two dependent look-ups (candd -> nx) instead of four (cand -> xy -> next -> xy) and one square root (the
+// closing edge) instead of three.  The two distances are the same f32 values the classic view computes (same operands, same order).
+struct LkViewPk {
+    const uint2 *candd;   // [n][k]: candidate id, bits of d(t, candidate)
+    const float4 *nx;     // [n]: bits of next[c], next[c]'s x, y, d(c, next[c]) of the CURRENT tour (kept by the step kernel)
+    uint32_t k;
+    uint32_t max_depth;
+};
+// candidate q of t_open: its id, d(t_open, id), and next[t_open] (for is_tour_edge)
+template <typename NextT>
+__device__ __forceinline__ void lk_probe(const LkViewT<NextT> &V, uint32_t t_open, float2 p_open, uint32_t q, uint32_t &t_next, float2 &p_next, float &d1)
+{
+    t_next = V.cand[(size_t)t_open * V.k + q];
+    p_next = V.xy[t_next];
+    d1 = dist(p_open, p_next);
+}
+__device__ __forceinline__ void lk_probe(const LkViewPk &V, uint32_t t_open, float2, uint32_t q, uint32_t &t_next, float2 &p_next, float &d1)
+{
+    const uint2 c = V.candd[(size_t)t_open * V.k + q];
+    t_next = c.x;
+    p_next = make_float2(0.0f, 0.0f);  // (not needed: both of its distances come ready)
+    d1 = __uint_as_float(c.y);
+}
+template <typename NextT>
+__device__ __forceinline__ uint32_t lk_next_of(const LkViewT<NextT> &V, uint32_t c) { return (uint32_t)V.next[c]; }
+__device__ __forceinline__ uint32_t lk_next_of(const LkViewPk &V, uint32_t c) { return __float_as_uint(V.nx[c].x); }
+// regime A: t_break = next[t_next], its point, d(t_next, t_break)
+template <typename NextT>
+__device__ __forceinline__ uint32_t lk_break_id(const LkViewT<NextT> &V, uint32_t t_next, float4 &rec)
+{
+    (void)rec;
+    return (uint32_t)V.next[t_next];
+}
+__device__ __forceinline__ uint32_t lk_break_id(const LkViewPk &V, uint32_t t_next, float4 &rec)
+{
+    rec = V.nx[t_next];
+    return __float_as_uint(rec.x);
+}
+template <typename NextT>
+__device__ __forceinline__ void lk_break_pt(const LkViewT<NextT> &V, uint32_t t_break, float2 p_next, const float4 &, float2 &p_break, float &d2)
+{
+    p_break = V.xy[t_break];
+    d2 = dist(p_next, p_break);
+}
+__device__ __forceinline__ void lk_break_pt(const LkViewPk &, uint32_t, float2, const float4 &rec, float2 &p_break, float &d2)
+{
+    p_break = make_float2(rec.y, rec.z);
+    d2 = rec.w;
+}
+
 __host__ __device__ __forceinline__ uint32_t lk_subs(const LkArgs &G)  // sub-searches per (t1, orientation) pair
 {
     return G.k * (G.k + 1u) * (G.split_levels == 3u ? G.k + 1u : 1u);
@@ -87,8 +139,8 @@ __device__ __forceinline__ bool in_chain(const uint32_t (&chain)[kLkMaxChain], u
 }
 
 // lin_kernighan.rs:265-340 find_lk_chain; DEPTH is the reference's `depth`, chain holds 2*DEPTH+2 cities on entry.
-template <int DEPTH, typename NextT>
-__device__ bool lk_chain(const LkViewT<NextT> &V, uint32_t (&chain)[kLkMaxChain], uint32_t &clen, const float2 p1,
+template <int DEPTH, typename VT>
+__device__ bool lk_chain(const VT &V, uint32_t (&chain)[kLkMaxChain], uint32_t &clen, const float2 p1,
                          const uint32_t t_open, const float2 p_open, const float gain)
 {
     if (DEPTH >= 1) {
@@ -101,19 +153,22 @@ __device__ bool lk_chain(const LkViewT<NextT> &V, uint32_t (&chain)[kLkMaxChain]
     if ((uint32_t)DEPTH >= V.max_depth) return false;  // :286-288
     if constexpr (DEPTH < kLkMaxDepth) {
         for (uint32_t q = 0; q < V.k; ++q) {
-            const uint32_t t_next = V.cand[(size_t)t_open * V.k + q];
-            const float2 p_next = V.xy[t_next];
-            const float g1 = gain - dist(p_open, p_next);
+            uint32_t t_next;
+            float2 p_next, p_break;
+            float d1, d2;
+            float4 rec;
+            lk_probe(V, t_open, p_open, q, t_next, p_next, d1);
+            const float g1 = gain - d1;
             if (g1 <= kLkEps) break;                                   // :292-295 candidates are sorted
             if (in_chain<2 * DEPTH + 2>(chain, t_next)) continue;      // used[t_next]
-            const uint32_t t_break = V.next[t_next];                   // :305 regime A
-            if ((uint32_t)V.next[t_open] == t_next || t_break == t_open) continue;  // is_tour_edge: prev[a]==b <=> next[b]==a
+            const uint32_t t_break = lk_break_id(V, t_next, rec);      // :305 regime A
+            if (lk_next_of(V, t_open) == t_next || t_break == t_open) continue;  // is_tour_edge: prev[a]==b <=> next[b]==a
             if (in_chain<2 * DEPTH + 2>(chain, t_break)) continue;     // used[t_break]
-            const float2 p_break = V.xy[t_break];
-            const float g2 = g1 + dist(p_next, p_break);
+            lk_break_pt(V, t_break, p_next, rec, p_break, d2);
+            const float g2 = g1 + d2;
             chain[2 * DEPTH + 2] = t_next;
             chain[2 * DEPTH + 3] = t_break;
-            if (lk_chain<DEPTH + 1, NextT>(V, chain, clen, p1, t_break, p_break, g2)) return true;
+            if (lk_chain<DEPTH + 1, VT>(V, chain, clen, p1, t_break, p_break, g2)) return true;
         }
     }
     return false;
@@ -377,7 +432,7 @@ __global__ __launch_bounds__(NT) void k_lk_solve(LkArgs G)
                     chain[0] = t1;
                     chain[1] = t2;
                     const float g0 = t1 == t2 ? 0.0f : dist(p1, p2);
-                    if (lk_chain<0, uint32_t>(V, chain, clen, p1, t2, p2, g0)) ok = chain_valid(chain, clen, tour, pos, n);
+                    if (lk_chain<0, LkView>(V, chain, clen, p1, t2, p2, g0)) ok = chain_valid(chain, clen, tour, pos, n);
                 }
                 if (ok) atomicMin(&s_key, idx);
                 TL_SYNC();
@@ -545,10 +600,10 @@ __global__ __launch_bounds__(256) void k_lk_scan(LkArgs G)
     bool found;
     if (LDS) {
         LkViewT<uint16_t> V{xyL, G.cand, nextL, G.k, G.max_depth};
-        found = lk_chain<0, uint16_t>(V, chain, clen, p1, t2, p2, g0);
+        found = lk_chain<0, LkViewT<uint16_t>>(V, chain, clen, p1, t2, p2, g0);
     } else {
         LkView V{G.xy, G.cand, G.next, G.k, G.max_depth};
-        found = lk_chain<0, uint32_t>(V, chain, clen, p1, t2, p2, g0);
+        found = lk_chain<0, LkView>(V, chain, clen, p1, t2, p2, g0);
     }
     if (found && chain_valid(chain, clen, G.tour, G.pos, n)) {
         uint32_t *slot = G.chains + (size_t)idx * kLkSlot;
@@ -566,8 +621,8 @@ __global__ __launch_bounds__(256) void k_lk_scan(LkArgs G)
 // chain.  The reference keeps the FIRST chain found in DFS order and drops the pair if that one is invalid (:373-381),
 // hence two steps: k_lk_scan_sub records the minimum (q1, s) with a chain per pair, k_lk_scan_pick re-derives that
 // chain, checks it, and posts the pair.
-template <typename NextT>
-__device__ bool lk_subsearch(const LkViewT<NextT> &V, uint32_t (&chain)[kLkMaxChain], uint32_t &clen, const float2 p1,
+template <typename VT>
+__device__ bool lk_subsearch(const VT &V, uint32_t (&chain)[kLkMaxChain], uint32_t &clen, const float2 p1,
                              const uint32_t t1, const uint32_t t2, const float2 p2, const float g0, const uint32_t q1, const uint32_t s)
 {
     // depth 0 (find_lk_chain :290-337 with depth = 0)
@@ -606,28 +661,31 @@ __device__ bool lk_subsearch(const LkViewT<NextT> &V, uint32_t (&chain)[kLkMaxCh
     const float g4 = g3 + dist(p5, p6);
     chain[4] = t5;
     chain[5] = t6;
-    return lk_chain<2, NextT>(V, chain, clen, p1, t6, p6, g4);
+    return lk_chain<2, VT>(V, chain, clen, p1, t6, p6, g4);
 }
 
 // One explicit branch of find_lk_chain's loop (:290-337) at depth D: candidate q of t_open.  On success the chain grows by
 // (t_next, t_break) and (t_open, p_open, gain) move on; a rejected branch returns false (for the `break` at g1 <= EPS see
 // the exactness note above: it is implied by the later branches' own tests).
-template <int D, typename NextT>
-__device__ __forceinline__ bool lk_branch(const LkViewT<NextT> &V, uint32_t (&chain)[kLkMaxChain], uint32_t &t_open, float2 &p_open,
+template <int D, typename VT>
+__device__ __forceinline__ bool lk_branch(const VT &V, uint32_t (&chain)[kLkMaxChain], uint32_t &t_open, float2 &p_open,
                                           float &gain, const uint32_t q)
 {
-    const uint32_t t_next = V.cand[(size_t)t_open * V.k + q];
-    const float2 p_next = V.xy[t_next];
-    const float g1 = gain - dist(p_open, p_next);
+    uint32_t t_next;
+    float2 p_next, p_break;
+    float d1, d2;
+    float4 rec;
+    lk_probe(V, t_open, p_open, q, t_next, p_next, d1);
+    const float g1 = gain - d1;
     if (g1 <= kLkEps) return false;
     if (in_chain<2 * D + 2>(chain, t_next)) return false;
-    const uint32_t t_break = V.next[t_next];
-    if ((uint32_t)V.next[t_open] == t_next || t_break == t_open) return false;
+    const uint32_t t_break = lk_break_id(V, t_next, rec);
+    if (lk_next_of(V, t_open) == t_next || t_break == t_open) return false;
     if (in_chain<2 * D + 2>(chain, t_break)) return false;
-    const float2 p_break = V.xy[t_break];
+    lk_break_pt(V, t_break, p_next, rec, p_break, d2);
     chain[2 * D + 2] = t_next;
     chain[2 * D + 3] = t_break;
-    gain = g1 + dist(p_next, p_break);
+    gain = g1 + d2;
     t_open = t_break;
     p_open = p_break;
     return true;
@@ -637,15 +695,15 @@ __device__ __forceinline__ bool lk_branch(const LkViewT<NextT> &V, uint32_t (&ch
 // branch s1-1; at depth 2 the closing test (s2 = 0) or branch s2-1, below which the walk is sequential (lk_chain<3>: at most
 // k^2 nodes instead of k^3).  Lexicographic order of (q1, s1, s2) is the reference's DFS order, so the minimum index with a
 // chain is the chain the sequential search returns; (q1, 0, s2 > 0) does not exist.
-template <typename NextT>
-__device__ bool lk_subsearch3(const LkViewT<NextT> &V, uint32_t (&chain)[kLkMaxChain], uint32_t &clen, const float2 p1,
+template <typename VT>
+__device__ bool lk_subsearch3(const VT &V, uint32_t (&chain)[kLkMaxChain], uint32_t &clen, const float2 p1,
                               const uint32_t t2, const float2 p2, const float g0, const uint32_t q1, const uint32_t s1, const uint32_t s2)
 {
     uint32_t t_open = t2;
     float2 p_open = p2;
     float gain = g0;
     if (0u >= V.max_depth) return false;
-    if (!lk_branch<0, NextT>(V, chain, t_open, p_open, gain, q1)) return false;
+    if (!lk_branch<0, VT>(V, chain, t_open, p_open, gain, q1)) return false;
     {   // depth 1 (:280-288)
         const float close_gain = gain - dist(p_open, p1);
         if (s1 == 0u) {
@@ -658,7 +716,7 @@ __device__ bool lk_subsearch3(const LkViewT<NextT> &V, uint32_t (&chain)[kLkMaxC
         if (close_gain > kLkEps) return false;  // the sequential search returned at s1 = 0
         if (1u >= V.max_depth) return false;
     }
-    if (!lk_branch<1, NextT>(V, chain, t_open, p_open, gain, s1 - 1u)) return false;
+    if (!lk_branch<1, VT>(V, chain, t_open, p_open, gain, s1 - 1u)) return false;
     {   // depth 2
         const float close_gain = gain - dist(p_open, p1);
         if (s2 == 0u) {
@@ -671,15 +729,15 @@ __device__ bool lk_subsearch3(const LkViewT<NextT> &V, uint32_t (&chain)[kLkMaxC
         if (close_gain > kLkEps) return false;
         if (2u >= V.max_depth) return false;
     }
-    if (!lk_branch<2, NextT>(V, chain, t_open, p_open, gain, s2 - 1u)) return false;
-    return lk_chain<3, NextT>(V, chain, clen, p1, t_open, p_open, gain);
+    if (!lk_branch<2, VT>(V, chain, t_open, p_open, gain, s2 - 1u)) return false;
+    return lk_chain<3, VT>(V, chain, clen, p1, t_open, p_open, gain);
 }
 
 // lk_subsearch3 cut in two for the fused scan (k_lk_scan_sub): the FRONT walks the three split levels and stops where the
 // sequential walk lk_chain<3> would begin — 0: no chain, 1: chain (clen set), 2: a walk is pending at depth 3 with
 // (chain[0..8), t_open = chain[7], p_open, gain), its depth-3 closing test already failed.
-template <typename NextT>
-__device__ int lk_subsearch3_front(const LkViewT<NextT> &V, uint32_t (&chain)[kLkMaxChain], uint32_t &clen, const float2 p1, const uint32_t t2,
+template <typename VT>
+__device__ int lk_subsearch3_front(const VT &V, uint32_t (&chain)[kLkMaxChain], uint32_t &clen, const float2 p1, const uint32_t t2,
                                    const float2 p2, const float g0, const uint32_t q1, const uint32_t s1, const uint32_t s2, float2 &p_open_out,
                                    float &gain_out)
 {
@@ -687,7 +745,7 @@ __device__ int lk_subsearch3_front(const LkViewT<NextT> &V, uint32_t (&chain)[kL
     float2 p_open = p2;
     float gain = g0;
     if (0u >= V.max_depth) return 0;
-    if (!lk_branch<0, NextT>(V, chain, t_open, p_open, gain, q1)) return 0;
+    if (!lk_branch<0, VT>(V, chain, t_open, p_open, gain, q1)) return 0;
     {
         const float close_gain = gain - dist(p_open, p1);
         if (s1 == 0u) {
@@ -700,7 +758,7 @@ __device__ int lk_subsearch3_front(const LkViewT<NextT> &V, uint32_t (&chain)[kL
         if (close_gain > kLkEps) return 0;
         if (1u >= V.max_depth) return 0;
     }
-    if (!lk_branch<1, NextT>(V, chain, t_open, p_open, gain, s1 - 1u)) return 0;
+    if (!lk_branch<1, VT>(V, chain, t_open, p_open, gain, s1 - 1u)) return 0;
     {
         const float close_gain = gain - dist(p_open, p1);
         if (s2 == 0u) {
@@ -713,7 +771,7 @@ __device__ int lk_subsearch3_front(const LkViewT<NextT> &V, uint32_t (&chain)[kL
         if (close_gain > kLkEps) return 0;
         if (2u >= V.max_depth) return 0;
     }
-    if (!lk_branch<2, NextT>(V, chain, t_open, p_open, gain, s2 - 1u)) return 0;
+    if (!lk_branch<2, VT>(V, chain, t_open, p_open, gain, s2 - 1u)) return 0;
     // lk_chain<3>'s head (:280-288)
     if (gain - dist(p_open, p1) > kLkEps) {
         clen = 8;
@@ -728,12 +786,12 @@ __device__ int lk_subsearch3_front(const LkViewT<NextT> &V, uint32_t (&chain)[kL
 // One (q3, s4) branch of a pending depth-3 walk: candidate q3 of t_open at depth 3; at depth 4 the closing test (s4 = 0) or
 // candidate s4 - 1, below which lk_chain<5> is a closing test (and, only for max_depth = 6, one more candidate loop).
 // Lexicographic order of (q3, s4) is the DFS order of lk_chain<3>, for the reasons given at lk_subsearch.
-template <typename NextT>
-__device__ bool lk_tail_branch(const LkViewT<NextT> &V, uint32_t (&chain)[kLkMaxChain], uint32_t &clen, const float2 p1, float2 p_open, float gain,
+template <typename VT>
+__device__ bool lk_tail_branch(const VT &V, uint32_t (&chain)[kLkMaxChain], uint32_t &clen, const float2 p1, float2 p_open, float gain,
                                const uint32_t q3, const uint32_t s4)
 {
     uint32_t t_open = chain[7];
-    if (!lk_branch<3, NextT>(V, chain, t_open, p_open, gain, q3)) return false;
+    if (!lk_branch<3, VT>(V, chain, t_open, p_open, gain, q3)) return false;
     const float close_gain = gain - dist(p_open, p1);
     if (s4 == 0u) {
         if (close_gain > kLkEps) {
@@ -744,16 +802,16 @@ __device__ bool lk_tail_branch(const LkViewT<NextT> &V, uint32_t (&chain)[kLkMax
     }
     if (close_gain > kLkEps) return false;  // the sequential walk returned at s4 = 0
     if (4u >= V.max_depth) return false;
-    if (!lk_branch<4, NextT>(V, chain, t_open, p_open, gain, s4 - 1u)) return false;
-    return lk_chain<5, NextT>(V, chain, clen, p1, t_open, p_open, gain);
+    if (!lk_branch<4, VT>(V, chain, t_open, p_open, gain, s4 - 1u)) return false;
+    return lk_chain<5, VT>(V, chain, clen, p1, t_open, p_open, gain);
 }
 
 // the rest of lk_chain<3> for a walk whose head (closing test, depth limit) the front has already passed: the head is
 // repeated (it fails again) — only used when the workgroup's queue of parked walks is full
-template <typename NextT>
-__device__ bool lk_chain_from3(const LkViewT<NextT> &V, uint32_t (&chain)[kLkMaxChain], uint32_t &clen, const float2 p1, const float2 p_open, const float gain)
+template <typename VT>
+__device__ bool lk_chain_from3(const VT &V, uint32_t (&chain)[kLkMaxChain], uint32_t &clen, const float2 p1, const float2 p_open, const float gain)
 {
-    return lk_chain<3, NextT>(V, chain, clen, p1, chain[7], p_open, gain);
+    return lk_chain<3, VT>(V, chain, clen, p1, chain[7], p_open, gain);
 }
 
 // the sub-search `sub` of pair (t1, t2) under the launch's split depth
@@ -762,14 +820,14 @@ __device__ __forceinline__ bool lk_run_sub(const LkArgs &G, uint32_t (&chain)[kL
 {
     LkView V{G.xy, G.cand, G.next, G.k, G.max_depth};
     const uint32_t k1 = G.k + 1u;
-    if (G.split_levels == 3u) return lk_subsearch3<uint32_t>(V, chain, clen, p1, t2, p2, g0, sub / (k1 * k1), (sub / k1) % k1, sub % k1);
-    return lk_subsearch<uint32_t>(V, chain, clen, p1, t1, t2, p2, g0, sub / k1, sub % k1);
+    if (G.split_levels == 3u) return lk_subsearch3<LkView>(V, chain, clen, p1, t2, p2, g0, sub / (k1 * k1), (sub / k1) % k1, sub % k1);
+    return lk_subsearch<LkView>(V, chain, clen, p1, t1, t2, p2, g0, sub / k1, sub % k1);
 }
 
 // BLOCK3D: one workgroup = one pair, threadIdx = (s2, s1, q1) — the sub-search digits come for free; the flat form (for
 // k(k+1)^2 > 1024) recovers them with a 64-bit and three 32-bit divisions per lane, which is most of what a lane that fails
 // its first test executes.
-template <bool BLOCK3D>
+template <bool BLOCK3D, bool PK = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lk_scan_sub(LkArgs G)
 {
     if (G.state->finished) return;
@@ -826,8 +884,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     chain[0] = t1;
     chain[1] = t2;
     const float g0 = t1 == t2 ? 0.0f : dist(p1, p2);
-    LkView V{G.xy, G.cand, G.next, G.k, G.max_depth};
     if (fused && G.split_levels == 3u) {
+        // (PK: the packed view, where the step kernel keeps LkArgs::nx — an instantiation of its own, the classic one's code is untouched)
+        using VT = typename std::conditional<PK, LkViewPk, LkView>::type;
+        VT V;
+        if constexpr (PK) V = LkViewPk{G.candd, G.nx, G.k, G.max_depth};
+        else V = LkView{G.xy, G.cand, G.next, G.k, G.max_depth};
         // Deferred tails.  What a scan waits for is the few lanes whose walk survives the three split levels and goes on
         // alone through up to k + k^2 candidates, three dependent look-ups each (measured: 58 us per scan, 23 us with
         // those walks cut off).  So a surviving lane parks its state in LDS and the workgroup — most of whose lanes failed
@@ -838,7 +900,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         uint32_t mykey = 0xFFFFFFFFu;
         float2 p_open;
         float gain;
-        const int st = lk_subsearch3_front<uint32_t>(V, chain, clen, p1, t2, p2, g0, q1, s1, s2, p_open, gain);
+        const int st = lk_subsearch3_front(V, chain, clen, p1, t2, p2, g0, q1, s1, s2, p_open, gain);
         if (st == 1) mykey = sub * (per + 1u);
         if (st == 2) {
             const uint32_t slot = atomicAdd(&s_qn, 1u);
@@ -849,7 +911,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                 s_q[slot][7] = sub;
                 s_q[slot][8] = __float_as_uint(p_open.x);
                 s_q[slot][9] = __float_as_uint(p_open.y);
-            } else if (lk_chain_from3<uint32_t>(V, chain, clen, p1, p_open, gain)) {  // queue full: walk on alone
+            } else if (lk_chain_from3(V, chain, clen, p1, p_open, gain)) {  // queue full: walk on alone
                 mykey = sub * (per + 1u);
             }
         }
@@ -870,7 +932,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 #pragma unroll
             for (int t = 0; t < 6; ++t) c2[2 + t] = s_q[e][t];
             const float2 po = make_float2(__uint_as_float(s_q[e][8]), __uint_as_float(s_q[e][9]));
-            if (lk_tail_branch<uint32_t>(V, c2, l2, p1, po, __uint_as_float(s_q[e][6]), q3, s4)) {
+            if (lk_tail_branch(V, c2, l2, p1, po, __uint_as_float(s_q[e][6]), q3, s4)) {
                 mykey = key;
                 clen = l2;
 #pragma unroll
@@ -891,9 +953,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             }
         }
         return;
+    
+        return;
     }
-    const bool got = G.split_levels == 3u ? lk_subsearch3<uint32_t>(V, chain, clen, p1, t2, p2, g0, q1, s1, s2)
-                                          : lk_subsearch<uint32_t>(V, chain, clen, p1, t1, t2, p2, g0, q1, s1);
+    LkView V{G.xy, G.cand, G.next, G.k, G.max_depth};
+    const bool got = G.split_levels == 3u ? lk_subsearch3<LkView>(V, chain, clen, p1, t2, p2, g0, q1, s1, s2)
+                                          : lk_subsearch<LkView>(V, chain, clen, p1, t1, t2, p2, g0, q1, s1);
     if (fused) {
         if (got) atomicMin(&s_minkey, sub);
         TL_SYNC();
@@ -963,7 +1028,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         uint32_t mykey = 0xFFFFFFFFu;
         float2 p_open;
         float gain;
-        const int st = dead ? 0 : lk_subsearch3_front<uint32_t>(V, chain, clen, p1, t2, p2, g0, q1, s1, s2, p_open, gain);
+        const int st = dead ? 0 : lk_subsearch3_front<LkView>(V, chain, clen, p1, t2, p2, g0, q1, s1, s2, p_open, gain);
         if (st == 1) mykey = sub * (per + 1u);
         if (st == 2) {
             const uint32_t slot = atomicAdd(&s_qn[par], 1u);
@@ -974,7 +1039,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                 s_q[par][slot][7] = sub;
                 s_q[par][slot][8] = __float_as_uint(p_open.x);
                 s_q[par][slot][9] = __float_as_uint(p_open.y);
-            } else if (lk_chain_from3<uint32_t>(V, chain, clen, p1, p_open, gain)) {  // queue full: walk on alone
+            } else if (lk_chain_from3<LkView>(V, chain, clen, p1, p_open, gain)) {  // queue full: walk on alone
                 mykey = sub * (per + 1u);
             }
         }
@@ -991,7 +1056,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 #pragma unroll
             for (int t = 0; t < 6; ++t) c2[2 + t] = s_q[par][e][t];
             const float2 po = make_float2(__uint_as_float(s_q[par][e][8]), __uint_as_float(s_q[par][e][9]));
-            if (lk_tail_branch<uint32_t>(V, c2, l2, p1, po, __uint_as_float(s_q[par][e][6]), q3, s4)) {
+            if (lk_tail_branch<LkView>(V, c2, l2, p1, po, __uint_as_float(s_q[par][e][6]), q3, s4)) {
                 mykey = key;
                 clen = l2;
 #pragma unroll
@@ -1074,10 +1139,14 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
 
     auto rebuild = [&]() {
         for (uint32_t r = tid; r < n; r += kLkNT) {
-            const uint32_t c = tour[r];
+            const uint32_t c = tour[r], cn = tour[r + 1u == n ? 0u : r + 1u];
             pos[c] = r;
-            next[c] = tour[r + 1u == n ? 0u : r + 1u];
+            next[c] = cn;
             prev[c] = tour[r == 0u ? n - 1u : r - 1u];
+            if (G.nx) {
+                const float2 pn = xy[cn];
+                G.nx[c] = make_float4(__uint_as_float(cn), pn.x, pn.y, dist(xy[c], pn));
+            }
         }
     };
     auto tour_distance = [&](const uint32_t *t) -> float {  // lin_kernighan.rs:118-122
@@ -1153,6 +1222,10 @@ __global__ __launch_bounds__(kLkNT) void k_lk_control(LkArgs G)
                 pos[c] = r;
                 next[c] = cn;
                 prev[c] = cp;
+                if (G.nx) {  // the packed view's record of c: its successor, the successor's point, the tour edge's length
+                    const float2 pn = xy[cn];
+                    G.nx[c] = make_float4(__uint_as_float(cn), pn.x, pn.y, dist(xy[c], pn));
+                }
             }
             if (blockIdx.x == 0 && tid == 0) {
                 S->scans += 1;
@@ -2045,12 +2118,22 @@ __global__ __launch_bounds__(kLkNT) void k_lk_begin(LkArgs G)
 {
     const uint32_t tid = threadIdx.x, n = G.n;
     for (uint32_t r = tid; r < n; r += kLkNT) {
-        const uint32_t c = G.tour[r];
+        const uint32_t c = G.tour[r], cn = G.tour[r + 1u == n ? 0u : r + 1u];
         G.city_ids[r] = c;
         G.best[r] = c;
         G.pos[c] = r;
-        G.next[c] = G.tour[r + 1u == n ? 0u : r + 1u];
+        G.next[c] = cn;
         G.prev[c] = G.tour[r == 0u ? n - 1u : r - 1u];
+        if (G.nx) {
+            const float2 pn = G.xy[cn];
+            G.nx[c] = make_float4(__uint_as_float(cn), pn.x, pn.y, dist(G.xy[c], pn));
+        }
+    }
+    if (G.candd) {  // the candidates with their distances, once per call
+        for (size_t e = tid; e < (size_t)n * G.k; e += kLkNT) {
+            const uint32_t c = G.cand[e];
+            G.candd[e] = make_uint2(c, __float_as_uint(dist(G.xy[e / G.k], G.xy[c])));
+        }
     }
     if (tid == 0) {
         LkState *S = G.state;
@@ -2093,7 +2176,8 @@ hipError_t launch_lk_round(const LkArgs &G0, hipStream_t s, uint32_t round)
 #endif
         if (per_pair <= 1024u) {  // one workgroup per pair, thread coordinates = sub-search digits
             const dim3 blk = G.split_levels == 3u ? dim3(k1, k1, G.k) : dim3(k1, G.k, 1);
-            hipLaunchKernelGGL(k_lk_scan_sub<true>, dim3(2u * G.n), blk, 0, s, G);
+            if (G.nx && G.fused_pick && G.split_levels == 3u) hipLaunchKernelGGL((k_lk_scan_sub<true, true>), dim3(2u * G.n), blk, 0, s, G);
+            else hipLaunchKernelGGL(k_lk_scan_sub<true>, dim3(2u * G.n), blk, 0, s, G);
         } else {
             hipLaunchKernelGGL(k_lk_scan_sub<false>, dim3((uint32_t)((lanes + 255u) / 256u)), dim3(256), 0, s, G);
         }

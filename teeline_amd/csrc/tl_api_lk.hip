@@ -233,7 +233,11 @@ static int lk_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed
     const uint32_t ils_P = ils_spec ? (uint32_t)c->cus * (2 * ils_lds <= (size_t)c->lds_bytes ? 2u : 1u) : 0u;  // two epochs per CU where their images fit
     const size_t o_ils_dc = o_sub + (keep_sub ? up(sub_b) : 0), o_ils_tour = o_ils_dc + (ils_spec ? up((size_t)n * k_small * 4) : 0),
                  o_ils_dist = o_ils_tour + up((size_t)ils_P * n * 4), o_ils_cnt = o_ils_dist + up((size_t)ils_P * 4);
-    const size_t total = o_ils_cnt + up((size_t)ils_P * 32);
+    // the packed view of the chip-wide scan (LkViewPk): candidates with their distances, successor records
+    const bool chip_step_form = fused_pick && levels == 3u && n >= 1500u && !(tf & TL_FLAG_LK_SEPARATE_STEP);
+    const bool packed_view = chip_step_form && !(c->flags & TL_FLAG_LK_CLASSIC_VIEW);
+    const size_t o_pk_c = o_ils_cnt + up((size_t)ils_P * 32), o_pk_n = o_pk_c + (packed_view ? up((size_t)n * k * 8) : 0);
+    const size_t total = o_pk_n + (packed_view ? up((size_t)n * 16) : 0);
     // every mode / size check and every allocation comes before the first event record and the first enqueue: a rejected call
     // leaves the previous kernel sequence's event pair intact and nothing in flight
     // (the single-workgroup forms keep no snapshots on the device: a trace of theirs is the final best tour alone, below)
@@ -299,7 +303,11 @@ static int lk_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed
         if (const char *e = getenv("TL_LK_PERSIST_BLOCKS")) G.persist_blocks = G.persist_blocks ? (uint32_t)atoi(e) : 0u;
 #endif
     }
-    G.chip_step = (fused_pick && levels == 3u && n >= 1500u && !(tf & TL_FLAG_LK_SEPARATE_STEP)) ? 1u : 0u;
+    G.chip_step = chip_step_form ? 1u : 0u;
+    if (packed_view) {  // (filled by k_lk_begin, kept by the step kernel)
+        G.candd = (uint2 *)(w + o_pk_c);
+        G.nx = (float4 *)(w + o_pk_n);
+    }
     if (snap_dev) {
         G.snap = (uint32_t *)c->out_pos.p;
         G.snap_dist = (float *)c->out_stats.p;

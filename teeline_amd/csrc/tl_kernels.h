@@ -244,6 +244,9 @@ struct LkArgs {
     uint32_t persist_blocks; // fused three-level scan: workgroups of the persistent grid (k_lk_scan_persist); 0 = one workgroup per pair
     // k_lk_ils (the LDS-resident single-workgroup ILS of a small instance): records per level queue (lk_ils_qcap), scans per launch,
     // and how many snapshots of the ring the host has taken so far (a slice ends when the ring is full of undelivered ones)
+    // the packed view of the chip-wide scan (lk.hip LkViewPk): candidate ids with their distances, successor records; nullptr = classic view
+    uint2 *candd;
+    float4 *nx;
     uint32_t ils_qcap, ils_slice, snap_delivered;
     uint32_t ils_threads;    // 0: by n (256 up to n = 200, else 1024); tuning: 256 / 512 / 1024
     // speculative epochs (k_lk_ils mode 2 + k_lk_ils_commit): ils_P workgroups = ils_P consecutive epochs kicked from the same best tour

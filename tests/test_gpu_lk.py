@@ -272,11 +272,16 @@ def test_lk_forms_at_the_chip_step_size():
     # n >= 1500 is where the chip-wide step kernel takes over; list lengths 1..10 cross from the one-workgroup-per-pair scan
     # (k (k+1)^2 <= 1024 lanes: k <= 9) to the flat form, depths 1..6 cover every cut of the split and of the parked walks
     import teeline_amd as TA
+    # (round 5: the scan reads the PACKED view by default — candidates with their distances, successor records kept by the step kernel —
+    #  and the classic cand -> xy -> next -> xy look-ups under TL_FLAG_LK_CLASSIC_VIEW: both against the oracle)
     xy = O.synth_xy(1600, seed=9)
-    with TA.Context(0) as ctx:
-        for k, depth, epochs in ((1, 5, 3), (2, 3, 3), (3, 6, 4), (5, 4, 4), (5, 2, 3), (5, 1, 2), (9, 3, 2), (10, 3, 2)):
-            assert_same(gpu_lk(ctx, xy, seed=7, epochs=epochs, max_depth=depth, n_nearest=k),
-                        O.lin_kernighan(xy, seed=7, epochs=epochs, max_depth=depth, n_nearest=k))
+    want = {}
+    for flags in (0, TA.TL_FLAG_LK_CLASSIC_VIEW):
+        with TA.Context(0, flags) as ctx:
+            for k, depth, epochs in ((1, 5, 3), (2, 3, 3), (3, 6, 4), (5, 4, 4), (5, 2, 3), (5, 1, 2), (9, 3, 2), (10, 3, 2)):
+                if (k, depth) not in want:
+                    want[(k, depth)] = O.lin_kernighan(xy, seed=7, epochs=epochs, max_depth=depth, n_nearest=k)
+                assert_same(gpu_lk(ctx, xy, seed=7, epochs=epochs, max_depth=depth, n_nearest=k), want[(k, depth)])
 
 
 def test_progress_channel_carries_the_reference_messages(ctx, tsplib_dir):
