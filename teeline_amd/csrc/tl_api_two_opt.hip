@@ -558,7 +558,7 @@ static int two_opt_best_sweep(tl_ctx *c, const float *xy, uint32_t n, const floa
     const uint32_t n_pad = ((n + 64u + 63u) / 64u) * 64u, ntile_cap = (((n_pad >> 6) + 63u) / 64u) * 64u;
     const uint32_t nblocks = n >= 4 ? best_sweep_scan_blocks(n) : 1;
     const size_t o_perm = 0, o_P = up((size_t)n * 4), o_box = up(o_P + (size_t)(n_pad + 1) * 8), o_msq = up(o_box + (size_t)ntile_cap * 16),
-                 o_par = up(o_msq + (size_t)ntile_cap * 4), o_cnt = up(o_par + (size_t)nblocks * 8), total = o_cnt + 256;
+                 o_par = up(o_msq + (size_t)ntile_cap * 4), o_rk = up(o_par + (size_t)nblocks * 8), o_cnt = up(o_rk + (size_t)n * 8), total = o_cnt + 256;
     if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->work, total)) || (rc = ensure(c, c->out_cost, 4))) return rc;
     unsigned char *w = (unsigned char *)c->work.p;
     std::vector<uint32_t> ident;
@@ -569,7 +569,7 @@ static int two_opt_best_sweep(tl_ctx *c, const float *xy, uint32_t n, const floa
     }
     HIPCHK(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(w + o_perm, init_pos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(w + o_cnt, 0, 64, c->stream));
+    HIPCHK(c, hipMemsetAsync(w + o_cnt, 0, 128, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     BestSweepArgs A{};
     A.xy = (const float2 *)c->xy.p;
@@ -578,6 +578,8 @@ static int two_opt_best_sweep(tl_ctx *c, const float *xy, uint32_t n, const floa
     A.tbox = (float4 *)(w + o_box);
     A.tmsq = (float *)(w + o_msq);
     A.partials = (unsigned long long *)(w + o_par);
+    A.rowkey = (unsigned long long *)(w + o_rk);
+    A.move = (uint32_t *)(w + o_cnt + 64);  // (zeroed with the counters: no move yet)
     A.counters = (uint64_t *)(w + o_cnt);
     A.n = n;
     A.n_pad = n_pad;
@@ -587,13 +589,57 @@ static int two_opt_best_sweep(tl_ctx *c, const float *xy, uint32_t n, const floa
     if (n >= 4) {
         HIPCHK(c, launch_best_sweep_init(A, c->stream));
         const uint64_t cap = 64ull * n + 1024;
+        // 64 sweeps (scan + apply) per poll of the done flag; after the first batch the same 64 sweeps replay as ONE hipGraph launch — a
+        // sweep is two short dependent kernels, and what it costs is mostly the gaps between separately enqueued launches (as in tl_lk)
+        constexpr int kSweepsPerPoll = 64;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t gexec = nullptr;
+        bool first = true, graph_ok = true;
+        int rc_loop = TL_OK;
         for (;;) {
-            for (int r = 0; r < 32; ++r) HIPCHK(c, launch_best_sweep_round(A, c->stream));  // kernels no-op once done
-            HIPCHK(c, hipMemcpyAsync(cnt, A.counters, 32, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (!first && graph_ok && !gexec) {
+                graph_ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                if (graph_ok) {
+                    hipError_t le = hipSuccess;
+                    for (int r = 0; r < kSweepsPerPoll && le == hipSuccess; ++r) le = launch_best_sweep_round(A, c->stream);
+                    const hipError_t ce = hipStreamEndCapture(c->stream, &graph);
+                    graph_ok = le == hipSuccess && ce == hipSuccess && graph && hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) == hipSuccess;
+                }
+                if (!graph_ok) {  // separately enqueued launches from here on, after making sure the stream has left capture mode
+                    (void)hipGetLastError();
+                    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                    if (hipStreamIsCapturing(c->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+                        hipGraph_t g2 = nullptr;
+                        (void)hipStreamEndCapture(c->stream, &g2);
+                        if (g2) (void)hipGraphDestroy(g2);
+                    }
+                    (void)hipGetLastError();
+                    if (graph) {
+                        (void)hipGraphDestroy(graph);
+                        graph = nullptr;
+                    }
+                }
+            }
+            hipError_t e = hipSuccess;
+            if (gexec) e = hipGraphLaunch(gexec, c->stream);
+            else for (int r = 0; r < kSweepsPerPoll && e == hipSuccess; ++r) e = launch_best_sweep_round(A, c->stream);  // kernels no-op once done
+            if (e == hipSuccess) e = hipMemcpyAsync(cnt, A.counters, 32, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                rc_loop = fail(c, TL_ERR_HIP, "two_opt (BEST_SWEEP): %s", hipGetErrorString(e));
+                break;
+            }
+            first = false;
             if (cnt[2]) break;
-            if (cnt[0] > cap) return fail(c, TL_ERR_NO_CONVERGE, "two_opt (BEST_SWEEP): sweep cap reached");
+            if (cnt[0] > cap) {
+                rc_loop = fail(c, TL_ERR_NO_CONVERGE, "two_opt (BEST_SWEEP): sweep cap reached");
+                break;
+            }
         }
+        if (gexec) (void)hipGraphExecDestroy(gexec);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (rc_loop != TL_OK) return rc_loop;
     }
     HIPCHK(c, launch_tour_length(A.xy, nullptr, n, A.perm, (float *)c->out_cost.p, c->stream));
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));

@@ -114,6 +114,8 @@ struct BestSweepArgs {
     float4 *tbox;                  // [ntile_cap] L0 boxes
     float *tmsq;                   // [ntile_cap]
     unsigned long long *partials;  // one packed key per scan workgroup
+    unsigned long long *rowkey;    // [n] every row's best candidate as of the last sweep that decided it (kNoKey64: none)
+    uint32_t *move;                // {a move has been applied, its row is, its column js}: what the next sweep must decide again
     uint64_t *counters;            // sweeps, moves, done, reversed
     uint32_t n, n_pad, ntile_cap, phase;
 };

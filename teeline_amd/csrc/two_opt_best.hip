@@ -7,10 +7,11 @@
 //   k_bs_init    tour-ordered coordinates P[k] = xy[perm[k]] and per-tile L0 metadata, in HBM (L2-resident)
 //   k_bs_scan    one wave per row i.  L0 (lanes = tiles) -> live-tile mask, L1 (lanes = j) on live tiles, L2 hardware
 //                sqrt to discard the clearly non-improving, exact delta for the rest.  Argmin by wavefront DPP/shuffle
-//                reduction of a packed 64-bit key (~delta bits << 32 | i << 16 | j), then per workgroup.
+//                reduction of a packed 64-bit key (~delta bits << 32 | i << 16 | j), then per workgroup.  Every row's best key is
+//                cached; a sweep decides only the rows (and, for the rows in front of the move, the columns) the previous move touched.
 //   k_bs_apply   one workgroup: reduces the per-workgroup keys, applies swap_2opt(path, i+1, j) on P and perm,
-//                rebuilds the L0 metadata of the touched tiles, bumps the counters / sets the done flag.
-// The host enqueues scan+apply pairs in batches and reads the done flag once per batch.
+//                rebuilds the L0 metadata of the touched tiles, bumps the counters / sets the done flag, files the move for the scan.
+// The host replays 64 sweeps (scan + apply) as one hipGraph per poll of the done flag.
 #include "tl_kernels.h"
 #include "two_opt_common.h"
 
@@ -21,7 +22,6 @@ namespace tl {
 namespace {
 
 constexpr unsigned long long kNoKey64 = ~0ULL;
-constexpr int kBsWaves = 4;  // rows per scan workgroup
 
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 {
@@ -53,6 +53,56 @@ __global__ __launch_bounds__(256) void k_bs_init(BestSweepArgs A)
     }
 }
 
+// A row's best candidate among the columns [jlo, jhi] (clipped to the row's own [i+2, n-2]) as a packed key, or kNoKey64.
+__device__ __forceinline__ unsigned long long bs_row_best(const BestSweepArgs &A, const float2 *__restrict__ P, uint32_t i, uint32_t jlo, uint32_t jhi, int lane)
+{
+    const uint32_t n = A.n;
+    unsigned long long best = kNoKey64;
+    const float2 a = P[i], b = P[i + 1u];
+    const float sqab = sqdist(a, b);
+    const float dab_a = __builtin_amdgcn_sqrtf(sqab);
+    const uint32_t jmin = i + 2u > jlo ? i + 2u : jlo, jmax = n - 2u < jhi ? n - 2u : jhi;
+    if (jmin > jmax) return best;
+    const uint32_t tmin = jmin >> 6, tmax = jmax >> 6;
+    for (uint32_t g = tmin >> 6; g <= (tmax >> 6); ++g) {
+        const uint32_t tl = (g << 6) + (uint32_t)lane;
+        const float4 box = A.tbox[tl];
+        const float msq = A.tmsq[tl];
+        const bool live = (tl >= tmin) && (tl <= tmax) && ((box_lb(a.x, a.y, box) < sqab) || (box_lb(b.x, b.y, box) < msq));  // L0
+        uint64_t m = __builtin_amdgcn_ballot_w64(live);
+        while (m) {
+            const uint32_t t = (g << 6) + (uint32_t)(__builtin_ffsll((long long)m) - 1);
+            m &= m - 1;
+            const uint32_t j = (t << 6) + (uint32_t)lane;
+            const float2 c = P[j], e = P[j + 1u];
+            const float sqce = sqdist(c, e), s1 = sqdist(a, c), s2 = sqdist(b, e);
+            bool test = (j >= jmin) & (j <= jmax) & ((s1 < sqab) | (s2 < sqce));  // L1
+            if (!__builtin_amdgcn_ballot_w64(test)) continue;
+            // L2: discard what the hardware sqrt already shows to be non-improving by a safe margin
+            const float neu_a = __builtin_amdgcn_sqrtf(s1) + __builtin_amdgcn_sqrtf(s2);
+            const float cur_a = dab_a + __builtin_amdgcn_sqrtf(sqce);
+            test = test & !(neu_a > cur_a + cur_a * 1.9073486e-6f);
+            if (!__builtin_amdgcn_ballot_w64(test)) continue;
+            const float neu = sqrt_rn(s1) + sqrt_rn(s2);
+            const float cur = sqrt_rn(sqab) + sqrt_rn(sqce);
+            if (test & (neu < cur)) {
+                const float delta = neu - cur;
+                const unsigned long long key = ((unsigned long long)(~__builtin_bit_cast(uint32_t, delta)) << 32) | (i << 16) | j;
+                best = key < best ? key : best;
+            }
+        }
+    }
+    return wave_min_u64(best);
+}
+
+// One wave per row.  Round 5: a row's best candidate is CACHED (A.rowkey) and a sweep decides only what the previous move can have changed.
+// The move reversed positions [is+1 .. js]: a row r > js reads none of them — its cached key stands; a row is <= r <= js has a new a or b —
+// decided afresh; a row r < is keeps its a and b, and of its columns only j in [is .. js] have a new c = p[j] or e = p[j+1]: its new best
+// is the smaller of the cached key and the best over those columns — unless the cached key's own column lies in that range (then afresh).
+// Same keys, hence the same argmin with the same tie rule (lowest delta, then lowest (i, j)), as deciding every row afresh.
+// (Scan and apply as ONE launch — 256 workgroups of 16 waves, rows strided over all waves, the workgroup that draws the sweep's last
+//  ticket applies the move — was built and measured: 19.0 us per sweep against 10.2 for the two launches at n = 10^4, NOTEBOOK r5.4.)
+constexpr int kBsWaves = 4;  // rows per scan workgroup
 __global__ __launch_bounds__(kBsWaves * 64) void k_bs_scan(BestSweepArgs A)
 {
     __shared__ unsigned long long s_key[kBsWaves];
@@ -63,41 +113,24 @@ __global__ __launch_bounds__(kBsWaves * 64) void k_bs_scan(BestSweepArgs A)
     unsigned long long best = kNoKey64;
     if (A.counters[2] == 0 && i + 3u < n) {  // not done; rows i in [0, n-3)
         const float2 *__restrict__ P = A.P;
-        const float2 a = P[i], b = P[i + 1u];
-        const float sqab = sqdist(a, b);
-        const float dab_a = __builtin_amdgcn_sqrtf(sqab);
-        const uint32_t jmin = i + 2u, tmin = jmin >> 6;
-        const uint32_t ngroups = ((A.n_pad >> 6) + 63u) >> 6;
-        for (uint32_t g = 0; g < ngroups; ++g) {
-            const uint32_t tl = (g << 6) + (uint32_t)lane;
-            const float4 box = A.tbox[tl];
-            const float msq = A.tmsq[tl];
-            const bool live = (tl >= tmin) && ((box_lb(a.x, a.y, box) < sqab) || (box_lb(b.x, b.y, box) < msq));  // L0
-            uint64_t m = __builtin_amdgcn_ballot_w64(live);
-            while (m) {
-                const uint32_t t = (g << 6) + (uint32_t)(__builtin_ffsll((long long)m) - 1);
-                m &= m - 1;
-                const uint32_t j = (t << 6) + (uint32_t)lane;
-                const float2 c = P[j], e = P[j + 1u];
-                const float sqce = sqdist(c, e), s1 = sqdist(a, c), s2 = sqdist(b, e);
-                bool test = (j >= jmin) & (j + 2u <= n) & ((s1 < sqab) | (s2 < sqce));  // L1
-                if (!__builtin_amdgcn_ballot_w64(test)) continue;
-                // L2: discard what the hardware sqrt already shows to be non-improving by a safe margin
-                const float neu_a = __builtin_amdgcn_sqrtf(s1) + __builtin_amdgcn_sqrtf(s2);
-                const float cur_a = dab_a + __builtin_amdgcn_sqrtf(sqce);
-                test = test & !(neu_a > cur_a + cur_a * 1.9073486e-6f);
-                if (!__builtin_amdgcn_ballot_w64(test)) continue;
-                const float neu = sqrt_rn(s1) + sqrt_rn(s2);
-                const float cur = sqrt_rn(sqab) + sqrt_rn(sqce);
-                if (test & (neu < cur)) {
-                    const float delta = neu - cur;
-                    const unsigned long long key = ((unsigned long long)(~__builtin_bit_cast(uint32_t, delta)) << 32) | (i << 16) | j;
-                    best = key < best ? key : best;
-                }
+        const uint32_t mv = A.move[0], is = A.move[1], js = A.move[2];
+        if (mv == 0u || (i >= is && i <= js)) {
+            best = bs_row_best(A, P, i, 0u, n, lane);
+            if (lane == 0) A.rowkey[i] = best;
+        } else if (i > js) {
+            best = A.rowkey[i];
+        } else {
+            const unsigned long long ck = A.rowkey[i];
+            const uint32_t cj = (uint32_t)(ck & 0xFFFFu);
+            if (ck != kNoKey64 && cj >= is && cj <= js) {
+                best = bs_row_best(A, P, i, 0u, n, lane);
+            } else {
+                const unsigned long long pk = bs_row_best(A, P, i, is, js, lane);
+                best = pk < ck ? pk : ck;
             }
+            if (best != ck && lane == 0) A.rowkey[i] = best;
         }
     }
-    best = wave_min_u64(best);
     if (lane == 0) s_key[wave] = best;
     TL_SYNC();
     if (threadIdx.x == 0) {
@@ -148,6 +181,9 @@ __global__ __launch_bounds__(1024) void k_bs_apply(BestSweepArgs A, uint32_t nbl
         A.counters[0] += 1;                       // sweeps
         A.counters[1] += 1;                       // moves
         A.counters[3] += (uint64_t)(js - is);     // reversed elements
+        A.move[1] = is;                           // what the next sweep's scan needs to know
+        A.move[2] = js;
+        A.move[0] = 1u;
     }
 }
 
@@ -163,8 +199,7 @@ hipError_t launch_best_sweep_init(const BestSweepArgs &A, hipStream_t s)
 
 hipError_t launch_best_sweep_round(const BestSweepArgs &A, hipStream_t s)
 {
-    const uint32_t rows = A.n - 3u;
-    const uint32_t nblocks = (rows + kBsWaves - 1) / kBsWaves;
+    const uint32_t nblocks = best_sweep_scan_blocks(A.n);
     hipLaunchKernelGGL(k_bs_scan, dim3(nblocks), dim3(kBsWaves * 64), 0, s, A);
     hipLaunchKernelGGL(k_bs_apply, dim3(1), dim3(1024), 0, s, A, nblocks);
     return hipGetLastError();
