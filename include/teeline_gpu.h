@@ -91,8 +91,8 @@ typedef enum tl_mode {
                                               late sweeps (once a sweep has applied fewer than n / 40 moves) of an instance with n >= 400 read the lists, csrc/two_opt_nl.hip)               */
 #define TL_FLAG_2OPT_NL_ALWAYS (1u << 19)  /* LDS 2-opt: neighbour-list rows at every n they fit and from the second sweep on            */
 #define TL_FLAG_LK_CHIP_WIDE (1u << 20)    /* tl_lk: chip-wide scans at every n (default: an instance whose search state fits one CU's LDS runs its
-                                              lk_pass in ONE workgroup with all state in LDS, k_lk_ils in csrc/lk.hip — up to n = 700, up to
-                                              n = 2000 with epochs and platoo_epochs >= 64)                                                      */
+                                              lk_pass in ONE workgroup with all state in LDS, k_lk_ils in csrc/lk.hip — up to n = 700, and wherever
+                                              it fits (n ~ 3000) with epochs and platoo_epochs >= 64)                                            */
 #define TL_FLAG_LK_ILS_LDS (1u << 21)      /* tl_lk: that single-workgroup LDS form at every n it fits                                          */
 #define TL_FLAG_LK_CLASSIC_VIEW (1u << 23)  /* tl_lk, chip-wide scans at n >= 1500: the chain search reads cand -> xy -> next -> xy (default: the
                                               packed view — candidates with their distances, successor records with the successor's point and the

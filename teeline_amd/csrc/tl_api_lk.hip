@@ -11,7 +11,7 @@ static constexpr uint32_t kLkSmallMaxN = 0, kLkSmallWave64MaxN = 0, kLkSmall256M
 #define TL_LK_ILS_MAX_N 700u  // largest n the LDS-resident ILS (k_lk_ils) takes by default ...
 #endif
 static constexpr uint32_t kLkIlsMaxN = TL_LK_ILS_MAX_N;
-static constexpr uint32_t kLkIlsMaxNLongPlateau = 2000u;  // ... and with a plateau of >= 64 epochs (the speculative epochs fill the chip)
+static constexpr uint32_t kLkIlsMaxNLongPlateau = 65535u;  // ... and, with a plateau of >= 64 epochs (the speculative epochs fill the chip), whatever fits one CU's LDS (n ~ 3 400 at k = 3, ~2 900 at k = 5)
 static constexpr uint32_t kLkIlsSlice = 8192u;  // scans per launch of k_lk_ils (tens of milliseconds)
 static constexpr uint32_t kLkIlsEpochScans = 512u;  // scans a speculative epoch may take before it files "unfinished" (x 8 per retry as the next epoch)
 static constexpr int kLkIlsBatches = 16;         // batches of speculative epochs per poll of the state (at most one progress message per batch: the ring holds 64)
