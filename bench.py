@@ -64,6 +64,9 @@ def parse():
                     help="skip the one untimed launch of the counting kernel variant (PMC passes: only the timed kernel runs)")
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1 without RCCL: one process, one tl_ctx per device, tl_two_opt_multistart_devices")
+    ap.add_argument("--rccl-in-library", action="store_true",
+                    help="with --single-process: the library's own RCCL collective (TL_FLAG_MULTISTART_RCCL: min-all-reduce of the keys + "
+                         "broadcast of the winner's tour over ncclCommInitAll communicators) instead of the host minimum")
     ap.add_argument("--force-launcher", action="store_true",
                     help="take the self-launch path even for --gpus 1 (one rank under torch.distributed.run, RCCL initialised): "
                          "the rehearsal of that path on a one-GPU box")
@@ -532,7 +535,7 @@ def single_process(a):
     n = a.n
     xy = TA.synth.synth_xy(n)
     prob = TA.TspProblem(np.arange(n), xy)
-    ctxs = [TA.Context(d) for d in range(a.gpus)]
+    ctxs = [TA.Context(d, TA.TL_FLAG_MULTISTART_RCCL if (a.rccl_in_library and d == 0) else 0) for d in range(a.gpus)]
     strong = a.restarts_total > 0
     count = a.restarts_total if strong else a.restarts * a.gpus
     per_sweep = (n - 3) * (n - 2) // 2
@@ -551,8 +554,11 @@ def single_process(a):
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"configs[3]: synthetic EUC_2D n={n}, multi-start REF_ORDER 2-opt, {count} seeded random restarts dealt over "
-                               f"{a.gpus} device(s) by ONE process (tl_two_opt_multistart_devices, no collective: host min of {a.gpus} keys)",
-                   "n": n, "restarts_total": count, "mode": "REF_ORDER", "restart_seed": a.seed, "launcher": "single-process"},
+                               f"{a.gpus} device(s) by ONE process (tl_two_opt_multistart_devices; " +
+                               ("the library's RCCL collective: key min-all-reduce + broadcast of the winner's tour)" if a.rccl_in_library
+                                else f"no collective: host min of {a.gpus} keys)"),
+                   "n": n, "restarts_total": count, "mode": "REF_ORDER", "restart_seed": a.seed,
+                   "launcher": "single-process" + (" + RCCL inside the library" if a.rccl_in_library else "")},
         "final_tour_cost": float(sol.total), "best_restart": sol.stats["best_restart"],
         "slowest_shard_kernel_ms": float(np.mean(kms)), "device": info,
         "note": "host-buffer entry: the rate includes the per-call PCIe traffic (coordinates up; costs, counters and the winner's tour down)",

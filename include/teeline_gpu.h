@@ -94,6 +94,10 @@ typedef enum tl_mode {
                                               lk_pass in ONE workgroup with all state in LDS, k_lk_ils in csrc/lk.hip — up to n = 700, and wherever
                                               it fits (n ~ 3000) with epochs and platoo_epochs >= 64)                                            */
 #define TL_FLAG_LK_ILS_LDS (1u << 21)      /* tl_lk: that single-workgroup LDS form at every n it fits                                          */
+#define TL_FLAG_MULTISTART_RCCL (1u << 24)  /* tl_two_opt_multistart(_devices), set on ctxs[0]: the winner is found by an RCCL min-all-reduce of the
+                                              devices' packed (cost, restart) keys and its tour reaches every device by an RCCL broadcast from its
+                                              owner (one process, ncclCommInitAll; librccl is loaded on first use) — the host minimum is computed
+                                              all the same and must agree.  Default: the host minimum alone.                                      */
 #define TL_FLAG_LK_CLASSIC_VIEW (1u << 23)  /* tl_lk, chip-wide scans at n >= 1500: the chain search reads cand -> xy -> next -> xy (default: the
                                               packed view — candidates with their distances, successor records with the successor's point and the
                                               tour edge's length: two dependent look-ups and one square root per branch instead of four and three) */

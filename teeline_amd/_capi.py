@@ -29,6 +29,7 @@ TL_FLAG_2OPT_NO_NL, TL_FLAG_2OPT_NL_ALWAYS = 1 << 18, 1 << 19  # LDS 2-opt: neig
 TL_FLAG_LK_SCAN_PERSIST = 1 << 17  # tl_lk (tuning build): the fused scan as a persistent grid striding over the window's pairs
 TL_FLAG_LK_CHIP_WIDE = 1 << 20  # tl_lk: chip-wide scans at every n
 TL_FLAG_LK_ILS_LDS = 1 << 21    # tl_lk: the single-workgroup LDS form (k_lk_ils) at every n it fits
+TL_FLAG_MULTISTART_RCCL = 1 << 24  # multi-start over several devices of one process: RCCL min-all-reduce + broadcast inside the library
 TL_FLAG_LK_CLASSIC_VIEW = 1 << 23  # tl_lk chip-wide: cand -> xy -> next -> xy look-ups instead of the packed records
 TL_FLAG_LK_NO_SPECULATION = 1 << 22  # tl_lk, LDS form: epochs one after the other (default: a batch of consecutive epochs at once)
 TL_FLAG_LK_SMALL = 1 << 9  # tl_lk: the LDS-resident single-workgroup form wherever it fits

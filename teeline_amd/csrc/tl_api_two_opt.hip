@@ -419,6 +419,71 @@ extern "C" int tl_two_opt_multistart(tl_ctx *c, const float *xy, uint32_t n, uin
                                          out_costs, stats);
 }
 
+// ------------------------------------------------------------------------------------------------
+// RCCL inside the library (TL_FLAG_MULTISTART_RCCL): SURVEY.md §8(e)'s collective for ONE process that drives several devices —
+// every device reduces its shard's packed (cost, restart) keys to one word, ncclAllReduce(ncclMin, uint64) over the devices'
+// communicators (ncclCommInitAll: one process, no bootstrap), ncclBroadcast of the winner's tour from its owner.  librccl is
+// loaded on first use (dlopen): a caller that never asks for it pays nothing at start-up and the library has no link-time
+// dependency on it.  The host minimum of tl_two_opt_multistart_devices is computed all the same and must agree.
+// ------------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+#include <map>
+#include <mutex>
+namespace {
+struct Rccl {
+    void *h = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::map<std::vector<int>, std::vector<void *>> comms;  // per device list, for the life of the process
+    std::mutex mu;
+    bool load()
+    {
+        if (h) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+        }
+        if (!h) return false;
+        CommInitAll = (decltype(CommInitAll))dlsym(h, "ncclCommInitAll");
+        AllReduce = (decltype(AllReduce))dlsym(h, "ncclAllReduce");
+        Broadcast = (decltype(Broadcast))dlsym(h, "ncclBroadcast");
+        GroupStart = (decltype(GroupStart))dlsym(h, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
+        GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
+        if (!CommInitAll || !AllReduce || !Broadcast || !GroupStart || !GroupEnd || !GetErrorString) {
+            dlclose(h);
+            h = nullptr;
+            return false;
+        }
+        return true;
+    }
+};
+Rccl g_rccl;
+constexpr int kNcclUint32 = 3, kNcclUint64 = 5, kNcclMin = 3;  // rccl.h: ncclDataType_t, ncclRedOp_t
+
+// one workgroup: min over a shard of tl_pack_cost_key(cost, first + r) — (f32 bits << 32) | restart, ~0 for an empty shard
+__global__ __launch_bounds__(256) void k_shard_key(const float *__restrict__ cost, uint32_t first, uint32_t count, unsigned long long *__restrict__ out)
+{
+    __shared__ unsigned long long sk[256];
+    unsigned long long best = ~0ull;
+    for (uint32_t r = threadIdx.x; r < count; r += 256u) {
+        const unsigned long long k = ((unsigned long long)__float_as_uint(cost[r]) << 32) | (unsigned long long)(first + r);
+        best = k < best ? k : best;
+    }
+    sk[threadIdx.x] = best;
+    __syncthreads();
+    for (uint32_t s2 = 128u; s2 > 0u; s2 >>= 1) {
+        if (threadIdx.x < s2 && sk[threadIdx.x + s2] < sk[threadIdx.x]) sk[threadIdx.x] = sk[threadIdx.x + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sk[0];
+}
+}  // namespace
+
 // The deal of restarts [first, first + count) over `parts` devices / ranks: contiguous blocks, the first count % parts take one more.
 // Host-only; tl_two_opt_multistart_devices deals with it, and a multi-process job's ranks (teeline_amd/host/multistart.py shard_total)
 // use the same map, so that a run's result does not depend on how it was spread.
@@ -485,9 +550,60 @@ extern "C" int tl_two_opt_multistart_devices(tl_ctx *const *ctxs, int n_ctxs, co
         kms_max = kms > kms_max ? kms : kms_max;
     }
     tl_ctx *cb = ctxs[best_dev];
-    HIPCHK(cb, hipSetDevice(cb->device));
-    HIPCHK(cb, hipMemcpyAsync(out_best_pos, (const uint32_t *)cb->out_pos.p + (size_t)best.local * n, (size_t)n * 4, hipMemcpyDeviceToHost, cb->stream));
-    HIPCHK(cb, hipStreamSynchronize(cb->stream));  // never the legacy stream: see tl_two_opt_trace
+    if (c0->flags & TL_FLAG_MULTISTART_RCCL) {
+        // ---- the collective over RCCL: key min-all-reduce, then the winner's tour from its owner to every device; device 0 hands it out
+        std::lock_guard<std::mutex> lk(g_rccl.mu);
+        if (!g_rccl.load()) return fail(c0, TL_ERR_UNSUPPORTED, "TL_FLAG_MULTISTART_RCCL: librccl could not be loaded (%s)", dlerror());
+        std::vector<int> devs;
+        for (int d = 0; d < n_ctxs; ++d) devs.push_back(ctxs[d]->device);
+        auto it = g_rccl.comms.find(devs);
+        if (it == g_rccl.comms.end()) {
+            std::vector<void *> cm((size_t)n_ctxs, nullptr);
+            const int r = g_rccl.CommInitAll(cm.data(), n_ctxs, devs.data());
+            if (r != 0) return fail(c0, TL_ERR_HIP, "ncclCommInitAll over %d device(s): %s", n_ctxs, g_rccl.GetErrorString(r));
+            it = g_rccl.comms.emplace(devs, cm).first;
+        }
+        const std::vector<void *> &cm = it->second;
+        for (int d = 0; d < n_ctxs; ++d) {  // per device: [key in | key out | tour] in its misc buffer; the shard's key on the device
+            tl_ctx *cd = ctxs[d];
+            HIPCHK(cd, hipSetDevice(cd->device));
+            if ((rc = ensure(cd, cd->misc, 256 + (size_t)n * 4))) return rc;
+            if (shard[d].count) hipLaunchKernelGGL(k_shard_key, dim3(1), dim3(256), 0, cd->stream, (const float *)cd->out_cost.p, shard[d].first, shard[d].count, (unsigned long long *)cd->misc.p);
+            else HIPCHK(cd, hipMemsetAsync(cd->misc.p, 0xFF, 8, cd->stream));
+        }
+        int r = g_rccl.GroupStart();
+        for (int d = 0; d < n_ctxs && r == 0; ++d) {
+            HIPCHK(ctxs[d], hipSetDevice(ctxs[d]->device));
+            r = g_rccl.AllReduce(ctxs[d]->misc.p, (unsigned char *)ctxs[d]->misc.p + 64, 1, kNcclUint64, kNcclMin, cm[(size_t)d], ctxs[d]->stream);
+        }
+        if (r == 0) r = g_rccl.GroupEnd();
+        if (r != 0) return fail(c0, TL_ERR_HIP, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
+        unsigned long long gkey = 0;
+        HIPCHK(c0, hipSetDevice(c0->device));
+        HIPCHK(c0, hipMemcpyAsync(&gkey, (unsigned char *)c0->misc.p + 64, 8, hipMemcpyDeviceToHost, c0->stream));
+        HIPCHK(c0, hipStreamSynchronize(c0->stream));
+        if (gkey != best.key) return fail(c0, TL_ERR_HIP, "RCCL min-all-reduce gave key %llx, the host minimum is %llx", gkey, (unsigned long long)best.key);
+        // the owner of restart (gkey & 0xFFFFFFFF) is the root of the broadcast
+        r = g_rccl.GroupStart();
+        for (int d = 0; d < n_ctxs && r == 0; ++d) {
+            HIPCHK(ctxs[d], hipSetDevice(ctxs[d]->device));
+            const void *src = d == best_dev ? (const void *)((const uint32_t *)ctxs[d]->out_pos.p + (size_t)best.local * n) : (const void *)((unsigned char *)ctxs[d]->misc.p + 256);
+            r = g_rccl.Broadcast(src, (unsigned char *)ctxs[d]->misc.p + 256, n, kNcclUint32, best_dev, cm[(size_t)d], ctxs[d]->stream);
+        }
+        if (r == 0) r = g_rccl.GroupEnd();
+        if (r != 0) return fail(c0, TL_ERR_HIP, "ncclBroadcast: %s", g_rccl.GetErrorString(r));
+        HIPCHK(c0, hipSetDevice(c0->device));
+        HIPCHK(c0, hipMemcpyAsync(out_best_pos, (unsigned char *)c0->misc.p + 256, (size_t)n * 4, hipMemcpyDeviceToHost, c0->stream));
+        HIPCHK(c0, hipStreamSynchronize(c0->stream));
+        for (int d = 1; d < n_ctxs; ++d) {  // (every device's stream has finished its part before the call returns)
+            HIPCHK(ctxs[d], hipSetDevice(ctxs[d]->device));
+            HIPCHK(ctxs[d], hipStreamSynchronize(ctxs[d]->stream));
+        }
+    } else {
+        HIPCHK(cb, hipSetDevice(cb->device));
+        HIPCHK(cb, hipMemcpyAsync(out_best_pos, (const uint32_t *)cb->out_pos.p + (size_t)best.local * n, (size_t)n * 4, hipMemcpyDeviceToHost, cb->stream));
+        HIPCHK(cb, hipStreamSynchronize(cb->stream));  // never the legacy stream: see tl_two_opt_trace
+    }
     const uint32_t best_restart = (uint32_t)(best.key & 0xFFFFFFFFull);
     if (out_best_cost) *out_best_cost = costs[best_restart - first];
     if (out_best_restart) *out_best_restart = best_restart;

@@ -212,6 +212,23 @@ def test_multistart_over_several_contexts_is_independent_of_the_split(ctx):
             assert sol.stats[key] == ref.stats[key]
 
 
+def test_multistart_collective_through_rccl_inside_the_library(ctx):
+    # TL_FLAG_MULTISTART_RCCL (round 5): the library itself min-all-reduces the devices' packed (cost, restart) keys over RCCL and
+    # broadcasts the winner's tour from its owner (one process, ncclCommInitAll; librccl dlopen'ed on first use).  The test box has ONE
+    # GPU, so this is the one-device communicator — every call of the path (group start / all-reduce / broadcast / the hand-out from
+    # device 0's buffer) runs, over a communicator of size 1; the result must be the host-minimum path's.
+    import teeline_amd as TA
+    n, R, seed = 700, 9, 4
+    xy = O.synth_xy(n, seed=23)
+    prob = TA.TspProblem(np.arange(n), xy)
+    ref, ref_costs = TA.two_opt.multistart(prob, R, seed=seed, first=2, ctx=ctx, return_costs=True)
+    with TA.Context(0, TA.TL_FLAG_MULTISTART_RCCL) as cr:
+        for _ in range(2):  # (the second call finds the communicator cached)
+            sol, costs = TA.two_opt.multistart_devices(prob, R, [cr], seed=seed, first=2, return_costs=True)
+            assert costs.tobytes() == ref_costs.tobytes() and list(sol.route()) == list(ref.route())
+            assert sol.total == ref.total and sol.stats["best_restart"] == ref.stats["best_restart"]
+
+
 def test_dm_is_euc2d_tells_coordinate_matrices_from_explicit_ones(ctx, tsplib_dir):
     # the reference's DistanceMatrix keeps no DistanceType (distance_matrix.rs:86-93): the shim asks the library
     import teeline_amd as TA
