@@ -1488,7 +1488,9 @@ __global__ __launch_bounds__(NT) void k_lk_ils(LkArgs G)
     // runs that epoch's lk_pass and files the tour it ends on, its length and its counters in slot j; k_lk_ils_commit then takes the
     // epochs in order up to the first one that is accepted (the later ones started from a best tour that is no longer the best).
     const uint32_t mode = G.ils_mode, slot = blockIdx.x;
-    if (mode == 2u && (S->finished != 0u || S->epoch + slot >= G.epochs)) return;
+    // (mode 2: the batch's width is S->applied — k_lk_ils_commit adapts it to how soon the last batches were decided: while every second
+    //  epoch is accepted a batch of 512 only waits for its slowest epoch; the grid stays ils_P wide, the workgroups beyond the width return)
+    if (mode == 2u && (S->finished != 0u || S->epoch + slot >= G.epochs || slot >= S->applied)) return;
     const bool fresh = mode != 2u && S->applied == 0u;
     for (uint32_t r = tid; r < n; r += NT) {
         xy[r] = G.xy[r];
@@ -1976,7 +1978,7 @@ __global__ __launch_bounds__(NT) void k_lk_ils(LkArgs G)
         G.best[r] = best[r];
     }
     if (tid == 0) {
-        S->applied = 1u;
+        S->applied = mode == 1u ? 16u : 1u;  // (mode 1 hands over to the epochs: their first batch is 16 wide)
         S->pass_moves = (uint32_t)pass_scans;
         S->finished = fin ? 1u : (cycling ? 2u : 0u);
         S->stage = stage;
@@ -2006,7 +2008,8 @@ __global__ __launch_bounds__(256) void k_lk_ils_commit(LkArgs G)
     LkState *S = G.state;
     if (S->finished) return;
     const uint32_t tid = threadIdx.x, n = G.n;
-    const uint32_t left = G.epochs - S->epoch, P = G.ils_P < left ? G.ils_P : left;
+    const uint32_t width = S->applied < G.ils_P ? S->applied : G.ils_P;
+    const uint32_t left = G.epochs - S->epoch, P = width < left ? width : left;
     if (tid == 0) {
         uint32_t epoch = S->epoch, platoo = S->platoo, acc = 0xFFFFFFFFu;
         float best_dist = S->best_dist;
@@ -2051,6 +2054,12 @@ __global__ __launch_bounds__(256) void k_lk_ils_commit(LkArgs G)
         S->exchanged = exchanged;
         S->finished = fin ? 1u : (S->key == 0xDEAD0001u ? 2u : 0u);
         S->window = window;
+        // the next batch's width: decided at epoch j -> a few times j; a batch that was rejected throughout -> four times as wide
+        {
+            uint32_t w2 = acc != 0xFFFFFFFFu ? 4u * (acc + 1u) + 8u : 4u * width;
+            w2 = w2 < 16u ? 16u : w2;
+            S->applied = w2 > G.ils_P ? G.ils_P : w2;
+        }
         s_acc = acc;
         s_d = best_dist;
 #ifdef TL_DEBUG_ILS
