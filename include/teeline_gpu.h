@@ -295,13 +295,13 @@ int tl_lk_live(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed,
 /* out: n x min(k, n-1) u32 — the k-NN buffer of the reference's kd-tree query per city (kdtree.rs:193-212, mod.rs:1839-1889):
  * ascending f32 distance, equal distances in the tree's visiting order.  The tree is the reference's wherever its median
  * selection is unambiguous (no points comparing Equal around a pivot, kdtree.rs:63,301-317); elsewhere the reference's tree is
- * implementation-defined and the (coordinate value, position) order decides.  k <= 16. */
+ * implementation-defined and the (coordinate value, position) order decides.  k <= 64. */
 int tl_build_candidates(tl_ctx *ctx, const float *xy, uint32_t n, uint32_t k, uint32_t *out);
 
 /* ---- NN seed: replaces nearest_neighbor::solve (nearest_neighbor.rs:8-76) ---------------------- */
 /* First unvisited among the n_nearest closest (stable ties, mod.rs:1848-1855), else the globally
  * nearest unvisited (tie -> lowest position; the reference iterates a HashSet there).  The walk's visited flags
- * live in one CU's LDS (n bytes): n <= ~160 000 (TL_ERR_UNSUPPORTED beyond); n_nearest <= 16.
+ * live in one CU's LDS (n bytes): n <= ~160 000 (TL_ERR_UNSUPPORTED beyond); n_nearest <= 64.
  * dm_packed NULL: EUC_2D from xy; otherwise every distance is read from the packed matrix (GEO / EXPLICIT problems,
  * distance_matrix.rs:259-297) and xy may be NULL. */
 int tl_nearest_neighbor(tl_ctx *ctx, const float *xy, const float *dm_packed, uint32_t n, uint32_t n_nearest,

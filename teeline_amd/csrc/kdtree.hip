@@ -269,7 +269,9 @@ hipError_t launch_knn_kdtree(const KdNode *nodes, const float2 *xy, uint32_t n, 
     const uint32_t grid = (n + 255u) / 256u, root = n / 2u;  // the level-0 segment [0, n) has its pivot at n / 2
     if (k <= 4) hipLaunchKernelGGL(k_knn_kdtree<4>, dim3(grid), dim3(256), 0, s, nodes, xy, n, k, cand, root);
     else if (k <= 8) hipLaunchKernelGGL(k_knn_kdtree<8>, dim3(grid), dim3(256), 0, s, nodes, xy, n, k, cand, root);
-    else hipLaunchKernelGGL(k_knn_kdtree<16>, dim3(grid), dim3(256), 0, s, nodes, xy, n, k, cand, root);
+    else if (k <= 16) hipLaunchKernelGGL(k_knn_kdtree<16>, dim3(grid), dim3(256), 0, s, nodes, xy, n, k, cand, root);
+    else if (k <= 32) hipLaunchKernelGGL(k_knn_kdtree<32>, dim3(grid), dim3(256), 0, s, nodes, xy, n, k, cand, root);
+    else hipLaunchKernelGGL(k_knn_kdtree<64>, dim3(grid), dim3(256), 0, s, nodes, xy, n, k, cand, root);  // (round 5: lists of up to 64)
     return hipGetLastError();
 }
 

@@ -1419,7 +1419,7 @@ constexpr size_t kIlsStatic = (size_t)(kIlsNT / 64) * kLkMaxSeg * 16 + 1024;
 // the form applies iff this returns a queue capacity (records per level) > 0
 uint32_t lk_ils_qcap(uint32_t n, uint32_t k, uint32_t max_depth, size_t lds_budget)
 {
-    if (n < 4 || n > 65535u || k == 0 || max_depth == 0 || max_depth > (uint32_t)kLkMaxDepth) return 0u;
+    if (n < 4 || n > 65535u || k == 0 || k > 16u || max_depth == 0 || max_depth > (uint32_t)kLkMaxDepth) return 0u;  // (k <= 16: the task -> (node, candidate) split of a level)
     if (ils_bits(k) * max_depth > 64u) return 0u;
     const size_t fixed = ils_fixed_bytes(n, k) + kIlsStatic;
     if (fixed >= lds_budget) return 0u;

@@ -363,13 +363,17 @@ hipError_t launch_knn(const float2 *xy, uint32_t n, uint32_t k, uint32_t *cand, 
             const uint32_t gq = (n + 15u) / 16u;
             if (k <= 4) hipLaunchKernelGGL((k_knn_quad<4, 16>), dim3(gq), dim3(256), 0, s, xy, n, k, cand);
             else if (k <= 8) hipLaunchKernelGGL((k_knn_quad<8, 16>), dim3(gq), dim3(256), 0, s, xy, n, k, cand);
-            else hipLaunchKernelGGL((k_knn_quad<16, 16>), dim3(gq), dim3(256), 0, s, xy, n, k, cand);
+            else if (k <= 16) hipLaunchKernelGGL((k_knn_quad<16, 16>), dim3(gq), dim3(256), 0, s, xy, n, k, cand);
+            else if (k <= 32) hipLaunchKernelGGL((k_knn_quad<32, 16>), dim3(gq), dim3(256), 0, s, xy, n, k, cand);
+            else hipLaunchKernelGGL((k_knn_quad<64, 16>), dim3(gq), dim3(256), 0, s, xy, n, k, cand);  // (round 5: lists of up to 64, the k-buffer in registers)
             return hipGetLastError();
         }
         const uint32_t gq = (n + 63u) / 64u;
         if (k <= 4) hipLaunchKernelGGL((k_knn_quad<4, 4>), dim3(gq), dim3(256), 0, s, xy, n, k, cand);
         else if (k <= 8) hipLaunchKernelGGL((k_knn_quad<8, 4>), dim3(gq), dim3(256), 0, s, xy, n, k, cand);
-        else hipLaunchKernelGGL((k_knn_quad<16, 4>), dim3(gq), dim3(256), 0, s, xy, n, k, cand);
+        else if (k <= 16) hipLaunchKernelGGL((k_knn_quad<16, 4>), dim3(gq), dim3(256), 0, s, xy, n, k, cand);
+        else if (k <= 32) hipLaunchKernelGGL((k_knn_quad<32, 4>), dim3(gq), dim3(256), 0, s, xy, n, k, cand);
+        else hipLaunchKernelGGL((k_knn_quad<64, 4>), dim3(gq), dim3(256), 0, s, xy, n, k, cand);  // (round 5: lists of up to 64, the k-buffer in registers)
         return hipGetLastError();
     }
 #ifdef TL_TUNE  // one lane per city: a rejected form, tuning build only

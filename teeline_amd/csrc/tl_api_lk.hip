@@ -49,7 +49,7 @@ extern "C" int tl_build_candidates(tl_ctx *c, const float *xy, uint32_t n, uint3
     if (n == 0) return fail(c, TL_ERR_BADARG, "tl_build_candidates: n == 0");
     if (k > n - 1) k = n - 1;  // lin_kernighan.rs:14
     if (k == 0) return TL_OK;
-    if (k > 16) return fail(c, TL_ERR_UNSUPPORTED, "tl_build_candidates: k=%u > 16", k);
+    if (k > 64) return fail(c, TL_ERR_UNSUPPORTED, "tl_build_candidates: k=%u > 64 (the k-nearest buffer of a query lives in registers; the reference's k is unbounded)", k);
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
     if ((rc = ensure(c, c->xy, (size_t)n * 8)) || (rc = ensure(c, c->misc, (size_t)n * k * 4))) return rc;
@@ -64,7 +64,7 @@ extern "C" int tl_build_candidates(tl_ctx *c, const float *xy, uint32_t n, uint3
 int tlapi::nn_seed_dev(tl_ctx *c, const float2 *d_xy, uint32_t n, uint32_t n_nearest, uint32_t *d_path)
 {
     uint32_t k = n_nearest > n - 1 ? n - 1 : n_nearest;
-    if (k > 16) return fail(c, TL_ERR_UNSUPPORTED, "nearest_neighbor: n_nearest=%u > 16", n_nearest);
+    if (k > 64) return fail(c, TL_ERR_UNSUPPORTED, "nearest_neighbor: n_nearest=%u > 64 (the k-nearest buffer of a query lives in registers; the reference's is unbounded)", n_nearest);
     int rc;
     if ((size_t)n + 1024 > (size_t)c->lds_bytes)
         return fail(c, TL_ERR_UNSUPPORTED, "nearest_neighbor: n=%u exceeds the LDS-resident visited flags (%d bytes of LDS)", n, c->lds_bytes);
@@ -163,7 +163,7 @@ static int lk_run(tl_ctx *c, const float *xy, uint32_t n, const float *dm_packed
     if (o.max_depth > tl_lk_deep::lk_max_depth())
         return fail(c, TL_ERR_UNSUPPORTED, "tl_lk: max_depth=%u > %u (the largest chain this build holds; the reference's max_depth is unbounded, mod.rs:1252)",
                     o.max_depth, tl_lk_deep::lk_max_depth());
-    if (o.n_nearest > 16) return fail(c, TL_ERR_UNSUPPORTED, "tl_lk: n_nearest=%u > 16", o.n_nearest);
+    if (o.n_nearest > 64) return fail(c, TL_ERR_UNSUPPORTED, "tl_lk: n_nearest=%u > 64 (the k-nearest buffer of a query lives in registers; the reference's n_nearest is unbounded, mod.rs:1252)", o.n_nearest);
     if (init_pos && !is_permutation(init_pos, n)) return fail(c, TL_ERR_BADARG, "tl_lk: init tour is not a permutation of 0..n-1");
     const auto t0 = std::chrono::steady_clock::now();
     if (stats) memset(stats, 0, sizeof(*stats));

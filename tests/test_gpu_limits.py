@@ -143,9 +143,24 @@ def test_candidate_lists_and_nn_seed_at_large_n(ctx):
     assert np.array_equal(got, want)
     k16 = TA.lin_kernighan.build_candidates(prob(xy[:5000]), 16, ctx=ctx)
     assert np.array_equal(k16, O.build_candidates_kdtree(xy[:5000], 16)[0])
+    # round 5: lists of up to 64 (the reference's n_nearest is an unbounded usize) — 17 / 33 / 64 against the oracle's
+    # kd-tree, brute force the same, one past the limit refused with a message that names it
+    for k in (17, 33, 64):
+        got = TA.lin_kernighan.build_candidates(prob(xy[:3000]), k, ctx=ctx)
+        assert np.array_equal(got, O.build_candidates_kdtree(xy[:3000], k)[0]), k
+    with TA.Context(0, TA.TL_FLAG_KNN_BRUTE) as cb:
+        assert np.array_equal(TA.lin_kernighan.build_candidates(prob(xy[:3000]), 40, ctx=cb), O.build_candidates_kdtree(xy[:3000], 40)[0])
     with pytest.raises(TA.TeelineGpuError) as e:
-        TA.lin_kernighan.build_candidates(prob(xy[:100]), 17, ctx=ctx)
-    assert e.value.code == TA._capi.TL_ERR_UNSUPPORTED
+        TA.lin_kernighan.build_candidates(prob(xy[:100]), 65, ctx=ctx)
+    assert e.value.code == TA._capi.TL_ERR_UNSUPPORTED and "unbounded" in str(e.value)
+    # ... and through the solvers that read them: the NN seed with n_nearest = 40, LK with n_nearest = 20 (chip-wide scans: the LDS form takes k <= 16)
+    sol = TA.nearest_neighbor.solve(prob(xy[:2000]), TA.HeuristicOptions(n_nearest=40), ctx=ctx)
+    rc, route, c = O.nearest_neighbor(xy[:2000], None, 2000, 40)
+    assert list(sol.route()) == route.tolist() and np.float32(sol.total).tobytes() == np.float32(c).tobytes()
+    h20 = TA.HeuristicOptions(epochs=3, platoo_epochs=3, n_nearest=20)
+    s20 = TA.lin_kernighan.solve(prob(xy[:300]), TA.LKOptions(h20, 3), None, None, ctx=ctx, seed=5)
+    rc, r20, c20, st20 = O.lin_kernighan(xy[:300], seed=5, epochs=3, platoo_epochs=3, n_nearest=20, max_depth=3)
+    assert list(s20.route()) == r20.tolist() and np.float32(s20.total).tobytes() == np.float32(c20).tobytes() and s20.stats["sweeps"] == st20["sweeps"]
     n2 = 40000
     sol = TA.nearest_neighbor.solve(prob(xy[:n2]), ctx=ctx)
     rc, route, c = O.nearest_neighbor(xy[:n2], None, n2, 3)
