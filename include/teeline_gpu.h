@@ -164,7 +164,8 @@ const char *tl_last_error(const tl_ctx *ctx); /* ctx may be NULL: last tl_create
 /* CU count, LDS bytes per workgroup and arch name of the context's device. */
 int tl_device_info(const tl_ctx *ctx, int *cus, int *lds_bytes, char *arch, size_t arch_len);
 /* Largest n the LDS-resident REF_ORDER 2-opt kernel takes (tour + coordinates live in one CU's LDS).  tl_two_opt
- * handles larger n (<= 65535) with the HBM-resident variant; the batch / multi-start entries are LDS-only. */
+ * handles larger n with the HBM-resident variant, and so (one descent after the other) do the multi-start and population entries;
+ * the device-resident tl_two_opt_batch_dev and the trace entry are LDS-only. */
 uint32_t tl_two_opt_lds_max_n(const tl_ctx *ctx);
 
 /* ---- numerics self-test -------------------------------------------------------------------------- */
@@ -333,7 +334,7 @@ uint64_t tl_pack_cost_key(float cost, uint32_t restart);
  * REF_ORDER descent, one workgroup per tour, all concurrently; tour r of out_pos / out_costs equals what
  * tl_two_opt returns for it alone (two_opt.rs:7-67 with init_tour = Some(tour r)).  The reference has no
  * batch form: its callers loop over two_opt::solve (the north-star's GA refinement would, too).
- * dm_packed as in tl_two_opt.  n is limited to tl_two_opt_lds_max_n (TL_ERR_UNSUPPORTED beyond). */
+ * dm_packed as in tl_two_opt.  Beyond tl_two_opt_lds_max_n (coordinates) the tours run one after the other through the HBM form. */
 int tl_two_opt_population(tl_ctx *ctx, const float *xy, uint32_t n, const float *dm_packed,
                           const uint32_t *init_pos, uint32_t count, uint32_t *out_pos, float *out_costs,
                           tl_stats *stats);

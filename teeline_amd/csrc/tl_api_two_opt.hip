@@ -484,6 +484,25 @@ __global__ __launch_bounds__(256) void k_shard_key(const float *__restrict__ cos
 }
 }  // namespace
 
+// restart r's start permutation on the host — the same stream as the kernels' (two_opt_ref.hip: draw k = splitmix64_at(seed + r, n - 1 - i) % (i + 1) for
+// i = n-1 .. 1, swaps applied in that order; oracle tlo_restart_perm) — for the descents that run one after the other through the HBM form
+static void restart_perm_host(uint32_t n, uint64_t seed, uint64_t r, std::vector<uint32_t> &perm)
+{
+    perm.resize(n);
+    for (uint32_t i = 0; i < n; ++i) perm[i] = i;
+    const uint64_t s0 = seed + r;
+    for (uint32_t i = n - 1; i >= 1; --i) {
+        uint64_t z = s0 + ((uint64_t)(n - 1 - i) + 1) * 0x9E3779B97F4A7C15ULL;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        z ^= z >> 31;
+        const uint32_t j = (uint32_t)(z % ((uint64_t)i + 1));
+        const uint32_t t = perm[i];
+        perm[i] = perm[j];
+        perm[j] = t;
+    }
+}
+
 // The deal of restarts [first, first + count) over `parts` devices / ranks: contiguous blocks, the first count % parts take one more.
 // Host-only; tl_two_opt_multistart_devices deals with it, and a multi-process job's ranks (teeline_amd/host/multistart.py shard_total)
 // use the same map, so that a run's result does not depend on how it was spread.
@@ -523,6 +542,46 @@ extern "C" int tl_two_opt_multistart_devices(tl_ctx *const *ctxs, int n_ctxs, co
     std::vector<Shard> shard((size_t)n_ctxs);
     for (int d = 0; d < n_ctxs; ++d) (void)tl_multistart_shard(first, count, n_ctxs, d, &shard[d].first, &shard[d].count);
     int rc;
+    if (n > lds_max_n(c0->lds_bytes)) {
+        // beyond the LDS-resident descent (round 5): the restarts one after the other through the HBM form, each
+        // shard on its own context — the same start permutations, so the same tours as a (hypothetical) batch would give
+        if (mode != TL_MODE_REF_ORDER) return fail(c0, TL_ERR_UNSUPPORTED, "batch 2-opt supports TL_MODE_REF_ORDER only");
+        std::vector<uint32_t> perm, pos(n), bestpos(n);
+        uint64_t bestkey = ~0ull;
+        tl_stats acc{};
+        std::vector<float> costs(count);
+        for (int d = 0; d < n_ctxs; ++d)
+            for (uint32_t r = shard[d].first; r < shard[d].first + shard[d].count; ++r) {
+                restart_perm_host(n, seed, r, perm);
+                float cst = 0.f;
+                tl_stats st1{};
+                if ((rc = two_opt_ref_large(ctxs[d], xy, n, perm.data(), pos.data(), &cst, &st1))) {
+                    if (d) fail(c0, rc, "device shard %d: %s", d, ctxs[d]->err.c_str());
+                    return rc;
+                }
+                costs[r - first] = cst;
+                acc.sweeps += st1.sweeps;
+                acc.moves += st1.moves;
+                acc.reversed += st1.reversed;
+                acc.candidates += st1.candidates;
+                acc.kernel_ms += st1.kernel_ms;
+                const uint64_t key = tl_pack_cost_key(cst, r);
+                if (key < bestkey) {
+                    bestkey = key;
+                    bestpos = pos;
+                }
+            }
+        memcpy(out_best_pos, bestpos.data(), (size_t)n * 4);
+        const uint32_t br = (uint32_t)(bestkey & 0xFFFFFFFFull);
+        if (out_best_cost) *out_best_cost = costs[br - first];
+        if (out_best_restart) *out_best_restart = br;
+        if (out_costs) memcpy(out_costs, costs.data(), (size_t)count * 4);
+        if (stats) {
+            *stats = acc;
+            stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+        return TL_OK;
+    }
     for (int d = 0; d < n_ctxs; ++d)
         if (shard[d].count && (rc = multistart_begin(ctxs[d], xy, n, seed, shard[d].first, shard[d].count, mode))) {
             if (d) fail(c0, rc, "device shard %d: %s", d, ctxs[d]->err.c_str());
@@ -627,6 +686,26 @@ extern "C" int tl_two_opt_population(tl_ctx *c, const float *xy, uint32_t n, con
     const auto t0 = std::chrono::steady_clock::now();
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
+    if (!dm_packed && n > lds_max_n(c->lds_bytes)) {
+        // beyond the LDS-resident descent: the tours one after the other through the HBM form (every individual's result equals tl_two_opt on it alone)
+        tl_stats acc{};
+        for (uint32_t r = 0; r < count; ++r) {
+            float cst = 0.f;
+            tl_stats st1{};
+            if ((rc = two_opt_ref_large(c, xy, n, init_pos + (size_t)r * n, out_pos + (size_t)r * n, &cst, &st1))) return rc;
+            if (out_costs) out_costs[r] = cst;
+            acc.sweeps += st1.sweeps;
+            acc.moves += st1.moves;
+            acc.reversed += st1.reversed;
+            acc.candidates += st1.candidates;
+            acc.kernel_ms += st1.kernel_ms;
+        }
+        if (stats) {
+            *stats = acc;
+            stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+        return TL_OK;
+    }
     const size_t dm_bytes = dm_packed ? (size_t)n * (n - 1) / 2 * 4 : 0;
     if ((rc = ensure(c, c->init, (size_t)count * n * 4)) || (rc = ensure(c, c->out_pos, (size_t)count * n * 4)) ||
         (rc = ensure(c, c->out_cost, (size_t)count * 4)) || (rc = ensure(c, c->out_stats, (size_t)count * TL_STATS_STRIDE * 8)))

@@ -41,10 +41,23 @@ def test_two_opt_size_limits(ctx):
         assert st2["moves"] == 0 and np.float32(c2).tobytes() == np.float32(sol.total).tobytes()
         assert sol.stats["candidates"] == sol.stats["sweeps"] * ((n - 3) * (n - 2) // 2)
     # (the HBM-resident form has had 64-bit (i, j) keys since round 4: no 65 535 limit any more — test_two_opt_beyond_65535_cities)
-    # multi-start / population are LDS-only
-    with pytest.raises(TA.TeelineGpuError) as e:
-        TA.two_opt.multistart(prob(O.synth_xy(nmax + 1, seed=11)), 2, seed=1, ctx=ctx)
-    assert e.value.code == TA._capi.TL_ERR_UNSUPPORTED
+    # multi-start / population beyond the LDS-resident descent (round 5): the descents run one after the other through
+    # the HBM form.  Population: two nearly optimal tours (the NN seed and the NN seed with a stretch reversed) against tl_two_opt on each;
+    # multi-start: ONE seeded restart at the limit + 1 (a random start of 16 K cities is seconds of descent) — its start permutation is the
+    # kernels' own stream (checked against the oracle's tlo_restart_perm through the result of the single descent from it).
+    n = nmax + 1
+    xy = O.synth_xy(n, seed=11)
+    rc, nn, cnn = O.nearest_neighbor(xy, None, n, 3)
+    t2 = nn.copy()
+    t2[100:900] = t2[100:900][::-1].copy()
+    sols = TA.two_opt.solve_population(prob(xy), [[int(v) for v in nn], [int(v) for v in t2]], ctx=ctx)
+    for tour, sol in zip((nn, t2), sols):
+        one = TA.two_opt.solve(prob(xy), None, None, [int(v) for v in tour], ctx=ctx)
+        assert list(sol.route()) == list(one.route()) and np.float32(sol.total).tobytes() == np.float32(one.total).tobytes()
+    ms, costs = TA.two_opt.multistart(prob(xy), 1, seed=7, first=3, ctx=ctx, return_costs=True)
+    one = TA.two_opt.solve(prob(xy), None, None, [int(v) for v in O.restart_perm(n, 7, 3)], ctx=ctx)
+    assert list(ms.route()) == list(one.route()) and np.float32(ms.total).tobytes() == np.float32(one.total).tobytes()
+    assert ms.stats["best_restart"] == 3 and np.float32(costs[0]).tobytes() == np.float32(one.total).tobytes()
 
 
 def test_two_opt_beyond_65535_cities(ctx):
