@@ -344,10 +344,19 @@ def test_config5_size_and_lds_limit(ctx):
         route, cost, st = gpu_two_opt(ctx, xym, None, m, nnm)
         rc, again, c2, st2 = O.two_opt(xym, None, m, init=route, max_candidates=1)
         assert st2["moves"] == 0 and c2 == cost and O.validate_tour(route)
-    # the batch entry stays LDS-only and says so loudly
-    with pytest.raises(TA.TeelineGpuError) as e:
-        TA.two_opt.multistart(TA.TspProblem(np.arange(nmax + 1), big), 2, ctx=ctx)
-    assert e.value.code == -6  # TL_ERR_UNSUPPORTED — never a CPU fallback
+    # (round 5: multi-start / population beyond the limit run through the HBM form — tests/test_gpu_limits.py::test_two_opt_size_limits;
+    #  the device-resident batch entry stays LDS-only and says so loudly, never a CPU fallback)
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    m = nmax + 1
+    d_xy = torch.from_numpy(np.ascontiguousarray(big[:m])).to(dev)
+    d_pos = torch.empty((1, m), dtype=torch.int32, device=dev)
+    d_cost = torch.empty(1, dtype=torch.float32, device=dev)
+    d_st = torch.zeros((1, 16), dtype=torch.int64, device=dev)
+    rc = ctx.lib.tl_two_opt_batch_dev(ctx.handle, d_xy.data_ptr(), m, None, 1, 0, 1, 0, d_pos.data_ptr(), d_cost.data_ptr(), d_st.data_ptr(),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == -6  # TL_ERR_UNSUPPORTED
 
 
 def test_lds_limit_random_start_matches_oracle(ctx):
