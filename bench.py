@@ -354,7 +354,7 @@ XCU_ROUND_US = (1.4, 2.1)  # profiles/r02_xcu_sync_probe.json: one cross-CU agre
 SCALING_NOTE = ("value / weak_per_gpu = R restarts PER GPU (one descent per CU; weak scaling, the headline); strong_256_total = 256 restarts IN ALL "
                 "dealt over the ranks (configs[3] as worded).  The strong reading is flat by design: a descent is sequential and holds one CU, a batch "
                 "lasts as long as its slowest descent whether a GPU runs 256 or 32, so efficiency ~1/N.  Spreading ONE descent over CUs does not pay: "
-                "a cross-CU round costs 1.4-2.1 us (profiles/r02_xcu_sync_probe.json), about one whole 2.2 us step (DESIGN.md §6)")
+                "a cross-CU round costs 1.4-2.1 us among <= 32 workgroups (profiles/r02_xcu_sync_probe.json) — about one whole 2.2 us step — and ~10 us among 256 (NOTEBOOK r5.6)")
 
 LINE_LIMIT = 4096  # the driver stopped parsing the line when it grew to 22 KB; the LAST stdout line stays below this
 SIDECAR = "bench_extras.json"
