@@ -361,6 +361,11 @@ int tl_two_opt_batch_dev(tl_ctx *ctx, const float *d_xy, uint32_t n, const uint3
 int tl_last_kernel_ms(tl_ctx *ctx, double *ms);
 int tl_dm_build_dev(tl_ctx *ctx, const float *d_xy, uint32_t n, int dist, int layout, float *d_out,
                     void *stream);
+/* Diagnostics: the 16 kernel-side counters of descent 0 of the most recent tl_two_opt / tl_two_opt_trace / tl_two_opt_population /
+ * tl_two_opt_multistart call of this context (host-buffer entries; words 0-4: sweeps, moves, reversed elements, status, steps; the
+ * rest is per kernel — matrix form: 5 = steps of sweeps run on the lists, 6 = such sweeps, 7 = their rows that walked the matrix rows).
+ * Not part of the reference's interface; tests and timing scripts read which form ran from it. */
+int tl_two_opt_last_counters(tl_ctx *ctx, uint64_t out[16]);
 
 #ifdef __cplusplus
 }

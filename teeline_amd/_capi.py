@@ -45,7 +45,7 @@ SYMBOLS = [
     "tl_two_opt_batch_dev", "tl_last_kernel_ms", "tl_dm_build_dev", "tl_build_candidates", "tl_nearest_neighbor",
     "tl_or_opt", "tl_or_opt_find_best_move", "tl_selftest_sqrt", "tl_two_opt_population", "tl_dm_is_euc2d",
     "tl_two_opt_multistart_devices", "tl_two_opt_trace", "tl_three_opt_trace", "tl_lk_trace", "tl_or_opt_trace",
-    "tl_lk_live", "tl_two_opt_neighbour_lists", "tl_two_opt_plan", "tl_multistart_shard",
+    "tl_lk_live", "tl_two_opt_neighbour_lists", "tl_two_opt_plan", "tl_multistart_shard", "tl_two_opt_last_counters",
 ]
 
 
@@ -122,6 +122,7 @@ def load():
     L.tl_pack_cost_key.restype = u64
     L.tl_two_opt_batch_dev.argtypes = [vp, vp, u32, vp, u64, u32, u32, i32, vp, vp, vp, vp]
     L.tl_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_double)]
+    L.tl_two_opt_last_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.tl_dm_build_dev.argtypes = [vp, vp, u32, i32, i32, vp, vp]
     L.tl_build_candidates.argtypes = [vp, vp, u32, u32, vp]
     L.tl_nearest_neighbor.argtypes = [vp, vp, vp, u32, u32, vp, f32p]

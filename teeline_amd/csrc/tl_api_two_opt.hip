@@ -8,6 +8,15 @@ using namespace tlapi;
 #ifndef TL_NL_MIN_N
 #define TL_NL_MIN_N 400u  // smallest instance whose descents build and read the neighbour lists
 #endif
+#ifndef TL_DM_LISTS_MIN_N
+#define TL_DM_LISTS_MIN_N 200u  // matrix form: smallest instance whose descents build and read the lists of the late sweeps
+#endif
+#ifndef TL_DM_LONG_MAX
+#define TL_DM_LONG_MAX 256u  // ... a sweep runs on them while at most this many cities have a tour edge beyond their 16th distance (the descent's list holds 256)
+#endif
+#ifndef TL_DM_MOVES_DIV
+#define TL_DM_MOVES_DIV 8u   // ... and the sweep before it applied at most n / 8 moves
+#endif
 #ifndef TL_NL_SWEEP_MIN
 #define TL_NL_SWEEP_MIN 3  // first sweep of a descent that may run in the late phase (tuning builds override it) ...
 #endif
@@ -59,9 +68,23 @@ static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uin
         // the packed triangle (reference layout) is expanded to a full row-major matrix once per call: a row scan then
         // gathers inside one 4n-byte row instead of one cache line per column (two_opt_dm.hip)
         int rc2;
-        if ((rc2 = ensure(c, c->dmfull, (size_t)n * n * 4))) return rc2;
+        // ... and, where the descents' late sweeps can use them, the lists cut from it (two_opt_dm.hip: the 16 nearest per city and the
+        // reverse relation, one pass of a wave per matrix row), behind the matrix in the same buffer
+        const bool lists = !(c->flags & (TL_FLAG_NO_PRUNE | TL_FLAG_2OPT_NO_NL)) && (n >= TL_DM_LISTS_MIN_N || (c->flags & TL_FLAG_2OPT_NL_ALWAYS)) &&
+                           two_opt_ref_dm_late_fits(n, c->lds_bytes);
+        const size_t full_bytes = ((size_t)n * n * 4 + 255u) & ~(size_t)255u;
+        if ((rc2 = ensure(c, c->dmfull, full_bytes + (lists ? dm_lists_ws_bytes(n) : 0u)))) return rc2;
         HIPCHK(c, launch_dm_expand_full(d_dm, n, (float *)c->dmfull.p, s));
         A.dm_full = (const float *)c->dmfull.p;
+        if (lists) {
+            HIPCHK(c, launch_dm_lists_build(A.dm_full, n, (unsigned char *)c->dmfull.p + full_bytes, &A.dml, s));
+            A.dml.long_max = (c->flags & TL_FLAG_2OPT_NL_ALWAYS) ? 256u : (uint32_t)TL_DM_LONG_MAX;
+            A.dml.moves_max = (c->flags & TL_FLAG_2OPT_NL_ALWAYS) ? 0xFFFFFFFFu : (n / (uint32_t)TL_DM_MOVES_DIV > 8u ? n / (uint32_t)TL_DM_MOVES_DIV : 8u);
+#ifdef TL_TUNE  // tuning builds only: the product library never reads the environment
+            if (const char *e = getenv("TL_DM_LONG_MAX")) A.dml.long_max = (uint32_t)atoi(e);
+            if (const char *e = getenv("TL_DM_MOVES_MAX")) A.dml.moves_max = (uint32_t)atoi(e);
+#endif
+        }
         HIPCHK(c, launch_two_opt_ref_dm(A, count, c->lds_bytes, s));
     } else {
         const int force_nt = (c->flags & TL_FLAG_2OPT_NT256) ? 256 : (c->flags & TL_FLAG_2OPT_NT512) ? 512 : 0;
@@ -107,6 +130,18 @@ static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uin
     HIPCHK(c, hipEventRecord(c->ev1, s));
     c->ev_valid = true;
     return ws_mark(c, s);
+}
+
+extern "C" int tl_two_opt_last_counters(tl_ctx *c, uint64_t out[16])
+{
+    TL_ENTER(c);
+    if (!c || !out) return fail(c, TL_ERR_BADARG, "tl_two_opt_last_counters: NULL argument");
+    static_assert(TL_STATS_STRIDE == 16, "the header documents 16 words");
+    if (!c->out_stats.p || c->out_stats.cap < (size_t)TL_STATS_STRIDE * 8) return fail(c, TL_ERR_BADARG, "tl_two_opt_last_counters: no 2-opt call on this context yet");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->out_stats.p, (size_t)TL_STATS_STRIDE * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return TL_OK;
 }
 
 extern "C" int tl_two_opt_plan(uint32_t n, uint32_t count, int cus, int lds_bytes, uint32_t flags, int *threads, int *late_phase)

@@ -63,6 +63,24 @@ struct TwoOptNl {
 size_t two_opt_nl_ws_bytes(uint32_t n);
 hipError_t launch_two_opt_nl_build(const float2 *xy, uint32_t n, void *ws, bool fresh, TwoOptNl *out, hipStream_t s, int form = 0);  // form 1: the workgroup-per-city kernel (cross-check)
 
+// two_opt_dm.hip — the matrix form's lists for its late sweeps: per city the 16 nearest by its matrix row and the
+// reverse relation, cut from the full matrix once per call and shared by every descent of the batch
+constexpr int kDmK = 16;     // nearest cities per city (the c side of a row: D[a][c] < D[a][b])
+constexpr int kDmInv = 48;   // reverse-list slots per city (the e side: D[b][e] < D[c][e]; lanes 16..63 of a row's pass)
+struct DmLists {
+    const uint16_t *id;       // [n][kDmK] nearest cities in (distance, id) order, the city itself excluded; nullptr = no lists
+    const float *d;           // [n][kDmK] their distances
+    const float *dk;          // [n] the kDmK-th of them (NaN where the row holds a NaN: never listed)
+    const uint16_t *inv_id;   // [n][kDmInv] the cities that hold this one among their kDmK (0xFFFF: empty slot)
+    const float *inv_d;       // [n][kDmInv] D[that city][this one]
+    const uint32_t *inv_cnt;  // [n] entries offered (beyond kDmInv: the list is incomplete, the row walks the matrix row)
+    uint32_t long_max;        // a sweep runs on the lists while at most this many cities have a tour edge beyond their dk
+    uint32_t moves_max;       // ... and the sweep before it applied at most this many moves
+};
+size_t dm_lists_ws_bytes(uint32_t n);
+bool two_opt_ref_dm_late_fits(uint32_t n, int lds_budget);  // the late sweeps' state fits the LDS beside the tour
+hipError_t launch_dm_lists_build(const float *full, uint32_t n, void *ws, DmLists *out, hipStream_t s);
+
 struct TwoOptBatchArgs {
     const float2 *xy;        // n cities, city order
     const float *dm;         // packed lower triangle (matrix kernels) or nullptr
@@ -84,6 +102,7 @@ struct TwoOptBatchArgs {
     const uint2 *fx_xy;      // LDS kernel, grid-coordinate form: per city {x (20 bits) | y low 12 bits << 20, y high 8 bits} (k_fx_encode)
     double fx_inv;           // ... fl64(1 / S) of its decimal grid, 0 = plain float2 form
     TwoOptNl nl;             // LDS kernel, 16-wave float2 form: neighbour lists for the late sweeps (rec == nullptr: off)
+    DmLists dml;             // matrix kernel: lists for its late sweeps (id == nullptr: off)
 };
 
 // two_opt_ref.hip

@@ -75,6 +75,12 @@ class Context:
         self.check(self._lib.tl_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
 
+    def two_opt_last_counters(self):
+        """tl_two_opt_last_counters: the 16 kernel-side counters of descent 0 of the most recent host-buffer 2-opt call (diagnostics)."""
+        out = (C.c_uint64 * 16)()
+        self.check(self._lib.tl_two_opt_last_counters(self._h, out))
+        return [int(v) for v in out]
+
 
 _default = threading.local()
 

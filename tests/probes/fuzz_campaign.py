@@ -52,7 +52,20 @@ with TA.Context(0) as ctx, TA.Context(0, TA.TL_FLAG_NO_PRUNE) as ctx2, TA.Contex
         if seed % 3 == 2: cases.append(("nl_nt256", prob, ctx9))  # ... and the 4-wave form (four per CU)
         if n <= 1500 and seed % 3 == 0:
             dm = TA.distance_matrix.build(np.arange(n), xy, ctx=ctx)
-            cases.append(("matrix", TA.TspProblem(np.arange(n), xy, TA.distance_matrix.DistanceMatrix(n, dm.items, np.arange(n), "explicit")), ctx))
+            pm = TA.TspProblem(np.arange(n), xy, TA.distance_matrix.DistanceMatrix(n, dm.items, np.arange(n), "explicit"))
+            cases.append(("matrix", pm, ctx))
+            cases.append(("matrix_nl", pm, ctx6))  # its late sweeps on lists wherever they fit (two_opt_dm.hip; by default from n = 200)
+        if os.environ.get("FUZZ_DM"):  # the matrix form only, every seed: the Euclidean matrix and a non-metric one (independent weights, ties)
+            n = int(rng.integers(8, 1400))
+            xy = np.ascontiguousarray(xy[:n] if len(xy) >= n else rng.random((n, 2)) * 1000, dtype=np.float32)
+            init = None if start == 0 else (O.restart_perm(n, seed, 0) if start == 1 else O.nearest_neighbor(xy, None, n, 3)[1])
+            packed = O.dm_build_packed(xy)
+            if seed % 2:
+                m = n * (n - 1) // 2
+                packed = (rng.integers(0, int(rng.integers(3, 2000)), m).astype(np.float32) if seed % 4 == 1 else rng.random(m, dtype=np.float32) * np.float32(100.0))
+            rc, route, cost, st = O.two_opt(None, packed, n, init=init)
+            pm = TA.TspProblem(np.arange(n), xy, TA.distance_matrix.DistanceMatrix(n, packed, np.arange(n), "explicit"))
+            cases = [("matrix", pm, ctx), ("matrix_nl", pm, ctx6)] + ([("matrix_no_nl", pm, ctx7)] if seed % 4 == 0 else [])
         for name, p, c in cases:
             sol = TA.two_opt.solve(p, None, None, None if init is None else [int(v) for v in init], ctx=c)
             a, b = np.float32(sol.total), np.float32(cost)
