@@ -938,6 +938,38 @@ def main():
                              "note": "16 algorithmic bytes per candidate (perm[j+1], D[a][c], D[b][e], D[c][e]; SURVEY.md §8(d)) against the "
                                      "L2-served gather rate of the guide; the descent is bound by the chain of dependent latencies of a "
                                      "step, not by that bandwidth"}}
+            # round 5: the late sweeps on lists cut from the matrix rows (two_opt_dm.hip) — which sweeps took them, and the same runs with
+            # the lists off (TL_FLAG_2OPT_NO_NL: the round-4 kernel's block shapes throughout); a larger matrix shows the n^2 / n gap
+            for name, init in (("nn_start", nn2), ("identity_start", None)):
+                TA.two_opt.solve(pm2, None, None, init, ctx=ctx)
+                cnt = ctx.two_opt_last_counters()
+                cfg1[name].update(steps=cnt[4], steps_on_lists=cnt[5], sweeps_on_lists=cnt[6], rows_walking_matrix_rows_wave0=cnt[7], rows_from_cached_records_wave0=cnt[8])
+            with TA.Context(local, TA.TL_FLAG_2OPT_NO_NL) as c3:
+                off = {}
+                for name, init in (("nn_start", nn2), ("identity_start", None)):
+                    for _ in range(2):
+                        so = TA.two_opt.solve(pm2, None, None, init, ctx=c3)
+                    assert list(so.route()) == list(TA.two_opt.solve(pm2, None, None, init, ctx=ctx).route()), "lists on / off: another tour"
+                    off[name + "_kernel_ms"] = so.stats["kernel_ms"]
+                for _ in range(2):
+                    so = TA.two_opt.solve_population(pm2, pop, ctx=c3)
+                off["population_256_kernel_ms"] = so[0].stats["kernel_ms"]
+                cfg1["without_lists"] = off
+                nb = 3000
+                xyb = TA.synth.synth_xy(nb)
+                dmb = TA.distance_matrix.build(np.arange(nb), xyb, ctx=ctx)
+                pmb = TA.TspProblem(np.arange(nb), xyb, TA.distance_matrix.DistanceMatrix(nb, dmb.items, np.arange(nb), "explicit"))
+                popb = [[int(v) for v in TA.synth.restart_perm(nb, a.seed, r)] for r in range(256)]
+                big = {}
+                for label, cx in (("with_lists", ctx), ("without_lists", c3)):
+                    for _ in range(2):
+                        sb = TA.two_opt.solve_population(pmb, popb, ctx=cx)
+                    big[label] = {"kernel_ms": sb[0].stats["kernel_ms"], "candidates_per_s": sb[0].stats["candidates"] / (sb[0].stats["kernel_ms"] * 1e-3),
+                                  "best_cost": float(min(float(s_.total) for s_ in sb))}
+                assert big["with_lists"]["best_cost"] == big["without_lists"]["best_cost"]
+                cfg1["population_256_n3000"] = big
+            cfg1["lists_note"] = ("sweeps that follow one with at most n^2 / 4000 moves, while at most 256 cities have a tour edge beyond their 16th-nearest distance, "
+                                  "decide a row from a's 16 nearest, b's reverse list and the long cities (DESIGN.md §4.4); same tours, asserted")
             extras["two_opt_matrix_in_hbm_n1002"] = cfg1
             n3 = 1002
             p3 = TA.TspProblem(np.arange(n3), TA.synth.synth_xy(n3))

@@ -88,8 +88,12 @@ typedef enum tl_mode {
 #define TL_FLAG_2OPT_NT256 (1u << 15)      /* LDS 2-opt: every descent on 4 waves (default: only when four descents share a CU)  */
 #define TL_FLAG_2OPT_FX (1u << 16)         /* LDS 2-opt: the grid-coordinate form (5 B per point) wherever the instance lies on a decimal grid */
 #define TL_FLAG_2OPT_NO_NL (1u << 18)      /* LDS 2-opt: never read neighbour lists — every pruned row walks its tiles (default: rows of the
-                                              late sweeps (once a sweep has applied fewer than n / 40 moves) of an instance with n >= 400 read the lists, csrc/two_opt_nl.hip)               */
-#define TL_FLAG_2OPT_NL_ALWAYS (1u << 19)  /* LDS 2-opt: neighbour-list rows at every n they fit and from the second sweep on            */
+                                              late sweeps (once a sweep has applied fewer than n / 40 moves) of an instance with n >= 400 read the lists, csrc/two_opt_nl.hip).
+                                              Matrix form (dm_packed): never cut lists from the matrix rows — every row walks its matrix rows (default: from
+                                              n = 200, a sweep that follows one with at most n^2 / 4000 moves decides a row from a's 16 nearest cities, b's
+                                              reverse list and the cities with a long tour edge, csrc/two_opt_dm.hip; same tours either way)                  */
+#define TL_FLAG_2OPT_NL_ALWAYS (1u << 19)  /* LDS 2-opt: neighbour-list rows at every n they fit and from the second sweep on; matrix form: list
+                                              rows at every n >= 8 and in every sweep that has at most 256 cities with a long tour edge              */
 #define TL_FLAG_LK_CHIP_WIDE (1u << 20)    /* tl_lk: chip-wide scans at every n (default: an instance whose search state fits one CU's LDS runs its
                                               lk_pass in ONE workgroup with all state in LDS, k_lk_ils in csrc/lk.hip — up to n = 700, and wherever
                                               it fits (n ~ 3000) with epochs and platoo_epochs >= 64)                                            */

@@ -28,7 +28,7 @@ with TA.Context(0) as ctx:
 ns = [int(v) for v in sys.argv[1:]] or [1002]
 env0 = dict(os.environ, TEELINE_GPU_LIB=os.path.join(ROOT, "teeline_amd", "libteeline_gpu_tune.so"))
 for n in ns:
-    for lm, mm in ((0, 0), (64, 10**9), (256, 10**9), (256, n // 4), (256, n // 8), (256, n // 16), (256, n // 40), (128, n // 8), (64, n // 8)):
+    for lm, mm in ((0, 0), (256, 10**9), (256, n), (256, n // 2), (256, n // 4), (256, n // 8), (256, n // 16), (128, 10**9), (128, n // 4)):
         env = dict(env0, TL_DM_LONG_MAX=str(lm), TL_DM_MOVES_MAX=str(mm))
         r = subprocess.run([sys.executable, "-c", CHILD, str(n)], env=env, capture_output=True, text=True)
         print(f"n={n} long_max {lm:4d} moves_max {mm:10d}: {r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:]}", flush=True)

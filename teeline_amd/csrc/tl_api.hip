@@ -143,7 +143,7 @@ extern "C" void tl_destroy(tl_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->ws_pending) (void)hipEventSynchronize(c->ev_ws);
-    for (DevBuf *b : {&c->xy, &c->dm, &c->init, &c->out_pos, &c->out_cost, &c->out_stats, &c->misc, &c->work, &c->dmfull, &c->kd, &c->fx, &c->nl})
+    for (DevBuf *b : {&c->xy, &c->dm, &c->init, &c->out_pos, &c->out_cost, &c->out_stats, &c->misc, &c->work, &c->dmfull, &c->kd, &c->fx, &c->nl, &c->dmx})
         if (b->p) (void)hipFree(b->p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);

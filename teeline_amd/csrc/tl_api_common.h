@@ -44,7 +44,7 @@ struct tl_ctx {
     int cus = 0, lds_bytes = 0;
     std::string arch;
     std::string err;
-    DevBuf xy, dm, init, out_pos, out_cost, out_stats, misc, work, dmfull, kd, fx, nl;
+    DevBuf xy, dm, init, out_pos, out_cost, out_stats, misc, work, dmfull, kd, fx, nl, dmx;  // dmx: matrix-form 2-opt, the descents' per-city records of their late sweeps
     uint32_t dm_n = 0;
     int dm_layout = -1;
     // which host thread is inside an entry point with this context (default id: none) and how deep (entries call entries)

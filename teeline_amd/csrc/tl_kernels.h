@@ -79,6 +79,7 @@ struct DmLists {
 };
 size_t dm_lists_ws_bytes(uint32_t n);
 bool two_opt_ref_dm_late_fits(uint32_t n, int lds_budget);  // the late sweeps' state fits the LDS beside the tour
+size_t two_opt_ref_dm_late_work_bytes(uint32_t n, uint32_t count);  // ... and the descents' per-city records in HBM (TwoOptBatchArgs::work)
 hipError_t launch_dm_lists_build(const float *full, uint32_t n, void *ws, DmLists *out, hipStream_t s);
 
 struct TwoOptBatchArgs {

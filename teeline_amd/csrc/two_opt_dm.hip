@@ -36,6 +36,7 @@ constexpr uint32_t kDmChain = TL_DM_CHAIN;  // improving moves one wave may chai
 #define TL_DM_WARM_MB 32
 #endif
 constexpr size_t kDmWarmBytes = (size_t)TL_DM_WARM_MB << 20;  // matrices up to this size are read once at the start of a descent (L2 / MALL warm-up)
+constexpr uint32_t kDmXl = 32;        // ... and entries of a city's cached "nearer than its successor" record
 constexpr uint32_t kDmLongCap = 256;  // cities with a tour edge beyond their kDmK-th distance a descent can hold (late sweeps)
 #ifndef TL_DM_LATE_ROWS
 #define TL_DM_LATE_ROWS 2
@@ -206,7 +207,10 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
 
     // ---- late sweeps (LATE): state and the decision taken where a sweep begins
     bool late = false;
-    uint32_t n_late_steps = 0, n_late_sweeps = 0, n_full_rows = 0;
+    uint32_t n_late_steps = 0, n_late_sweeps = 0, n_full_rows = 0, n_xl_rows = 0;
+    // per descent, in HBM: for a city whose row has been walked as `a`, the cities nearer than its tour successor was then
+    uint2 *__restrict__ xlist = LATE ? reinterpret_cast<uint2 *>(A.work) + (size_t)d * ((size_t)n * (kDmXl + 1u)) : nullptr;
+    uint2 *__restrict__ xmeta = LATE ? xlist + (size_t)n * kDmXl : nullptr;  // {entries (0xFFFFFFFF: none), bits of the D[a][b] they were cut for}
     const uint16_t *__restrict__ nlid = A.dml.id;
     const float *__restrict__ nld = A.dml.d;
     const uint16_t *__restrict__ invid = A.dml.inv_id;
@@ -249,7 +253,10 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
         if (late) ++n_late_sweeps;
     };
     if (LATE) {
-        for (uint32_t k = tid; k < n; k += kDmNT) dkl[k] = A.dml.dk[k];
+        for (uint32_t k = tid; k < n; k += kDmNT) {
+            dkl[k] = A.dml.dk[k];
+            xmeta[k] = make_uint2(0xFFFFFFFFu, 0u);
+        }
         if (tid < kDmNT / 64) hkey[tid] = kNoKey;
         TL_SYNC();
         if (n >= 4) sweep_begin(0xFFFFFFFFu);
@@ -282,6 +289,10 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
         sweep_begin((uint32_t)(moves - sweep_m0));
         sweep_m0 = moves;
     };
+    // 32-bit byte offsets from a uniform base (global_load with an SGPR base and a VGPR offset, no 64-bit address arithmetic per lane):
+    // the late sweeps' state limits n to ~10^4, so the matrix stays below 2^29 bytes
+    auto ld_f = [](const float *base, uint32_t idx) -> float { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (idx << 2)); };
+    auto ld_h = [](const uint16_t *base, uint32_t idx) -> uint32_t { return *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(base) + (idx << 1)); };
     // ---- the sweeps that run on the lists: a loop of their own, so that the other block shapes' loop carries none of their state
     auto late_sweeps = [&]() {
         while (late && !done) {
@@ -336,9 +347,9 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
                     float ld[kDmLateRows];
     #pragma unroll
                     for (uint32_t q = 0; q < kDmLateRows; ++q) {
-                        const size_t at = aside ? (size_t)ra[q] * kDmK + lane : (size_t)rb[q] * kDmInv + (lane - (uint32_t)kDmK);
-                        lu[q] = aside ? nlid[at] : invid[at];
-                        ld[q] = aside ? nld[at] : invd[at];
+                        const uint32_t at = aside ? ra[q] * (uint32_t)kDmK + lane : rb[q] * (uint32_t)kDmInv + (lane - (uint32_t)kDmK);
+                        lu[q] = ld_h(aside ? nlid : invid, at);
+                        ld[q] = ld_f(aside ? nld : invd, at);
                         cntb[q] = invcnt[rb[q]];
                     }
                     uint32_t bj[kDmLateRows];       // per lane: its best (smallest) improving column of row q, and that candidate's two new edges
@@ -359,7 +370,7 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
     #pragma unroll
                         for (uint32_t q = 0; q < kDmLateRows; ++q) {
                             c_v[q] = ev && j >= rjmin[q];
-                            c_gbe[q] = dm[c_v[q] ? (size_t)rb[q] * n + e : (size_t)0];  // (lanes without a candidate read one shared word: no branch, and the
+                            c_gbe[q] = ld_f(dm, c_v[q] ? rb[q] * n + e : 0u);  // (lanes without a candidate read one shared word: no branch, and the
                                                                                         //  outstanding loads stay countable for s_waitcnt)
                         }
                     }
@@ -382,10 +393,10 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
     #pragma unroll
                         for (uint32_t q = 0; q < kDmLateRows; ++q) {  // C: D[a][c] behind D[b][e] < D[c][e] (issued with the gathers of A and B)
                             c_v[q] = c_v[q] && c_gbe[q] < c_dce;
-                            c_gac[q] = dm[c_v[q] ? (size_t)ra[q] * n + c_c : (size_t)0];
+                            c_gac[q] = ld_f(dm, c_v[q] ? ra[q] * n + c_c : 0u);
                         }
 #pragma unroll
-                        for (uint32_t q = 0; q < kDmLateRows; ++q) gd[q] = dm[val[q] ? (size_t)(aside ? rb[q] : ra[q]) * n + oth[q] : (size_t)0];
+                        for (uint32_t q = 0; q < kDmLateRows; ++q) gd[q] = ld_f(dm, val[q] ? (aside ? rb[q] : ra[q]) * n + oth[q] : 0u);
 #pragma unroll
                         for (uint32_t q = 0; q < kDmLateRows; ++q) {
                             const float dac = aside ? ld[q] : gd[q], dbe = aside ? gd[q] : ld[q];
@@ -418,12 +429,12 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
     #pragma unroll
                         for (uint32_t q = 0; q < kDmLateRows; ++q) {
                             v2[q] = ev && j >= rjmin[q];
-                            gbe[q] = dm[v2[q] ? (size_t)rb[q] * n + e : (size_t)0];
+                            gbe[q] = ld_f(dm, v2[q] ? rb[q] * n + e : 0u);
                         }
     #pragma unroll
                         for (uint32_t q = 0; q < kDmLateRows; ++q) {
                             v2[q] = v2[q] && gbe[q] < dce;
-                            gac[q] = dm[v2[q] ? (size_t)ra[q] * n + c : (size_t)0];
+                            gac[q] = ld_f(dm, v2[q] ? ra[q] * n + c : 0u);
                         }
     #pragma unroll
                         for (uint32_t q = 0; q < kDmLateRows; ++q) {
@@ -453,10 +464,30 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
                                 posted = true;
                                 continue;
                             }
-                            ++n_full_rows;
                             const float *__restrict__ rowa = dm + (size_t)ra[q] * n;
                             const float *__restrict__ rowb = dm + (size_t)rb[q] * n;
-                            if (!a_listed) {  // row a, every city as c: eight coalesced loads in flight, then the survivors' D[b][e] together
+                            // Row a's cities nearer than b are the same every time the scan meets this row (the matrix does not change) as long
+                            // as D[a][b] has not grown: the first walk leaves them in the descent's cache (<= kDmXl of them; more: no entry),
+                            // later ones read that one record.  A tour edge beyond the 16th distance tends to stay for many steps — the rows
+                            // ahead of the scan are decided again by every step until it reaches them — and for good once 2-opt cannot mend it.
+                            uint2 xm = make_uint2(0xFFFFFFFFu, 0u);
+                            if (!a_listed) xm = xmeta[ra[q]];
+                            if (!a_listed && xm.x <= kDmXl && rdab[q] <= __builtin_bit_cast(float, xm.y)) {
+                                ++n_xl_rows;
+                                const bool in = lane < xm.x;
+                                const uint2 ent = xlist[(size_t)ra[q] * kDmXl + (in ? lane : 0u)];
+                                const float dac = __builtin_bit_cast(float, ent.y);
+                                const uint32_t j = pos[ent.x];
+                                const bool f = in && j >= rjmin[q] && j <= n - 2u && dac < rdab[q];
+                                const float dbe = rowb[f ? perm[j + 1u] : 0u];
+                                if (f && dac + dbe < rdab[q] + edge[j] && j < bj[q]) {
+                                    bj[q] = j;
+                                    bdac[q] = dac;
+                                    bdbe[q] = dbe;
+                                }
+                            } else if (!a_listed) {  // row a, every city as c: eight coalesced loads in flight, then the survivors' D[b][e] together
+                                ++n_full_rows;
+                                uint32_t xbase = 0u;
                                 for (uint32_t u0 = 0; u0 < n; u0 += 512u) {
                                     float va[8], wa[8];
                                     uint32_t ja[8];
@@ -470,9 +501,14 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
                                     for (int t = 0; t < 8; ++t) {
                                         const uint32_t u = u0 + 64u * (uint32_t)t + lane;
                                         ja[t] = pos[u < n ? u : 0u];
-                                        const bool f = u < n && ja[t] >= rjmin[q] && ja[t] <= n - 2u && va[t] < rdab[q];
+                                        const bool near = u < n && u != ra[q] && va[t] < rdab[q];  // (what the cache keeps: at any position)
+                                        const bool f = near && ja[t] >= rjmin[q] && ja[t] <= n - 2u;
                                         fa |= (f ? 1u : 0u) << t;
                                         wa[t] = rowb[f ? perm[ja[t] + 1u] : 0u];  // D[b][e]
+                                        const uint64_t nm = __builtin_amdgcn_ballot_w64(near);
+                                        const uint32_t at = xbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
+                                        if (near && at < kDmXl) xlist[(size_t)ra[q] * kDmXl + at] = make_uint2(u, __builtin_bit_cast(uint32_t, va[t]));
+                                        xbase += (uint32_t)__builtin_popcountll(nm);
                                     }
     #pragma unroll
                                     for (int t = 0; t < 8; ++t) {
@@ -483,8 +519,10 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
                                         }
                                     }
                                 }
+                                if (lane == 0) xmeta[ra[q]] = make_uint2(xbase <= kDmXl ? xbase : 0xFFFFFFFFu, __builtin_bit_cast(uint32_t, rdab[q]));
                             }
-                            if (!b_listed) {  // row b, every city as e (clustered instances: more than 48 cities hold b among their 16 nearest)
+                            if (!b_listed) {
+                                ++n_full_rows;  // row b, every city as e (clustered instances: more than 48 cities hold b among their 16 nearest)
                                 for (uint32_t u0 = 0; u0 < n; u0 += 256u) {
                                     float vb[4], wb[4];
                                     uint32_t jb2[4];
@@ -822,6 +860,7 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
         st[5] = n_late_steps;   // steps, sweeps begun on the lists, rows of those that walked their matrix rows (wave 0's)
         st[6] = n_late_sweeps;
         st[7] = n_full_rows;
+        st[8] = n_xl_rows;      // ... and rows that read a's cached record instead
         st[15] = log_n;  // words offered to the move log (moves + sweep marks)
 #ifdef TL_DM_PROFILE
         printf("dmprof late: lists A/B %lu long C %lu rows+post %lu rest %lu wait %lu apply %lu steps %lu grabs %lu matrix-row rows %u\n", qd[16], qd[17], qd[22], qd[18], qd[19], qd[20], qd[21], qd[23], n_full_rows);
@@ -852,9 +891,11 @@ size_t dm_lists_ws_bytes(uint32_t n)
     return al256((size_t)n * kDmK * 2) + al256((size_t)n * kDmK * 4) + al256((size_t)n * 4) + al256((size_t)n * kDmInv * 2) +
            al256((size_t)n * kDmInv * 4) + al256((size_t)n * 4);
 }
+size_t two_opt_ref_dm_late_work_bytes(uint32_t n, uint32_t count) { return (size_t)count * n * (kDmXl + 1u) * 8u; }
 bool two_opt_ref_dm_late_fits(uint32_t n, int lds_budget)
 {
-    return n >= 8u && two_opt_ref_dm_lds_bytes(n) + two_opt_ref_dm_late_bytes(n) <= (size_t)lds_budget;
+    // (n <= 16384: the late sweeps address the matrix and the lists with 32-bit byte offsets; the LDS budget is the tighter bound on gfx950)
+    return n >= 8u && n <= 16384u && two_opt_ref_dm_lds_bytes(n) + two_opt_ref_dm_late_bytes(n) <= (size_t)lds_budget;
 }
 hipError_t launch_dm_lists_build(const float *full, uint32_t n, void *ws, DmLists *out, hipStream_t s)
 {
