@@ -76,6 +76,8 @@ __global__ __launch_bounds__(256) void k_dm_expand_full(const float *__restrict_
 // improving (two_opt.rs:49: D[a][c] + D[b][e] < D[a][b] + D[c][e]) implies D[a][c] < D[a][b] or D[b][e] < D[c][e], since an f32
 // sum is monotone in both terms; with D[a][b] <= dk[a] the first puts c among a's kDmK nearest, with D[c][e] <= dk[e] the
 // second puts b among e's (the matrix is symmetric: it was expanded from the packed triangle), i.e. e in b's reverse list.
+// PER > 0: the row's n <= 64 * PER distances stay in registers over the 16 walks; PER = 0: they are read again each time.
+template <int PER>
 __global__ __launch_bounds__(256) void k_dm_lists(const float *__restrict__ full, uint32_t n, uint16_t *__restrict__ id, float *__restrict__ dl,
                                                   float *__restrict__ dk, uint16_t *__restrict__ inv_id, float *__restrict__ inv_d,
                                                   uint32_t *__restrict__ inv_cnt)
@@ -83,36 +85,65 @@ __global__ __launch_bounds__(256) void k_dm_lists(const float *__restrict__ full
     const uint32_t a = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (a >= n) return;
     const float *__restrict__ row = full + (size_t)a * n;
-    unsigned long long prev = 0ull;
+    constexpr int NR = PER > 0 ? PER : 1;
+    uint32_t kv[NR];  // order-preserving keys of this lane's distances (0xFFFFFFFF: no city — a itself, or beyond n)
     bool nan = false;
+    if (PER > 0) {
+#pragma unroll
+        for (int t = 0; t < NR; ++t) {
+            const uint32_t c = lane + 64u * (uint32_t)t;
+            const float v = row[c < n ? c : 0u];
+            nan = nan || (c < n && c != a && v != v);
+            kv[t] = (c < n && c != a) ? fkey(v) : 0xFFFFFFFFu;  // (float order; -0 before +0, which compare equal: harmless)
+        }
+    }
+    // each walk takes the smallest (key, city) beyond the last one taken: the smallest key first (a DPP maximum of the complement), then
+    // the smallest city among the lanes that hold it
+    uint32_t pk = 0u, pc = 0u;
     float last = 0.0f;
     uint32_t taken = 0;
     for (uint32_t r = 0; r < (uint32_t)kDmK; ++r) {
-        unsigned long long best = ~0ull;
-        for (uint32_t c = lane; c < n; c += 64u) {
-            if (c == a) continue;
-            const float v = row[c];
-            if (r == 0u && v != v) nan = true;
-            const unsigned long long key = ((unsigned long long)fkey(v) << 32) | c;  // (float order; -0 before +0, which compare equal: harmless)
-            if ((r == 0u || key > prev) && key < best) best = key;
-        }
-        for (int o = 32; o >= 1; o >>= 1) {
-            const unsigned long long other = __shfl_xor(best, o, 64);
-            best = other < best ? other : best;
-        }
-        if (best == ~0ull) break;  // fewer than kDmK other cities
-        const uint32_t c = (uint32_t)best;
-        const float v = row[c];
-        if (lane == 0) {
-            id[(size_t)a * kDmK + r] = (uint16_t)c;
-            dl[(size_t)a * kDmK + r] = v;
-            const uint32_t slot = atomicAdd(&inv_cnt[c], 1u);
-            if (slot < (uint32_t)kDmInv) {
-                inv_id[(size_t)c * kDmInv + slot] = (uint16_t)a;
-                inv_d[(size_t)c * kDmInv + slot] = v;
+        uint32_t bk = 0xFFFFFFFFu, bc = 0xFFFFFFFFu;
+        if (PER > 0) {
+#pragma unroll
+            for (int t = 0; t < NR; ++t) {
+                const uint32_t c = lane + 64u * (uint32_t)t, k = kv[t];
+                const bool beyond = r == 0u || k > pk || (k == pk && c > pc);
+                const bool better = k < bk;  // (a lane's cities come in ascending order: the first of equal keys stays)
+                if (k != 0xFFFFFFFFu && beyond && better) {
+                    bk = k;
+                    bc = c;
+                }
+            }
+        } else {
+            for (uint32_t c = lane; c < n; c += 64u) {
+                if (c == a) continue;
+                const float v = row[c];
+                if (r == 0u && v != v) nan = true;
+                const uint32_t k = fkey(v);
+                const bool beyond = r == 0u || k > pk || (k == pk && c > pc);
+                if (beyond && k < bk) {
+                    bk = k;
+                    bc = c;
+                }
             }
         }
-        prev = best;
+        const uint32_t mk = ~rl_u(wave_max_key_lane63(~bk), 63u);
+        // (a lane without a candidate holds bc = 0xFFFFFFFF; a candidate's key can be 0xFFFFFFFF only for a NaN pattern, whose rows are never listed)
+        const uint32_t mc = ~rl_u(wave_max_key_lane63((bk == mk && bc != 0xFFFFFFFFu) ? ~bc : 0u), 63u);
+        if (mc == 0xFFFFFFFFu) break;  // fewer than kDmK other cities
+        const float v = row[mc];
+        if (lane == 0) {
+            id[(size_t)a * kDmK + r] = (uint16_t)mc;
+            dl[(size_t)a * kDmK + r] = v;
+            const uint32_t slot = atomicAdd(&inv_cnt[mc], 1u);
+            if (slot < (uint32_t)kDmInv) {
+                inv_id[(size_t)mc * kDmInv + slot] = (uint16_t)a;
+                inv_d[(size_t)mc * kDmInv + slot] = v;
+            }
+        }
+        pk = mk;
+        pc = mc;
         last = v;
         ++taken;
     }
@@ -170,27 +201,6 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
     if (tid < 4) keys[tid] = kNoKey;
     TL_SYNC();
     for (uint32_t k = tid; k + 1u < n; k += kDmNT) edge[k] = dm[(size_t)perm[k] * n + perm[k + 1u]];
-    if ((size_t)n * n * 4u <= kDmWarmBytes) {
-        // The descent touches a matrix row for the first time almost every step of its first sweep (row a of every i, the row of
-        // every move's new b), and a first touch is a miss of this XCD's L2 — k_dm_expand_full ran on all of them — i.e. a round
-        // trip to the Infinity Cache / HBM in front of a step.  So stream the matrix through once (4 MB at n = 1002: ~30 us).
-        const float4 *__restrict__ m4 = reinterpret_cast<const float4 *>(dm);
-        const size_t n4 = (size_t)n * n / 4u;
-        float acc = 0.0f;
-        for (size_t k = tid; k < n4; k += kDmNT) {
-            const float4 v = m4[k];
-            acc += (v.x + v.y) + (v.z + v.w);
-        }
-        if (LATE) {  // ... and the lists behind it (one buffer: ids, distances, bounds, reverse lists, counts)
-            const float4 *__restrict__ l4 = reinterpret_cast<const float4 *>(A.dml.id);
-            const size_t nl4 = (size_t)(reinterpret_cast<const unsigned char *>(A.dml.inv_cnt + n) - reinterpret_cast<const unsigned char *>(A.dml.id)) / 16u;
-            for (size_t k = tid; k < nl4; k += kDmNT) {
-                const float4 v = l4[k];
-                acc += (v.x + v.y) + (v.z + v.w);
-            }
-        }
-        if (acc == -1.0f) keys[3] = 0u;  // (never taken for the distances, which are >= 0; either way it only keeps the loads)
-    }
     TL_SYNC();
 
     const uint32_t nrows = n - 3;
@@ -261,6 +271,29 @@ __global__ __launch_bounds__(kDmNT) void k_two_opt_ref_dm(TwoOptBatchArgs A)
         TL_SYNC();
         if (n >= 4) sweep_begin(0xFFFFFFFFu);
     }
+    if ((size_t)n * n * 4u <= kDmWarmBytes) {
+        // The descent touches a matrix row for the first time almost every step of its first sweep (row a of every i, the row of
+        // every move's new b), and a first touch is a miss of this XCD's L2 — k_dm_expand_full ran on all of them — i.e. a round
+        // trip to the Infinity Cache / HBM in front of a step.  So stream the matrix through once (4 MB at n = 1002: ~30 us).
+        // (A descent whose first sweep already runs on the lists — an NN tour — touches few matrix entries: it warms the lists only.)
+        const float4 *__restrict__ m4 = reinterpret_cast<const float4 *>(dm);
+        const size_t n4 = late ? 0u : (size_t)n * n / 4u;
+        float acc = 0.0f;
+        for (size_t k = tid; k < n4; k += kDmNT) {
+            const float4 v = m4[k];
+            acc += (v.x + v.y) + (v.z + v.w);
+        }
+        if (LATE) {  // ... and the lists behind it (one buffer: ids, distances, bounds, reverse lists, counts)
+            const float4 *__restrict__ l4 = reinterpret_cast<const float4 *>(A.dml.id);
+            const size_t nl4 = (size_t)(reinterpret_cast<const unsigned char *>(A.dml.inv_cnt + n) - reinterpret_cast<const unsigned char *>(A.dml.id)) / 16u;
+            for (size_t k = tid; k < nl4; k += kDmNT) {
+                const float4 v = l4[k];
+                acc += (v.x + v.y) + (v.z + v.w);
+            }
+        }
+        if (acc == -1.0f) keys[3] = 0u;  // (never taken for the distances, which are >= 0; either way it only keeps the loads)
+    }
+    TL_SYNC();
 
 #ifdef TL_DM_PROFILE
     uint64_t qd[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // wave 0's cycles in dense steps: row set-up, first decision, chain, barrier wait, boundary + reversals, [5] steps; wide steps from [8]: staging, -, scan, ...
@@ -915,7 +948,8 @@ hipError_t launch_dm_lists_build(const float *full, uint32_t n, void *ws, DmList
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(inv_cnt, 0, (size_t)n * 4, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_dm_lists, dim3((n + 3u) / 4u), dim3(256), 0, s, full, n, id, d, dk, inv_id, inv_d, inv_cnt);
+    auto kern = n <= 1024u ? k_dm_lists<16> : n <= 2048u ? k_dm_lists<32> : k_dm_lists<0>;
+    hipLaunchKernelGGL(kern, dim3((n + 3u) / 4u), dim3(256), 0, s, full, n, id, d, dk, inv_id, inv_d, inv_cnt);
     out->id = id;
     out->d = d;
     out->dk = dk;
