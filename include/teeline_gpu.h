@@ -42,7 +42,8 @@
 extern "C" {
 #endif
 
-#define TL_ABI_VERSION 5
+#define TL_ABI_VERSION 5 /* bumped when an existing entry point, struct or code changes meaning; additions (round 5: tl_multistart_shard,
+                            tl_two_opt_last_counters, new tl_create flags, k <= 64) leave it — a caller built against 5 runs unchanged */
 
 typedef struct tl_ctx tl_ctx;
 
