@@ -70,8 +70,9 @@ static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uin
         int rc2;
         // ... and, where the descents' late sweeps can use them, the lists cut from it (two_opt_dm.hip: the 16 nearest per city and the
         // reverse relation, one pass of a wave per matrix row), behind the matrix in the same buffer
+        // (the descents' per-city records are 264 bytes per city and descent: a batch that would need more than 8 GB of them runs without lists)
         const bool lists = !(c->flags & (TL_FLAG_NO_PRUNE | TL_FLAG_2OPT_NO_NL)) && (n >= TL_DM_LISTS_MIN_N || (c->flags & TL_FLAG_2OPT_NL_ALWAYS)) &&
-                           two_opt_ref_dm_late_fits(n, c->lds_bytes);
+                           two_opt_ref_dm_late_fits(n, c->lds_bytes) && two_opt_ref_dm_late_work_bytes(n, count) <= ((size_t)8 << 30);
         const size_t full_bytes = ((size_t)n * n * 4 + 255u) & ~(size_t)255u;
         if ((rc2 = ensure(c, c->dmfull, full_bytes + (lists ? dm_lists_ws_bytes(n) : 0u)))) return rc2;
         HIPCHK(c, launch_dm_expand_full(d_dm, n, (float *)c->dmfull.p, s));
