@@ -139,3 +139,17 @@ def test_population_of_tours_on_one_matrix(forms):
         for init, s in zip(pop, sols):
             rc, p, c, st = O.two_opt(None, packed, n, init=np.asarray(init, np.uint32))
             assert list(s.route()) == p.tolist() and np.float32(s.total).tobytes() == np.float32(c).tobytes()
+
+
+def test_last_counters_before_any_call_and_after_a_coordinate_call():
+    """tl_two_opt_last_counters: an error on a context that has not run a 2-opt call yet; after a coordinate-form call the first five
+    words are that descent's sweeps, moves, reversed elements, status and steps."""
+    import teeline_amd as TA
+    with TA.Context(0) as c:
+        with pytest.raises(TA.TeelineGpuError):
+            c.two_opt_last_counters()
+        n = 300
+        xy = O.synth_xy(n, seed=2)
+        sol = TA.two_opt.solve(TA.TspProblem(np.arange(n), xy), None, None, None, ctx=c)
+        cnt = c.two_opt_last_counters()
+        assert cnt[0] == sol.stats["sweeps"] and cnt[1] == sol.stats["moves"] and cnt[3] == 0 and cnt[4] > 0
