@@ -968,7 +968,7 @@ def main():
                                   "best_cost": float(min(float(s_.total) for s_ in sb))}
                 assert big["with_lists"]["best_cost"] == big["without_lists"]["best_cost"]
                 cfg1["population_256_n3000"] = big
-            cfg1["lists_note"] = ("sweeps that follow one with at most n^2 / 4000 moves, while at most 256 cities have a tour edge beyond their 16th-nearest distance, "
+            cfg1["lists_note"] = ("sweeps that follow one with at most n^2 / 4000 moves, while at most 1024 cities have a tour edge beyond their 16th-nearest distance, "
                                   "decide a row from a's 16 nearest, b's reverse list and the long cities (DESIGN.md §4.4); same tours, asserted")
             extras["two_opt_matrix_in_hbm_n1002"] = cfg1
             n3 = 1002

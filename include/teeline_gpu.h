@@ -94,7 +94,7 @@ typedef enum tl_mode {
                                               n = 200, a sweep that follows one with at most n^2 / 4000 moves decides a row from a's 16 nearest cities, b's
                                               reverse list and the cities with a long tour edge, csrc/two_opt_dm.hip; same tours either way)                  */
 #define TL_FLAG_2OPT_NL_ALWAYS (1u << 19)  /* LDS 2-opt: neighbour-list rows at every n they fit and from the second sweep on; matrix form: list
-                                              rows at every n >= 8 and in every sweep that has at most 256 cities with a long tour edge              */
+                                              rows at every n >= 8 and in every sweep that has at most 1024 cities with a long tour edge              */
 #define TL_FLAG_LK_CHIP_WIDE (1u << 20)    /* tl_lk: chip-wide scans at every n (default: an instance whose search state fits one CU's LDS runs its
                                               lk_pass in ONE workgroup with all state in LDS, k_lk_ils in csrc/lk.hip — up to n = 700, and wherever
                                               it fits (n ~ 3000) with epochs and platoo_epochs >= 64)                                            */

@@ -12,7 +12,7 @@ using namespace tlapi;
 #define TL_DM_LISTS_MIN_N 200u  // matrix form: smallest instance whose descents build and read the lists of the late sweeps
 #endif
 #ifndef TL_DM_LONG_MAX
-#define TL_DM_LONG_MAX 256u  // ... a sweep runs on them while at most this many cities have a tour edge beyond their 16th distance (the descent's list holds 256)
+#define TL_DM_LONG_MAX 1024u  // ... a sweep runs on them while at most this many cities have a tour edge beyond their 16th distance (the descent's list holds 1024)
 #endif
 #ifndef TL_DM_MOVES_DIV
 #define TL_DM_MOVES_DIV 4000u  // ... and the sweep before it applied at most n^2 / 4000 moves: on the lists a sweep costs ~n rows + a step per move, in the
@@ -81,7 +81,7 @@ static int two_opt_enqueue(tl_ctx *c, const float2 *d_xy, const float *d_dm, uin
             if ((rc2 = ensure(c, c->dmx, two_opt_ref_dm_late_work_bytes(n, count)))) return rc2;  // (not c->work: tl_two_opt_trace keeps the move log there)
             A.work = (uint32_t *)c->dmx.p;
             HIPCHK(c, launch_dm_lists_build(A.dm_full, n, (unsigned char *)c->dmfull.p + full_bytes, &A.dml, s));
-            A.dml.long_max = (c->flags & TL_FLAG_2OPT_NL_ALWAYS) ? 256u : (uint32_t)TL_DM_LONG_MAX;
+            A.dml.long_max = (c->flags & TL_FLAG_2OPT_NL_ALWAYS) ? 1024u : (uint32_t)TL_DM_LONG_MAX;
             A.dml.moves_max = (c->flags & TL_FLAG_2OPT_NL_ALWAYS) ? 0xFFFFFFFFu : (uint32_t)((uint64_t)n * n / TL_DM_MOVES_DIV > 8u ? (uint64_t)n * n / TL_DM_MOVES_DIV : 8u);
 #ifdef TL_TUNE  // tuning builds only: the product library never reads the environment
             if (const char *e = getenv("TL_DM_LONG_MAX")) A.dml.long_max = (uint32_t)atoi(e);
