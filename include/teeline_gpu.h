@@ -91,7 +91,7 @@ typedef enum tl_mode {
 #define TL_FLAG_2OPT_NO_NL (1u << 18)      /* LDS 2-opt: never read neighbour lists — every pruned row walks its tiles (default: rows of the
                                               late sweeps (once a sweep has applied fewer than n / 40 moves) of an instance with n >= 400 read the lists, csrc/two_opt_nl.hip).
                                               Matrix form (dm_packed): never cut lists from the matrix rows — every row walks its matrix rows (default: from
-                                              n = 200, a sweep that follows one with at most n^2 / 4000 moves decides a row from a's 16 nearest cities, b's
+                                              n = 500, a sweep that follows one with at most n^2 / 4000 moves decides a row from a's 16 nearest cities, b's
                                               reverse list and the cities with a long tour edge, csrc/two_opt_dm.hip; same tours either way)                  */
 #define TL_FLAG_2OPT_NL_ALWAYS (1u << 19)  /* LDS 2-opt: neighbour-list rows at every n they fit and from the second sweep on; matrix form: list
                                               rows at every n >= 8 and in every sweep that has at most 1024 cities with a long tour edge              */

@@ -9,7 +9,8 @@ using namespace tlapi;
 #define TL_NL_MIN_N 400u  // smallest instance whose descents build and read the neighbour lists
 #endif
 #ifndef TL_DM_LISTS_MIN_N
-#define TL_DM_LISTS_MIN_N 200u  // matrix form: smallest instance whose descents build and read the lists of the late sweeps
+#define TL_DM_LISTS_MIN_N 500u  // matrix form: smallest instance whose descents build and read the lists of the late sweeps (n = 200 / 300: the lists
+                                // cost 3-20 % more than they save, n = 532: even, n = 1 002: -33 % from the NN tour; scripts/timing_dm_late.py)
 #endif
 #ifndef TL_DM_LONG_MAX
 #define TL_DM_LONG_MAX 1024u  // ... a sweep runs on them while at most this many cities have a tour edge beyond their 16th distance (the descent's list holds 1024)

@@ -54,7 +54,7 @@ with TA.Context(0) as ctx, TA.Context(0, TA.TL_FLAG_NO_PRUNE) as ctx2, TA.Contex
             dm = TA.distance_matrix.build(np.arange(n), xy, ctx=ctx)
             pm = TA.TspProblem(np.arange(n), xy, TA.distance_matrix.DistanceMatrix(n, dm.items, np.arange(n), "explicit"))
             cases.append(("matrix", pm, ctx))
-            cases.append(("matrix_nl", pm, ctx6))  # its late sweeps on lists wherever they fit (two_opt_dm.hip; by default from n = 200)
+            cases.append(("matrix_nl", pm, ctx6))  # its late sweeps on lists wherever they fit (two_opt_dm.hip; by default from n = 500)
         if os.environ.get("FUZZ_DM"):  # the matrix form only, every seed: the Euclidean matrix and a non-metric one (independent weights, ties)
             n = int(rng.integers(8, 1400))
             xy = np.ascontiguousarray(xy[:n] if len(xy) >= n else rng.random((n, 2)) * 1000, dtype=np.float32)
